@@ -1,0 +1,261 @@
+"""ORACLE-SIDE TEST INFRASTRUCTURE — CPU emulator of the engine program (ir.OP_DT records).
+
+Only tests/ may import this.  It executes a compiled `Program` op by op with numpy/torch on the CPU so that
+the *graph compiler* (BN folding, fusion, concat placement, channel padding, weight tiling, buffer
+allocation, attention matching) can be validated against oracle/net_ref.py without a GPU.  It doubles as
+the executable specification of what each HIP kernel must compute.  It is never used by the product path:
+vse_amd.engine refuses to run without the HIP library.
+
+Arithmetic: activations are held in fp32 unless `round_f16=True`, in which case every op output is rounded
+to fp16 exactly where the HIP kernels store fp16 (useful to predict the fp16 error budget).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import importlib
+ir = importlib.import_module("vse_amd.ir")
+
+
+def _act(x, code, a=0.0, b=0.0):
+    if code == ir.ACT_NONE:
+        return x
+    if code == ir.ACT_RELU:
+        return torch.relu(x)
+    if code == ir.ACT_HSWISH:
+        return x * torch.clamp(x + 3.0, 0.0, 6.0) / 6.0
+    if code == ir.ACT_SWISH:
+        return x * torch.sigmoid(x)
+    if code == ir.ACT_SIGMOID:
+        return torch.sigmoid(x)
+    if code == ir.ACT_HSIGMOID:
+        return torch.clamp(x * a + b, 0.0, 1.0)
+    raise ValueError(code)
+
+
+class Emulator:
+    def __init__(self, prog, round_f16=False):
+        self.prog = prog
+        self.round = round_f16
+        # round_f16: byte-exact fp16 workspace.  otherwise: fp32 shadow with one float per 2 bytes.
+        # poisoned with NaN: pad channels / stale buffers must never leak into results
+        if round_f16:
+            self.ws = np.zeros(prog.ws_bytes, dtype=np.uint8)
+            self.ws.view(np.uint16)[:] = 0x7E00
+        else:
+            self.ws = np.full(prog.ws_bytes // 2 + 2, np.nan, dtype=np.float32)
+        self.wblob = prog.weights.array()
+        self.ext = {}
+
+    # ---- view access -------------------------------------------------------------------------------
+    def _arena(self, v):
+        a = int(v["arena"])
+        if a == ir.ARENA_WS:
+            return self.ws
+        if a == ir.ARENA_W:
+            return self.wblob
+        return self.ext[a - ir.ARENA_EXT0]
+
+    def _shadow(self, v):
+        return (not self.round) and int(v["arena"]) == ir.ARENA_WS
+
+    def read(self, v):
+        """-> float32 torch tensor [n,h,w,c]"""
+        n, h, w, c, ld, es = (int(v[k]) for k in ("n", "h", "w", "c", "ld", "esize"))
+        arena = self._arena(v)
+        if self._shadow(v):
+            st = es // 2
+            idx = int(v["off"]) // 2 + (np.arange(n * h * w)[:, None] * ld + np.arange(c)[None, :]) * st
+            return torch.from_numpy(arena[idx].reshape(n, h, w, c).copy())
+        dt = np.float16 if es == 2 else np.float32
+        base = int(v["off"])
+        cnt = (n * h * w - 1) * ld + c
+        flat = arena[base:base + cnt * es].view(dt)
+        idx = (np.arange(n * h * w)[:, None] * ld + np.arange(c)[None, :])
+        return torch.from_numpy(flat[idx].astype(np.float32).reshape(n, h, w, c))
+
+    def write(self, v, t, as_int=False):
+        n, h, w, c, ld, es = (int(v[k]) for k in ("n", "h", "w", "c", "ld", "esize"))
+        arena = self._arena(v)
+        arr = t.detach().numpy().reshape(n * h * w, c)
+        if self._shadow(v):
+            st = es // 2
+            idx = int(v["off"]) // 2 + (np.arange(n * h * w)[:, None] * ld + np.arange(c)[None, :]) * st
+            arena[idx] = arr
+            return
+        dt = np.float16 if es == 2 else np.float32
+        base = int(v["off"])
+        cnt = (n * h * w - 1) * ld + c
+        flat = arena[base:base + cnt * es].view(dt)
+        idx = (np.arange(n * h * w)[:, None] * ld + np.arange(c)[None, :])
+        flat[idx] = arr.astype(dt)
+
+    def wread(self, off, count, dt):
+        return self.wblob[off:off + count * np.dtype(dt).itemsize].view(dt)
+
+    # ---- run -----------------------------------------------------------------------------------------
+    def run(self, x_nhwc8):
+        """x: float array [N,H,W,8] (fp16-representable).  Returns list of output arrays."""
+        prog = self.prog
+        self.ext[0] = np.ascontiguousarray(x_nhwc8.astype(np.float16)).view(np.uint8).reshape(-1)
+        for k, o in enumerate(prog.outputs):
+            self.ext[k + 1] = np.zeros(o["n"] * o["h"] * o["w"] * o["ld"] * o["esize"], dtype=np.uint8)
+        for r in prog.ops:
+            getattr(self, "_op%d" % int(r["kind"]))(r)
+        outs = []
+        for k, o in enumerate(prog.outputs):
+            outs.append(self.ext[k + 1].view(np.float32).reshape(o["n"], o["h"], o["w"], o["ld"]).copy())
+        return outs
+
+    @staticmethod
+    def _up(t, shift):
+        if shift == 0:
+            return t
+        s = 1 << shift
+        return t.repeat_interleave(s, dim=1).repeat_interleave(s, dim=2)
+
+    def _op1(self, r):   # CONV
+        p, f = r["p"], r["f"]
+        kh, kw, sh, sw, ph, pw = (int(p[i]) for i in range(6))
+        Np, Kp, cinp = int(p[ir.P_COUT]), int(p[ir.P_KTOT]), int(p[ir.P_CINP])
+        x = self._up(self.read(r["in0"]), int(p[ir.P_INSHIFT]))
+        assert x.shape[3] == cinp
+        wt = self.wread(int(r["w_off"]), (Kp // 32) * Np * 32, np.float16).astype(np.float32)
+        wmat = wt.reshape(Kp // 32, Np, 32).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]
+        w4 = torch.from_numpy(np.ascontiguousarray(wmat.reshape(Np, kh, kw, cinp).transpose(0, 3, 1, 2)))
+        bias = torch.from_numpy(self.wread(int(r["b_off"]), Np, np.float32).copy())
+        y = F.conv2d(x.permute(0, 3, 1, 2), w4, bias, (sh, sw), (ph, pw)).permute(0, 2, 3, 1)
+        y = _act(y, int(p[ir.P_ACT]), float(f[ir.FS_ACT_A]), float(f[ir.FS_ACT_B]))
+        y = y * float(f[ir.FS_POST_A]) + float(f[ir.FS_POST_B])
+        flags = int(r["flags"])
+        if flags & ir.F_PIXSHUF:
+            n, h, w, _ = y.shape
+            cp = Np // 4
+            y = y.reshape(n, h, w, 2, 2, cp).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, cp)
+        if flags & ir.F_RES:
+            res = self._up(self.read(r["in1"]), int(p[ir.P_RESSHIFT]))
+            y[..., :res.shape[3]] += res[..., :y.shape[3]]
+        y = _act(y, int(p[ir.P_ACT2]))
+        oc = int(r["out"]["c"])
+        self.write(r["out"], y[..., :oc] if y.shape[3] >= oc else F.pad(y, (0, oc - y.shape[3])))
+
+    def _op2(self, r):   # DWCONV
+        p, f = r["p"], r["f"]
+        kh, kw, sh, sw, ph, pw = (int(p[i]) for i in range(6))
+        x = self.read(r["in0"])
+        cp = x.shape[3]
+        wk = self.wread(int(r["w_off"]), kh * kw * cp, np.float16).astype(np.float32).reshape(kh, kw, cp)
+        w4 = torch.from_numpy(np.ascontiguousarray(wk.transpose(2, 0, 1)[:, None]))
+        bias = torch.from_numpy(self.wread(int(r["b_off"]), cp, np.float32).copy())
+        y = F.conv2d(x.permute(0, 3, 1, 2), w4, bias, (sh, sw), (ph, pw), groups=cp).permute(0, 2, 3, 1)
+        y = _act(y, int(p[ir.P_ACT]), float(f[ir.FS_ACT_A]), float(f[ir.FS_ACT_B]))
+        y = y * float(f[ir.FS_POST_A]) + float(f[ir.FS_POST_B])
+        self.write(r["out"], y)
+
+    def _op3(self, r):   # POOL
+        p = r["p"]
+        kh, kw, sh, sw, ph, pw = (int(p[i]) for i in range(6))
+        x = self.read(r["in0"]).permute(0, 3, 1, 2)
+        ceil = bool(p[ir.P_POOL_CEIL])
+        if p[ir.P_POOL_MAX]:
+            y = F.max_pool2d(x, (kh, kw), (sh, sw), (ph, pw), ceil_mode=ceil)
+        else:
+            y = F.avg_pool2d(x, (kh, kw), (sh, sw), (ph, pw), ceil_mode=ceil,
+                             count_include_pad=not bool(p[ir.P_POOL_EXCL]))
+        self.write(r["out"], y.permute(0, 2, 3, 1))
+
+    def _op4(self, r):   # GAP
+        x = self.read(r["in0"])
+        self.write(r["out"], x.mean((1, 2), keepdim=True))
+
+    def _op5(self, r):   # SCALE
+        x = self.read(r["in0"])
+        s = self.read(r["in1"])
+        y = x * s
+        if int(r["flags"]) & ir.F_RES:
+            y = y + x
+        self.write(r["out"], y)
+
+    def _op6(self, r):   # BINARY
+        p = r["p"]
+        x = self.read(r["in0"])
+        y = self._up(self.read(r["in1"]), int(p[ir.P_BIN_SHIFT]))
+        z = x * y if p[ir.P_BIN_MUL] else x + y
+        self.write(r["out"], _act(z, int(p[ir.P_BIN_ACT])))
+
+    def _op7(self, r):   # RESIZE
+        x = self._up(self.read(r["in0"]), int(r["p"][0]))
+        oc = int(r["out"]["c"])
+        self.write(r["out"], x[..., :oc])
+
+    def _op8(self, r):   # UNARY
+        f = r["f"]
+        x = self.read(r["in0"])
+        oc = int(r["out"]["c"])
+        x = x[..., :oc]
+        y = _act(x * float(f[ir.FS_PRE_A]) + float(f[ir.FS_PRE_B]), int(r["p"][0]), float(f[ir.FS_ACT_A]),
+                 float(f[ir.FS_ACT_B]))
+        self.write(r["out"], y * float(f[ir.FS_POST_A]) + float(f[ir.FS_POST_B]))
+
+    def _op9(self, r):   # LAYERNORM
+        x = self.read(r["in0"])
+        c = x.shape[3]
+        gb = self.wread(int(r["w_off"]), 2 * c, np.float32)
+        y = F.layer_norm(x, (c,), torch.from_numpy(gb[:c].copy()), torch.from_numpy(gb[c:].copy()),
+                         float(r["f"][ir.FS_EPS]))
+        self.write(r["out"], y)
+
+    def _op10(self, r):  # ATTN
+        heads, hd = int(r["p"][ir.P_HEADS]), int(r["p"][ir.P_HDIM])
+        scale = float(r["f"][ir.FS_SCALE])
+        x = self.read(r["in0"])                    # [B,1,T,3*C]
+        B, _, T, _ = x.shape
+        qkv = x.reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)   # [3,B,h,T,d]
+        q, k, v = qkv[0] * scale, qkv[1], qkv[2]
+        att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+        y = (att @ v).permute(0, 2, 1, 3).reshape(B, 1, T, heads * hd)
+        self.write(r["out"], y)
+
+    def _op11(self, r):  # SOFTMAX
+        ncls = int(r["p"][ir.P_NCLS])
+        x = self.read(r["in0"])[..., :ncls]
+        pr = torch.softmax(x, dim=-1)
+        mx, idx = pr.max(dim=-1)
+        n, h, w, _ = x.shape
+        out = np.zeros((n, h, w, 2), np.float32)
+        out[..., 0] = idx.numpy().astype(np.int32).view(np.float32) if False else 0
+        iv = r["out"]
+        arena = self._arena(iv)
+        base = int(iv["off"])
+        raw = arena[base:base + n * h * w * 8].view(np.int32).reshape(n, h, w, 2)
+        raw[..., 0] = idx.numpy().astype(np.int32)
+        raw[..., 1] = mx.numpy().astype(np.float32).view(np.int32)
+        if int(r["out2"]["n"]) > 0:
+            self.write(r["out2"], pr)
+
+    def _op12(self, r):  # LSTM (one direction of one layer); in0 = fp32 gate pre-activations [B,1,T,4H]
+        H = int(r["p"][ir.P_HID])
+        rev = bool(r["p"][ir.P_REVERSE])
+        g = self.read(r["in0"])
+        B, _, T, _ = g.shape
+        whh = torch.from_numpy(self.wread(int(r["w_off"]), H * 4 * H, np.float16).astype(np.float32).reshape(H, 4 * H))
+        h = torch.zeros(B, H)
+        c = torch.zeros(B, H)
+        out = torch.zeros(B, 1, T, H)
+        for t in (range(T - 1, -1, -1) if rev else range(T)):
+            z = g[:, 0, t] + h @ whh
+            i, f_, gg, o = z.chunk(4, dim=1)
+            c = torch.sigmoid(f_) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            if self.round:
+                h = h.half().float()
+            out[:, 0, t] = h
+        self.write(r["out"], out)
+
+
+def to_nhwc8(x_nchw):
+    """float32 NCHW [N,3,H,W] -> fp16-rounded float NHWC with 8 physical channels."""
+    n, c, h, w = x_nchw.shape
+    out = np.zeros((n, h, w, 8), np.float32)
+    out[..., :c] = np.transpose(np.asarray(x_nchw), (0, 2, 3, 1))
+    return out.astype(np.float16).astype(np.float32)

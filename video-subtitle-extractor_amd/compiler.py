@@ -1,0 +1,985 @@
+"""Graph compiler: model descriptor (+ fp32 weights) -> fused NHWC/fp16 engine program.
+
+Host-side only (numpy).  The output `Program` is what the C-ABI runtime executes: a flat array of
+`vse_op` records (ir.OP_DT), a packed weight blob and a workspace size.  Design points (MI355X-first,
+not a translation of the Paddle executor):
+
+  * activations are NHWC fp16 with channels padded to a multiple of 8, so every implicit-GEMM gather is
+    a 16-byte vector per (tap, 8-channel group); weights are pre-tiled [K/32][Cout][32] fp16 in exactly
+    the order the conv kernel streams them through LDS;
+  * batch-norm, conv bias and the PP-LCNetV3 "learnable affine" scalars before the activation are folded
+    into the weights/bias in fp32 at compile time; activation, post-activation affine, residual add
+    (optionally nearest-upsampled: FPN top-down adds) run in the conv epilogue;
+  * channel concatenation is free: producers write straight into channel slices of the concat buffer
+    (a view = buffer + channel offset + pixel stride);
+  * layout-only ops (flatten/transpose/reshape/squeeze between NCHW and [B,T,C]) vanish because
+    NHWC [B,1,T,C] *is* [B,T,C];
+  * SVTR attention sub-graphs are pattern-matched into one fused attention op; final class softmax is one
+    op that also emits argmax + max-prob for the CTC collapse;
+  * buffers are placed in one workspace arena by liveness (first-fit), sized for the batch.
+
+Reference call sites this replaces: the Paddle predictor `run()` inside paddleocr's TextDetector /
+TextRecognizer, reached from backend/tools/subtitle_detect.py:25 and backend/tools/ocr.py:27.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import ir
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------ views
+@dataclass
+class Buf:
+    id: int
+    n: int
+    h: int
+    w: int
+    ld: int
+    esize: int = 2
+    ext: Optional[int] = None      # external slot index (0 = input, 1.. = outputs) or None
+    first: int = 1 << 30
+    last: int = -1
+    offset: int = 0
+
+    @property
+    def nbytes(self):
+        return self.n * self.h * self.w * self.ld * self.esize
+
+
+@dataclass
+class View:
+    buf: Buf
+    coff: int                      # channel offset inside the buffer
+    n: int
+    h: int
+    w: int
+    segs: List[Tuple[int, int]]    # [(physical start relative to coff, logical count)]
+    span: int                      # physical channel span
+    up: int = 0                    # virtual nearest-upsample shift (logical h,w already upsampled)
+    tag: str = "nchw"              # logical layout of the Paddle tensor this view stands for
+
+    @property
+    def c(self):
+        return sum(s[1] for s in self.segs)
+
+    def chmap(self):
+        out = []
+        for st, cnt in self.segs:
+            out += list(range(st, st + cnt))
+        return np.asarray(out, dtype=np.int64)
+
+    @property
+    def src_h(self):
+        return self.h >> self.up
+
+    @property
+    def src_w(self):
+        return self.w >> self.up
+
+
+@dataclass
+class Program:
+    ops: np.ndarray                 # ir.OP_DT records
+    weights: "WeightStore"          # shared packed weight blob
+    ws_bytes: int
+    in_shape: Tuple[int, int, int, int]          # N,H,W,Cphys of the fp16 NHWC input
+    outputs: List[dict] = field(default_factory=list)   # [{name, n,h,w,c,ld,esize,kind}]
+    names: List[str] = field(default_factory=list)      # debug: op -> originating tensor name
+    gmacs: float = 0.0              # algorithmic MACs of conv/linear ops (for the roofline)
+
+
+class WeightStore:
+    """Packed weight blob shared by every plan compiled for one model (offsets are shape-independent)."""
+
+    def __init__(self):
+        self.blob = bytearray()
+        self.index = {}
+
+    def add(self, key, arr):
+        if key in self.index:
+            return self.index[key]
+        off = rup(len(self.blob), 256)
+        self.blob.extend(b"\0" * (off - len(self.blob)))
+        self.blob.extend(np.ascontiguousarray(arr).tobytes())
+        self.index[key] = off
+        return off
+
+    def array(self):
+        return np.frombuffer(bytes(self.blob), dtype=np.uint8).copy()
+
+
+# ------------------------------------------------------------------------------------------------ compiler
+_VIRTUAL = {"nearest_interp_v2", "flatten_contiguous_range", "transpose2", "reshape2", "squeeze2", "dropout",
+            "assign", "shape", "fill_constant", "fill_constant_batch_size_like", "scale_noop"}
+_ACTS = {"relu": ir.ACT_RELU, "hard_swish": ir.ACT_HSWISH, "swish": ir.ACT_SWISH, "sigmoid": ir.ACT_SIGMOID,
+         "hard_sigmoid": ir.ACT_HSIGMOID}
+
+
+class Compiler:
+    def __init__(self, desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True,
+                 store=None):
+        self.desc = desc
+        self.W = weights
+        self.ops = desc["ops"]
+        self.N, self.H, self.Wd = batch, height, width
+        self.fetch_cols = tuple(fetch_cols)
+        self.want_probs = want_probs
+        self.env: Dict[str, View] = {}
+        self.bufs: List[Buf] = []
+        self.ir_ops: List[dict] = []
+        self.store = store if store is not None else WeightStore()
+        self.done = set()
+        self.outputs = []
+        self.gmacs = 0.0
+        # producer / consumer maps
+        self.producer = {}
+        self.consumers = {}
+        for i, op in enumerate(self.ops):
+            for outs in op["out"].values():
+                for o in outs:
+                    self.producer.setdefault(o, i)
+            for ins in op["in"].values():
+                for n in ins:
+                    self.consumers.setdefault(n, []).append(i)
+        self._mark_live()
+        self._plan_concats()
+
+    # -------------------------------------------------------------------------------------------- helpers
+    def _mark_live(self):
+        """Dead-code elimination backwards from the requested fetch columns."""
+        need = set()
+        for op in self.ops:
+            if op["type"] == "fetch" and op["attrs"].get("col", 0) in self.fetch_cols:
+                need.add(op["in"]["X"][0])
+        self.live = [False] * len(self.ops)
+        for i in range(len(self.ops) - 1, -1, -1):
+            op = self.ops[i]
+            if op["type"] == "fetch":
+                self.live[i] = op["attrs"].get("col", 0) in self.fetch_cols
+                continue
+            outs = [o for v in op["out"].values() for o in v]
+            if any(o in need for o in outs):
+                self.live[i] = True
+                for v in op["in"].values():
+                    need.update(v)
+
+    def _live_consumers(self, name):
+        return [i for i in self.consumers.get(name, []) if self.live[i]]
+
+    def _plan_concats(self):
+        """tensor name -> (concat out name, physical channel offset) so producers write in place."""
+        self.placement = {}
+        self.concat_layout = {}
+        for i, op in enumerate(self.ops):
+            if op["type"] != "concat" or not self.live[i]:
+                continue
+            out = op["out"]["Out"][0]
+            self.concat_layout[out] = None   # resolved lazily when channel counts are known
+            for name in op["in"]["X"]:
+                if name not in self.placement and len([c for c in self.consumers.get(name, [])
+                                                        if self.ops[c]["type"] == "concat"]) == 1:
+                    self.placement[name] = out
+
+    def is_param(self, name):
+        return name in self.W
+
+    def new_buf(self, n, h, w, ld, esize=2, ext=None):
+        b = Buf(len(self.bufs), n, h, w, ld, esize, ext)
+        self.bufs.append(b)
+        return b
+
+    def _concat_buf(self, cname, n, h, w):
+        """Create the concat buffer once all input channel counts are known (they are: static shapes)."""
+        lay = self.concat_layout.get(cname)
+        if lay is not None:
+            return lay
+        op = self.ops[self.producer[cname]]
+        offs = []
+        tot = 0
+        for name in op["in"]["X"]:
+            c = self._static_channels(name)
+            offs.append((tot, c))
+            tot += rup(c, 8)
+        buf = self.new_buf(n, h, w, tot)
+        lay = {"buf": buf, "offs": offs, "inputs": list(op["in"]["X"])}
+        self.concat_layout[cname] = lay
+        return lay
+
+    def _static_channels(self, name):
+        """Logical channel count of a tensor from the descriptor's var shapes (NCHW dim 1)."""
+        if name in self.env:
+            return self.env[name].c
+        dims = self.desc["var_shapes"].get(name)
+        assert dims is not None and len(dims) == 4 and dims[1] > 0, (name, dims)
+        return dims[1]
+
+    def alloc_out(self, name, n, h, w, c, esize=2):
+        """Output view for tensor `name`; lands inside a concat buffer slice when planned so."""
+        cname = self.placement.get(name)
+        if cname is not None and esize == 2:
+            lay = self._concat_buf(cname, n, h, w)
+            b = lay["buf"]
+            if (b.n, b.h, b.w) == (n, h, w):
+                k = lay["inputs"].index(name)
+                off, cc = lay["offs"][k]
+                assert cc == c, (name, cc, c)
+                return View(b, off, n, h, w, [(0, c)], rup(c, 8))
+        span = rup(c, 8)
+        b = self.new_buf(n, h, w, span, esize)
+        return View(b, 0, n, h, w, [(0, c)], span)
+
+    def vrec(self, v: Optional[View]):
+        r = ir.empty_view()
+        if v is None:
+            return r
+        b = v.buf
+        r["off"] = v.coff * b.esize        # arena base added after allocation
+        r["arena"] = -1 - b.id             # patched after allocation
+        r["n"], r["h"], r["w"] = v.n, v.src_h, v.src_w
+        r["c"], r["ld"], r["esize"] = v.span, b.ld, b.esize
+        return r
+
+    def emit(self, kind, name, ins, out, flags=0, p=None, f=None, w_off=0, b_off=0, aux_off=0, out2=None):
+        idx = len(self.ir_ops)
+        rec = dict(kind=kind, name=name, flags=flags, p=dict(p or {}), f=dict(f or {}), ins=list(ins), out=out,
+                   out2=out2, w_off=w_off, b_off=b_off, aux_off=aux_off)
+        for v in list(ins) + [out, out2]:
+            if v is not None:
+                v.buf.first = min(v.buf.first, idx)
+                v.buf.last = max(v.buf.last, idx)
+        self.ir_ops.append(rec)
+        return rec
+
+    def add_weights(self, key, arr):
+        """Append to the weight blob (256-byte aligned); identical keys are shared across plans."""
+        return self.store.add(key, arr)
+
+    # -------------------------------------------------------------------------------------------- materialize
+    def materialize(self, v: View, name="mat"):
+        """Turn a virtual (upsampled) view into a real buffer."""
+        if v.up == 0:
+            return v
+        out = self.alloc_out("__mat_" + name, v.n, v.h, v.w, v.c)
+        if v.segs != [(0, v.c)]:
+            out = View(self.new_buf(v.n, v.h, v.w, v.span), 0, v.n, v.h, v.w, list(v.segs), v.span)
+        self.emit(ir.OP_RESIZE, name, [v], out, p={0: v.up})
+        return out
+
+    # -------------------------------------------------------------------------------------------- resolve
+    def resolve(self, name) -> Optional[View]:
+        """View for a tensor, looking through not-yet-visited layout-only producers."""
+        if name in self.env:
+            return self.env[name]
+        i = self.producer.get(name)
+        if i is None:
+            return None
+        op = self.ops[i]
+        if op["type"] in _VIRTUAL or (op["type"] == "scale" and self._scale_is_noop(op)):
+            if self._lower_virtual(i, dry=True):
+                return self.env.get(name)
+        return None
+
+    @staticmethod
+    def _scale_is_noop(op):
+        a = op["attrs"]
+        return abs(a.get("scale", 1.0) - 1.0) < 1e-12 and abs(a.get("bias", 0.0)) < 1e-12
+
+    def _lower_virtual(self, i, dry=False):
+        op = self.ops[i]
+        t = op["type"]
+        a = op["attrs"]
+        if t in ("shape", "fill_constant", "fill_constant_batch_size_like"):
+            self.done.add(i)
+            return True
+        inname = op["in"]["X"][0] if "X" in op["in"] else op["in"]["Input"][0]
+        src = self.resolve(inname)
+        if src is None:
+            return False
+        outname = op["out"]["Out"][0]
+        v = View(src.buf, src.coff, src.n, src.h, src.w, list(src.segs), src.span, src.up, src.tag)
+        if t == "nearest_interp_v2":
+            s = a["scale"]
+            assert s[0] == s[1] and s[0] in (2.0, 4.0, 8.0), s
+            sh = int(round(math.log2(s[0])))
+            v.up = src.up + sh
+            v.h, v.w = src.h << sh, src.w << sh
+        elif t == "flatten_contiguous_range":
+            assert src.tag == "nchw" and src.h == 1 and a["start_axis"] == 2
+            v.tag = "bct"
+        elif t == "squeeze2":
+            assert src.tag == "nchw" and src.h == 1 and a["axes"] == [2]
+            v.tag = "bct"
+        elif t == "transpose2":
+            perm = tuple(a["axis"])
+            trans = {("bct", (0, 2, 1)): "btc", ("btc", (0, 2, 1)): "bct", ("bct", (2, 0, 1)): "tbc",
+                     ("tbc", (1, 0, 2)): "btc", ("btc", (1, 0, 2)): "tbc", ("b1tc", (0, 3, 1, 2)): "nchw"}
+            key = (src.tag, perm)
+            if key not in trans:
+                raise NotImplementedError(f"transpose2 {key} at op {i}")
+            v.tag = trans[key]
+        elif t == "reshape2":
+            # only the SVTR tail reshape [B,T,C] -> [B,1,T,C] reaches here (attention reshapes are matched
+            # inside _lower_attention)
+            assert src.tag == "btc", (src.tag, i)
+            v.tag = "b1tc"
+        elif t in ("dropout", "assign", "scale"):
+            pass
+        else:
+            raise NotImplementedError(t)
+        self.env[outname] = v
+        self.done.add(i)
+        return True
+
+    # -------------------------------------------------------------------------------------------- epilogue chain
+    def _scalar_param(self, name):
+        if self.is_param(name) and self.W[name].size == 1:
+            return float(self.W[name].reshape(-1)[0])
+        return None
+
+    def absorb_epilogue(self, start_name, i_prod, cout, allow_res=True, out_dims=None):
+        """Follow the single-consumer chain after a linear op and fold what the kernel epilogue can do.
+
+        Returns dict(scale[c], shift[c], act, act_a, act_b, post_a, post_b, res(View|None), res_first, act2,
+                     out_name)."""
+        scale = np.ones(cout, np.float64)
+        shift = np.zeros(cout, np.float64)
+        st = dict(act=ir.ACT_NONE, act_a=0.0, act_b=0.0, post_a=1.0, post_b=0.0, res=None, act2=ir.ACT_NONE)
+        name = start_name
+        stage = 0   # 0: pre-act affine, 1: post-act scalar affine, 2: after residual, 3: closed
+        while True:
+            cons = self._live_consumers(name)
+            if len(cons) != 1 or name in self.placement:
+                # a tensor that is a concat input may still be followed by fusable ops only if that consumer is
+                # the concat itself -> stop
+                break
+            j = cons[0]
+            op = self.ops[j]
+            t = op["type"]
+            a = op["attrs"]
+            if t in ("elementwise_add", "elementwise_mul"):
+                x, y = op["in"]["X"][0], op["in"]["Y"][0]
+                other = y if x == name else x
+                if self.is_param(other):
+                    pv = self.W[other].astype(np.float64).reshape(-1)
+                    if pv.size == 1:
+                        s = float(pv[0])
+                        if stage == 0:
+                            if t == "elementwise_mul":
+                                scale *= s
+                                shift *= s
+                            else:
+                                shift += s
+                        elif stage == 1:
+                            if t == "elementwise_mul":
+                                st["post_a"] *= s
+                                st["post_b"] *= s
+                            else:
+                                st["post_b"] += s
+                        else:
+                            break
+                    elif pv.size == cout and stage == 0:
+                        if t == "elementwise_mul":
+                            scale *= pv
+                            shift *= pv
+                        else:
+                            shift += pv
+                    else:
+                        break
+                elif t == "elementwise_add" and allow_res and stage <= 1 and st["res"] is None:
+                    rv = self.resolve(other)
+                    if rv is None or rv.tag not in ("nchw", "btc", "tbc") or rv.segs != [(0, cout)]:
+                        break
+                    if out_dims is not None and (rv.n, rv.h, rv.w) != tuple(out_dims):
+                        break
+                    st["res"] = rv
+                    stage = 2
+                else:
+                    break
+            elif t == "batch_norm" and stage == 0:
+                g = self.W[op["in"]["Scale"][0]].astype(np.float64)
+                b = self.W[op["in"]["Bias"][0]].astype(np.float64)
+                m = self.W[op["in"]["Mean"][0]].astype(np.float64)
+                var = self.W[op["in"]["Variance"][0]].astype(np.float64)
+                k = g / np.sqrt(var + a["epsilon"])
+                scale = scale * k
+                shift = (shift - m) * k + b
+                name = op["out"]["Y"][0]
+                self.done.add(j)
+                continue
+            elif t in _ACTS:
+                if stage == 0:
+                    st["act"] = _ACTS[t]
+                    if t == "hard_sigmoid":
+                        st["act_a"], st["act_b"] = a["slope"], a["offset"]
+                    stage = 1
+                elif stage == 2 and t == "relu":
+                    st["act2"] = ir.ACT_RELU
+                    stage = 3
+                else:
+                    break
+            elif t in ("dropout", "assign") or (t == "scale" and self._scale_is_noop(op)):
+                pass
+            else:
+                break
+            name = op["out"]["Out"][0]
+            self.done.add(j)
+        st.update(scale=scale, shift=shift, out_name=name)
+        return st
+
+    # -------------------------------------------------------------------------------------------- conv lowering
+    def pack_conv_weights(self, w, scale, inv: View, pixshuf=False):
+        """w: [Cout,Cin,kh,kw] fp32 (already transposed for convT).  Returns (blob fp16 [K/32][Np][32], Np, Kp)."""
+        cout, cin, kh, kw = w.shape
+        w = w.astype(np.float64) * scale.reshape(-1, 1, 1, 1)
+        cinp = inv.span
+        coutp = rup(cout, 8)
+        full = np.zeros((coutp, kh, kw, cinp), np.float64)
+        full[:cout][:, :, :, inv.chmap()] = np.transpose(w, (0, 2, 3, 1))
+        K = kh * kw * cinp
+        Kp = rup(K, 32)
+        mat = np.zeros((coutp, Kp), np.float64)
+        mat[:, :K] = full.reshape(coutp, K)
+        return mat, coutp, Kp
+
+    @staticmethod
+    def tile_weights(mat):
+        """[Np][Kp] -> [Kp/32][Np][32] fp16."""
+        npad, kp = mat.shape
+        t = mat.reshape(npad, kp // 32, 32).transpose(1, 0, 2)
+        return np.ascontiguousarray(t).astype(np.float16)
+
+    def lower_conv(self, i):
+        op = self.ops[i]
+        a = op["attrs"]
+        t = op["type"]
+        wname = op["in"]["Filter"][0]
+        w = self.W[wname]
+        inv = self.resolve(op["in"]["Input"][0])
+        assert inv is not None and inv.tag == "nchw", (i, op["in"])
+        outname = op["out"]["Output"][0]
+        sh, sw = a["strides"]
+        pads = a["paddings"]
+        ph, pw = (pads[0], pads[1]) if len(pads) == 2 else (pads[0], pads[2])
+        groups = a.get("groups", 1)
+        if t == "depthwise_conv2d" or (groups > 1 and groups == w.shape[0] and w.shape[1] == 1):
+            return self.lower_dwconv(i, inv, w, sh, sw, ph, pw)
+        assert groups == 1, "only dense and depthwise convs occur (SURVEY App. E)"
+        if t == "conv2d_transpose":
+            assert (sh, sw) == (2, 2) and w.shape[2:] == (2, 2) and (ph, pw) == (0, 0)
+            cin, cout = w.shape[0], w.shape[1]
+            ep = self.absorb_epilogue(outname, i, cout, allow_res=False)
+            inv = self.materialize(inv, outname)
+            coutp = rup(cout, 8)
+            # GEMM N ordered (dy,dx,co): W2[(dy,dx,co), ci]
+            w2 = np.zeros((4 * coutp, inv.span), np.float64)
+            wt = w.astype(np.float64) * ep["scale"].reshape(1, -1, 1, 1)
+            cm = inv.chmap()
+            for dy in range(2):
+                for dx in range(2):
+                    blk = np.zeros((coutp, inv.span))
+                    blk[:cout][:, cm] = wt[:, :, dy, dx].T
+                    w2[(dy * 2 + dx) * coutp:(dy * 2 + dx + 1) * coutp] = blk
+            Kp = rup(inv.span, 32)
+            mat = np.zeros((4 * coutp, Kp))
+            mat[:, :inv.span] = w2
+            bias = np.zeros(4 * coutp, np.float32)
+            for q in range(4):
+                bias[q * coutp:q * coutp + cout] = ep["shift"]
+            oh, ow = inv.h * 2, inv.w * 2
+            out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
+            w_off = self.add_weights(("convT", wname, tuple(inv.segs), ep["out_name"]), self.tile_weights(mat))
+            b_off = self.add_weights(("convTb", wname, ep["out_name"]), bias)
+            self.emit(ir.OP_CONV, ep["out_name"], [inv], out, flags=ir.F_PIXSHUF,
+                      p={ir.P_KH: 1, ir.P_KW: 1, ir.P_SH: 1, ir.P_SW: 1, ir.P_PH: 0, ir.P_PW: 0,
+                         ir.P_ACT: ep["act"], ir.P_ACT2: 0, ir.P_COUT: 4 * coutp, ir.P_KTOT: Kp,
+                         ir.P_INSHIFT: 0, ir.P_RESSHIFT: 0, ir.P_CINP: inv.span},
+                      f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
+                         ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
+            self.gmacs += inv.n * inv.h * inv.w * cin * cout * 4 / 1e9
+            self.env[ep["out_name"]] = out
+            return
+        cout, cin, kh, kw = w.shape
+        assert cin == inv.c, (cin, inv.c, outname)
+        oh = (inv.h + 2 * ph - kh) // sh + 1
+        ow = (inv.w + 2 * pw - kw) // sw + 1
+        ep = self.absorb_epilogue(outname, i, cout, out_dims=(inv.n, oh, ow))
+        mat, coutp, Kp = self.pack_conv_weights(w, ep["scale"], inv)
+        bias = np.zeros(coutp, np.float32)
+        bias[:cout] = ep["shift"]
+        out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
+        res = ep["res"]
+        flags = 0
+        ins = [inv]
+        resshift = 0
+        if res is not None:
+            assert (res.n, res.h, res.w, res.c) == (inv.n, oh, ow, cout), (outname, res, oh, ow, cout)
+            assert res.segs == [(0, cout)]
+            flags |= ir.F_RES
+            ins.append(res)
+            resshift = res.up
+        w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]), self.tile_weights(mat))
+        b_off = self.add_weights(("convb", wname, ep["out_name"]), bias)
+        self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
+                  p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
+                     ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"], ir.P_COUT: coutp, ir.P_KTOT: Kp,
+                     ir.P_INSHIFT: inv.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span},
+                  f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
+                     ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
+        self.gmacs += inv.n * oh * ow * cin * cout * kh * kw / 1e9
+        self.env[ep["out_name"]] = out
+
+    def lower_dwconv(self, i, inv, w, sh, sw, ph, pw):
+        op = self.ops[i]
+        outname = op["out"]["Output"][0]
+        wname = op["in"]["Filter"][0]
+        c, _, kh, kw = w.shape
+        assert c == inv.c and inv.segs == [(0, c)]
+        inv = self.materialize(inv, outname)
+        ep = self.absorb_epilogue(outname, i, c, allow_res=False)
+        oh = (inv.h + 2 * ph - kh) // sh + 1
+        ow = (inv.w + 2 * pw - kw) // sw + 1
+        cp = inv.span
+        wk = np.zeros((kh * kw, cp), np.float32)
+        wk[:, :c] = (w.astype(np.float64)[:, 0] * ep["scale"].reshape(-1, 1, 1)).reshape(c, kh * kw).T
+        bias = np.zeros(cp, np.float32)
+        bias[:c] = ep["shift"]
+        out = self.alloc_out(ep["out_name"], inv.n, oh, ow, c)
+        w_off = self.add_weights(("dw", wname, ep["out_name"]), wk.astype(np.float16))
+        b_off = self.add_weights(("dwb", wname, ep["out_name"]), bias)
+        self.emit(ir.OP_DWCONV, ep["out_name"], [inv], out,
+                  p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
+                     ir.P_ACT: ep["act"]},
+                  f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
+                     ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
+        self.gmacs += inv.n * oh * ow * c * kh * kw / 1e9
+        self.env[ep["out_name"]] = out
+
+    def lower_linear(self, i):
+        """matmul_v2 with a parameter RHS = 1x1 conv over [B,1,T,C]."""
+        op = self.ops[i]
+        x = self.resolve(op["in"]["X"][0])
+        wname = op["in"]["Y"][0]
+        w = self.W[wname]      # [in,out]
+        assert x is not None and x.tag in ("btc", "tbc"), (i, x and x.tag)
+        assert not op["attrs"].get("trans_x", False) and not op["attrs"].get("trans_y", False)
+        outname = op["out"]["Out"][0]
+        cin, cout = w.shape
+        assert cin == x.c
+        # attention qkv projection?  (linear -> reshape [0,-1,3,heads,hd])
+        ep = self.absorb_epilogue(outname, i, cout, out_dims=(x.n, x.h, x.w))
+        w4 = w.T.reshape(cout, cin, 1, 1)
+        mat, coutp, Kp = self.pack_conv_weights(w4, ep["scale"], x)
+        bias = np.zeros(coutp, np.float32)
+        bias[:cout] = ep["shift"]
+        out = self.alloc_out(ep["out_name"], x.n, x.h, x.w, cout)
+        out.tag = x.tag
+        ins = [x]
+        flags = 0
+        if ep["res"] is not None:
+            r = ep["res"]
+            assert (r.n, r.h, r.w, r.c) == (x.n, x.h, x.w, cout) and r.up == 0
+            ins.append(r)
+            flags |= ir.F_RES
+        w_off = self.add_weights(("lin", wname, tuple(x.segs), ep["out_name"]), self.tile_weights(mat))
+        b_off = self.add_weights(("linb", wname, ep["out_name"]), bias)
+        self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
+                  p={ir.P_KH: 1, ir.P_KW: 1, ir.P_SH: 1, ir.P_SW: 1, ir.P_PH: 0, ir.P_PW: 0,
+                     ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"], ir.P_COUT: coutp, ir.P_KTOT: Kp,
+                     ir.P_INSHIFT: 0, ir.P_RESSHIFT: 0, ir.P_CINP: x.span},
+                  f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
+                     ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
+        self.gmacs += x.n * x.h * x.w * cin * cout / 1e9
+        self.env[ep["out_name"]] = out
+
+    # -------------------------------------------------------------------------------------------- attention
+    def try_lower_attention(self, i):
+        """reshape2(qkv)[B,T,3,h,d] -> transpose -> slices -> scale -> q.kT -> softmax -> .v -> transpose ->
+        reshape [B,T,C]  ==> one OP_ATTN.  Returns True when matched."""
+        op = self.ops[i]
+        src = self.resolve(op["in"]["X"][0])
+        if src is None or src.tag != "btc":
+            return False
+        cons = self._live_consumers(op["out"]["Out"][0])
+        if len(cons) != 1 or self.ops[cons[0]]["type"] != "transpose2" or \
+                list(self.ops[cons[0]]["attrs"]["axis"]) != [2, 0, 3, 1, 4]:
+            return False
+        C3 = src.c
+        assert C3 % 3 == 0
+        C = C3 // 3
+        # walk forward collecting the block until the reshape back to [B,T,C]
+        j = cons[0]
+        heads = None
+        scale = None
+        visited = [i, j]
+        frontier = [self.ops[j]["out"]["Out"][0]]
+        end_name = None
+        seen = set()
+        while frontier:
+            nm = frontier.pop()
+            for k in self._live_consumers(nm):
+                if k in seen:
+                    continue
+                seen.add(k)
+                o = self.ops[k]
+                visited.append(k)
+                t = o["type"]
+                if t == "scale":
+                    scale = o["attrs"]["scale"]
+                if t == "reshape2" and k != i:
+                    end_name = o["out"]["Out"][0]
+                    continue
+                assert t in ("slice", "scale", "transpose2", "matmul_v2", "softmax", "dropout", "shape",
+                             "fill_constant"), (t, k)
+                frontier.append(o["out"]["Out"][0])
+        assert end_name is not None and scale is not None
+        hd = int(round(1.0 / (scale * scale)))
+        heads = C // hd
+        assert heads * hd == C, (C, hd)
+        for k in visited:
+            self.done.add(k)
+        # shape-tensor helper ops feeding the reshapes
+        qkv = self.materialize(src)
+        out = self.alloc_out(end_name, qkv.n, qkv.h, qkv.w, C)
+        out.tag = "btc"
+        self.emit(ir.OP_ATTN, end_name, [qkv], out, p={ir.P_HEADS: heads, ir.P_HDIM: hd}, f={ir.FS_SCALE: scale})
+        self.env[end_name] = out
+        return True
+
+    # -------------------------------------------------------------------------------------------- other ops
+    def lower_pool(self, i):
+        op = self.ops[i]
+        a = op["attrs"]
+        x = self.resolve(op["in"]["X"][0])
+        assert x is not None and x.tag == "nchw"
+        name = op["out"]["Out"][0]
+        x = self.materialize(x, name)
+        if a.get("adaptive", False) or a.get("global_pooling", False):
+            assert a["pooling_type"] == "avg" and (a.get("global_pooling", False) or list(a["ksize"]) == [1, 1])
+            out = self.alloc_out(name, x.n, 1, 1, x.c)
+            out.segs, out.span = list(x.segs), x.span
+            if out.buf.ld != x.span:
+                out = View(self.new_buf(x.n, 1, 1, x.span), 0, x.n, 1, 1, list(x.segs), x.span)
+            self.emit(ir.OP_GAP, name, [x], out)
+            self.env[name] = out
+            return
+        kh, kw = a["ksize"]
+        sh, sw = a["strides"]
+        pads = a["paddings"]
+        ph, pw = (pads[0], pads[1]) if len(pads) == 2 else (pads[0], pads[2])
+        ceil = bool(a.get("ceil_mode", False))
+
+        def osz(n, k, s, p):
+            if ceil:
+                o = -(-(n + 2 * p - k) // s) + 1
+                if (o - 1) * s >= n + p:
+                    o -= 1
+                return o
+            return (n + 2 * p - k) // s + 1
+        oh, ow = osz(x.h, kh, sh, ph), osz(x.w, kw, sw, pw)
+        assert x.segs == [(0, x.c)]
+        out = self.alloc_out(name, x.n, oh, ow, x.c)
+        self.emit(ir.OP_POOL, name, [x], out,
+                  p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
+                     ir.P_POOL_MAX: int(a["pooling_type"] == "max"), ir.P_POOL_CEIL: int(ceil),
+                     ir.P_POOL_EXCL: int(a.get("exclusive", True))})
+        self.env[name] = out
+
+    def lower_binary(self, i):
+        op = self.ops[i]
+        t = op["type"]
+        xn, yn = op["in"]["X"][0], op["in"]["Y"][0]
+        name = op["out"]["Out"][0]
+        if self.is_param(xn) or self.is_param(yn):
+            pn, tn = (xn, yn) if self.is_param(xn) else (yn, xn)
+            s = self._scalar_param(pn)
+            x = self.resolve(tn)
+            assert s is not None and x is not None, f"unfused non-scalar param {t} at op {i}"
+            x = self.materialize(x, name)
+            out = self.alloc_out(name, x.n, x.h, x.w, x.c)
+            out.tag = x.tag
+            a, b = (s, 0.0) if t == "elementwise_mul" else (1.0, s)
+            self.emit(ir.OP_UNARY, name, [x], out, p={0: ir.ACT_NONE},
+                      f={ir.FS_PRE_A: a, ir.FS_PRE_B: b, ir.FS_POST_A: 1.0, ir.FS_POST_B: 0.0})
+            self.env[name] = out
+            return
+        x, y = self.resolve(xn), self.resolve(yn)
+        assert x is not None and y is not None, (i, xn, yn)
+        if t == "elementwise_mul":
+            # SE gate: big [N,H,W,C] * gate [N,1,1,C]; optionally followed by "+ big" (residual SE)
+            if (y.h, y.w) == (1, 1):
+                big, gate, bigname = x, y, xn
+            else:
+                big, gate, bigname = y, x, yn
+            assert (gate.h, gate.w) == (1, 1) and gate.c == big.c, (i, x, y)
+            big = self.materialize(big, name)
+            flags = 0
+            outname = name
+            cons = self._live_consumers(name)
+            if len(cons) == 1 and name not in self.placement:
+                o2 = self.ops[cons[0]]
+                if o2["type"] == "elementwise_add" and bigname in (o2["in"]["X"][0], o2["in"]["Y"][0]):
+                    flags |= ir.F_RES
+                    outname = o2["out"]["Out"][0]
+                    self.done.add(cons[0])
+            assert big.segs == [(0, big.c)] and gate.segs == [(0, gate.c)]
+            out = self.alloc_out(outname, big.n, big.h, big.w, big.c)
+            self.emit(ir.OP_SCALE, outname, [big, gate], out, flags=flags)
+            self.env[outname] = out
+            return
+        # add of two activation tensors (y may be a virtual upsample of a coarser map)
+        if x.up and not y.up:
+            x, y = y, x
+        x = self.materialize(x, name)
+        assert (x.n, x.h, x.w, x.c) == (y.n, y.h, y.w, y.c), (i, x, y)
+        assert x.segs == [(0, x.c)] and y.segs == [(0, y.c)]
+        act = ir.ACT_NONE
+        outname = name
+        cons = self._live_consumers(name)
+        if len(cons) == 1 and name not in self.placement and self.ops[cons[0]]["type"] == "relu":
+            act = ir.ACT_RELU
+            outname = self.ops[cons[0]]["out"]["Out"][0]
+            self.done.add(cons[0])
+        out = self.alloc_out(outname, x.n, x.h, x.w, x.c)
+        out.tag = x.tag
+        self.emit(ir.OP_BINARY, outname, [x, y], out, p={ir.P_BIN_MUL: 0, ir.P_BIN_SHIFT: y.up, ir.P_BIN_ACT: act})
+        self.env[outname] = out
+
+    def lower_unary(self, i):
+        op = self.ops[i]
+        t = op["type"]
+        a = op["attrs"]
+        x = self.resolve(op["in"]["X"][0])
+        name = op["out"]["Out"][0]
+        x = self.materialize(x, name)
+        out = self.alloc_out(name, x.n, x.h, x.w, x.c)
+        out.tag = x.tag
+        f = {ir.FS_PRE_A: 1.0, ir.FS_PRE_B: 0.0, ir.FS_POST_A: 1.0, ir.FS_POST_B: 0.0}
+        act = ir.ACT_NONE
+        if t == "scale":
+            if a.get("bias_after_scale", True):
+                f[ir.FS_PRE_A], f[ir.FS_PRE_B] = a["scale"], a.get("bias", 0.0)
+            else:
+                f[ir.FS_PRE_A], f[ir.FS_PRE_B] = a["scale"], a.get("bias", 0.0) * a["scale"]
+        else:
+            act = _ACTS[t]
+            if t == "hard_sigmoid":
+                f[ir.FS_ACT_A], f[ir.FS_ACT_B] = a["slope"], a["offset"]
+        self.emit(ir.OP_UNARY, name, [x], out, p={0: act}, f=f)
+        self.env[name] = out
+
+    def lower_concat(self, i):
+        op = self.ops[i]
+        name = op["out"]["Out"][0]
+        assert op["attrs"]["axis"] == 1
+        ins = [self.resolve(n) for n in op["in"]["X"]]
+        assert all(v is not None for v in ins), (i, op["in"]["X"])
+        v0 = ins[0]
+        lay = self._concat_buf(name, v0.n, v0.h, v0.w)
+        b = lay["buf"]
+        segs = []
+        for nm, v, (off, c) in zip(op["in"]["X"], ins, lay["offs"]):
+            assert (v.n, v.h, v.w, v.c) == (b.n, b.h, b.w, c), (name, nm, v, c)
+            if not (v.buf is b and v.coff == off and v.up == 0):
+                dst = View(b, off, v.n, v.h, v.w, [(0, c)], rup(c, 8))
+                assert v.segs == [(0, c)]
+                self.emit(ir.OP_RESIZE, name + ":" + nm, [v], dst, p={0: v.up})
+            segs.append((off, c))
+        out = View(b, 0, v0.n, v0.h, v0.w, segs, b.ld)
+        self.env[name] = out
+
+    def lower_layernorm(self, i):
+        op = self.ops[i]
+        x = self.resolve(op["in"]["X"][0])
+        assert x.tag == "btc" and x.up == 0 and x.c == x.span
+        name = op["out"]["Y"][0]
+        g = self.W[op["in"]["Scale"][0]].astype(np.float32).reshape(-1)
+        b = self.W[op["in"]["Bias"][0]].astype(np.float32).reshape(-1)
+        out = self.alloc_out(name, x.n, x.h, x.w, x.c)
+        out.tag = "btc"
+        w_off = self.add_weights(("ln", op["in"]["Scale"][0]), np.concatenate([g, b]))
+        self.emit(ir.OP_LAYERNORM, name, [x], out, f={ir.FS_EPS: op["attrs"]["epsilon"]}, w_off=w_off)
+        self.env[name] = out
+
+    def lower_softmax_out(self, i):
+        """Final class softmax -> (probs f32 [B,T,C] optional, argmax i32 [B,T], maxp f32 [B,T])."""
+        op = self.ops[i]
+        x = self.resolve(op["in"]["X"][0])
+        assert x.tag == "btc" and x.up == 0
+        name = op["out"]["Out"][0]
+        ncls = x.c
+        B, T = x.n, x.w
+        pb = self.new_buf(B, 1, T, ncls, esize=4, ext=len(self.outputs) + 1) if self.want_probs else None
+        if pb is not None:
+            self.outputs.append(dict(name=name, kind="probs", n=B, h=1, w=T, c=ncls, ld=ncls, esize=4))
+        ib = self.new_buf(B, 1, T, 2, esize=4, ext=len(self.outputs) + 1)
+        self.outputs.append(dict(name=name + ":idx_maxp", kind="idx_maxp", n=B, h=1, w=T, c=2, ld=2, esize=4))
+        pv = View(pb, 0, B, 1, T, [(0, ncls)], ncls) if pb is not None else None
+        iv = View(ib, 0, B, 1, T, [(0, 2)], 2)
+        self.emit(ir.OP_SOFTMAX, name, [x], iv, p={ir.P_NCLS: ncls}, out2=pv)
+        self.env[name] = iv
+        self._fetched = name
+
+    def lower_rnn(self, i):
+        op = self.ops[i]
+        a = op["attrs"]
+        assert a["mode"] == "LSTM"
+        x = self.resolve(op["in"]["Input"][0])
+        assert x.tag == "tbc", x.tag
+        x = self.materialize(x)
+        H = a["hidden_size"]
+        ndir = 2 if a["is_bidirec"] else 1
+        L = a["num_layers"]
+        wl = op["in"]["WeightList"]
+        ncell = L * ndir
+        cur = x
+        name = op["out"]["Out"][0]
+        for layer in range(L):
+            outb = self.new_buf(cur.n, 1, cur.w, ndir * H)
+            for d in range(ndir):
+                c = layer * ndir + d
+                w_ih = self.W[wl[2 * c]].astype(np.float64)       # [4H,in]
+                w_hh = self.W[wl[2 * c + 1]].astype(np.float32)   # [4H,H]
+                b = (self.W[wl[2 * ncell + 2 * c]].astype(np.float64) +
+                     self.W[wl[2 * ncell + 2 * c + 1]].astype(np.float64))
+                # input projection for all T as one GEMM (fp32 output to keep gate pre-activations exact-ish)
+                mat, coutp, Kp = self.pack_conv_weights(w_ih.reshape(4 * H, -1, 1, 1), np.ones(4 * H), cur)
+                gb = self.new_buf(cur.n, 1, cur.w, 4 * H, esize=4)
+                gates = View(gb, 0, cur.n, 1, cur.w, [(0, 4 * H)], 4 * H)
+                key = f"{name}:l{layer}d{d}"
+                w_off = self.add_weights(("lstm_ih", wl[2 * c]), self.tile_weights(mat))
+                b_off = self.add_weights(("lstm_b", wl[2 * c]), b.astype(np.float32))
+                self.emit(ir.OP_CONV, key + ":proj", [cur], gates, flags=ir.F_OUT_F32,
+                          p={ir.P_KH: 1, ir.P_KW: 1, ir.P_SH: 1, ir.P_SW: 1, ir.P_PH: 0, ir.P_PW: 0,
+                             ir.P_ACT: 0, ir.P_ACT2: 0, ir.P_COUT: coutp, ir.P_KTOT: Kp, ir.P_INSHIFT: 0,
+                             ir.P_RESSHIFT: 0, ir.P_CINP: cur.span},
+                          f={ir.FS_POST_A: 1.0}, w_off=w_off, b_off=b_off)
+                self.gmacs += cur.n * cur.w * cur.c * 4 * H / 1e9
+                whh_off = self.add_weights(("lstm_hh", wl[2 * c + 1]), w_hh.T.copy().astype(np.float16))  # [H][4H]
+                ov = View(outb, d * H, cur.n, 1, cur.w, [(0, H)], H)
+                self.emit(ir.OP_LSTM, key, [gates], ov, p={ir.P_HID: H, ir.P_REVERSE: d}, w_off=whh_off)
+                self.gmacs += cur.n * cur.w * H * 4 * H / 1e9
+            cur = View(outb, 0, cur.n, 1, cur.w, [(0, ndir * H)], ndir * H, 0, "tbc")
+        self.env[name] = cur
+
+    # -------------------------------------------------------------------------------------------- driver
+    def compile(self) -> Program:
+        N, H, Wd = self.N, self.H, self.Wd
+        inb = self.new_buf(N, H, Wd, 8, ext=0)
+        for i, op in enumerate(self.ops):
+            if i in self.done or not self.live[i]:
+                continue
+            t = op["type"]
+            if t == "feed":
+                self.env[op["out"]["Out"][0]] = View(inb, 0, N, H, Wd, [(0, 3)], 8)
+            elif t == "fetch":
+                self._lower_fetch(i)
+            elif t in ("conv2d", "depthwise_conv2d", "conv2d_transpose"):
+                self.lower_conv(i)
+            elif t == "batch_norm":
+                raise NotImplementedError(f"stand-alone batch_norm at op {i}")
+            elif t == "pool2d":
+                self.lower_pool(i)
+            elif t in ("elementwise_add", "elementwise_mul"):
+                self.lower_binary(i)
+            elif t == "concat":
+                self.lower_concat(i)
+            elif t == "matmul_v2" or t == "matmul":
+                assert self.is_param(op["in"]["Y"][0]), f"free matmul outside attention at op {i}"
+                self.lower_linear(i)
+            elif t == "layer_norm":
+                self.lower_layernorm(i)
+            elif t == "softmax":
+                self.lower_softmax_out(i)
+            elif t == "rnn":
+                self.lower_rnn(i)
+            elif t == "reshape2":
+                if not self.try_lower_attention(i):
+                    assert self._lower_virtual(i), i
+            elif t in _ACTS or (t == "scale" and not self._scale_is_noop(op)):
+                self.lower_unary(i)
+            elif t in _VIRTUAL or t == "scale" or t == "slice":
+                if t == "slice":
+                    self.done.add(i)      # only shape-tensor plumbing reaches here
+                    continue
+                assert self._lower_virtual(i), (i, t)
+            else:
+                raise NotImplementedError(f"{t} at op {i}")
+        return self._finish()
+
+    def _lower_fetch(self, i):
+        op = self.ops[i]
+        name = op["in"]["X"][0]
+        v = self.resolve(name)
+        if v.buf.ext is not None:
+            return      # softmax head already wrote external outputs
+        # dense fp16 map [N,H,W,c]: copy/convert into an external fp32 buffer, channel-exact
+        v = self.materialize(v, name)
+        ob = self.new_buf(v.n, v.h, v.w, v.c, esize=4, ext=len(self.outputs) + 1)
+        self.outputs.append(dict(name=name, kind="map", n=v.n, h=v.h, w=v.w, c=v.c, ld=v.c, esize=4))
+        ov = View(ob, 0, v.n, v.h, v.w, [(0, v.c)], v.c)
+        self.emit(ir.OP_UNARY, "fetch:" + name, [v], ov, flags=ir.F_OUT_F32, p={0: ir.ACT_NONE},
+                  f={ir.FS_PRE_A: 1.0, ir.FS_PRE_B: 0.0, ir.FS_POST_A: 1.0, ir.FS_POST_B: 0.0})
+
+    def _allocate(self):
+        """First-fit offsets by liveness for workspace buffers."""
+        ws = [b for b in self.bufs if b.ext is None and b.last >= 0]
+        ws.sort(key=lambda b: (b.first, -b.nbytes))
+        placed = []   # (offset, size, first, last)
+        total = 0
+        for b in ws:
+            size = rup(b.nbytes, 256)
+            cands = sorted((p for p in placed if not (p[3] < b.first or p[2] > b.last)), key=lambda p: p[0])
+            off = 0
+            for p in cands:
+                if off + size <= p[0]:
+                    break
+                off = max(off, p[0] + p[1])
+            b.offset = off
+            placed.append((off, size, b.first, b.last))
+            total = max(total, off + size)
+        return total
+
+    def _finish(self) -> Program:
+        ws_bytes = self._allocate()
+        recs = np.zeros(len(self.ir_ops), dtype=ir.OP_DT)
+        names = []
+        for k, o in enumerate(self.ir_ops):
+            r = recs[k]
+            r["kind"] = o["kind"]
+            r["flags"] = o["flags"]
+            for idx, val in o["p"].items():
+                r["p"][idx] = val
+            for idx, val in o["f"].items():
+                r["f"][idx] = val
+            slots = ["in0", "in1", "in2"]
+            for s, v in zip(slots, o["ins"]):
+                r[s] = self._final_view(v)
+            r["out"] = self._final_view(o["out"])
+            if o["out2"] is not None:
+                r["out2"] = self._final_view(o["out2"])
+            r["w_off"], r["b_off"], r["aux_off"] = o["w_off"], o["b_off"], o["aux_off"]
+            names.append(o["name"])
+        return Program(ops=recs, weights=self.store, ws_bytes=int(ws_bytes), in_shape=(self.N, self.H, self.Wd, 8),
+                       outputs=self.outputs, names=names, gmacs=self.gmacs)
+
+    def _final_view(self, v: View):
+        r = self.vrec(v)
+        b = v.buf
+        if b.ext is None:
+            r["arena"] = ir.ARENA_WS
+            r["off"] = b.offset + v.coff * b.esize
+        else:
+            r["arena"] = ir.ARENA_EXT0 + b.ext
+            r["off"] = v.coff * b.esize
+        return r
+
+
+def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None):
+    return Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store).compile()

@@ -1,0 +1,81 @@
+"""Engine IR shared by the Python graph compiler and the C-ABI runtime (csrc/vse_runtime.hip).
+
+One `vse_op` record = one HIP kernel launch.  The record layout here MUST match `struct vse_op` in
+include/vse_hip.h (checked by tests/test_abi.py through vse_sizeof_op()).
+"""
+import numpy as np
+
+# op kinds ---------------------------------------------------------------------------------------
+OP_CONV = 1       # implicit-GEMM MFMA conv (also linear / 2x2 s2 transposed conv via pixel-shuffle store)
+OP_DWCONV = 2     # depthwise kxk conv
+OP_POOL = 3       # max / avg pooling window
+OP_GAP = 4        # global average pool -> [N,1,1,C]
+OP_SCALE = 5      # out = x * s[n,c]   (SE gate);  flag: + x (residual SE)
+OP_BINARY = 6     # out = act(x (+|*) up(y))
+OP_RESIZE = 7     # out = nearest-upsample(x)  (copy when shift == 0); writes into concat slices
+OP_UNARY = 8      # out = act(x*a+b)*a2+b2
+OP_LAYERNORM = 9  # over channels
+OP_ATTN = 10      # fused multi-head self-attention over T (SVTR mixer)
+OP_SOFTMAX = 11   # class softmax -> fp32 probs (optional) + argmax + max prob
+OP_LSTM = 12      # one direction of one LSTM layer (recurrent part; input projection is an OP_CONV)
+
+ACT_NONE, ACT_RELU, ACT_HSWISH, ACT_SWISH, ACT_SIGMOID, ACT_HSIGMOID = 0, 1, 2, 3, 4, 5
+
+# arenas -----------------------------------------------------------------------------------------
+ARENA_WS = 0       # activation workspace (caller-owned)
+ARENA_W = 1        # weights (library-owned, uploaded once)
+ARENA_EXT0 = 2     # external pointers passed to vse_plan_run(): 2 = input, 3.. = outputs
+
+VIEW_DT = np.dtype([
+    ("off", "<i8"),      # byte offset of element (n=0,h=0,w=0,c=0) inside the arena
+    ("arena", "<i4"),
+    ("n", "<i4"), ("h", "<i4"), ("w", "<i4"),
+    ("c", "<i4"),        # physical channel span of the view (multiple of 8 unless ld == 1)
+    ("ld", "<i4"),       # elements between consecutive pixels
+    ("esize", "<i4"),    # 2 = f16, 4 = f32/i32
+    ("pad", "<i4"),
+], align=False)
+
+OP_DT = np.dtype([
+    ("kind", "<i4"),
+    ("flags", "<i4"),
+    ("p", "<i4", (22,)),
+    ("f", "<f4", (8,)),
+    ("in0", VIEW_DT), ("in1", VIEW_DT), ("in2", VIEW_DT), ("out", VIEW_DT), ("out2", VIEW_DT),
+    ("w_off", "<i8"), ("b_off", "<i8"), ("aux_off", "<i8"),
+], align=False)
+
+# p[] slots for OP_CONV
+P_KH, P_KW, P_SH, P_SW, P_PH, P_PW = 0, 1, 2, 3, 4, 5
+P_ACT, P_ACT2 = 6, 7
+P_COUT = 8          # GEMM N (physical out channels incl. padding; x4 for pixel-shuffle)
+P_KTOT = 9          # padded K (multiple of 32)
+P_INSHIFT = 10      # nearest-upsample shift applied when gathering the input
+P_RESSHIFT = 11     # nearest-upsample shift applied when reading the residual
+P_CINP = 12         # physical input channels (multiple of 8)
+# flags for OP_CONV
+F_RES = 1           # has residual (in1)
+F_PIXSHUF = 2       # 2x2 stride-2 transposed conv: N = 4*Coutp ordered (dy,dx,co)
+F_OUT_F32 = 4       # store fp32
+# f[] slots (all kinds that carry an activation)
+FS_ACT_A, FS_ACT_B = 0, 1      # hard_sigmoid slope/offset
+FS_POST_A, FS_POST_B = 2, 3    # scalar affine after the activation
+FS_PRE_A, FS_PRE_B = 4, 5      # scalar affine before the activation (OP_UNARY)
+FS_EPS = 6
+FS_SCALE = 7
+
+# OP_POOL p[]: P_KH..P_PW as conv, then
+P_POOL_MAX, P_POOL_CEIL, P_POOL_EXCL = 6, 7, 8
+# OP_BINARY p[]
+P_BIN_MUL, P_BIN_SHIFT, P_BIN_ACT = 0, 1, 2
+# OP_SCALE flags: F_RES -> out = x + x*s
+# OP_ATTN p[]
+P_HEADS, P_HDIM = 0, 1
+# OP_SOFTMAX p[]
+P_NCLS = 0
+# OP_LSTM p[]
+P_HID, P_REVERSE = 0, 1
+
+
+def empty_view():
+    return np.zeros((), dtype=VIEW_DT)
