@@ -124,7 +124,7 @@ _ACTS = {"relu": ir.ACT_RELU, "hard_swish": ir.ACT_HSWISH, "swish": ir.ACT_SWISH
 
 class Compiler:
     def __init__(self, desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True,
-                 store=None):
+                 store=None, reuse=True):
         self.desc = desc
         self.W = weights
         self.ops = desc["ops"]
@@ -135,6 +135,7 @@ class Compiler:
         self.bufs: List[Buf] = []
         self.ir_ops: List[dict] = []
         self.store = store if store is not None else WeightStore()
+        self.reuse = reuse
         self.done = set()
         self.outputs = []
         self.gmacs = 0.0
@@ -666,7 +667,10 @@ class Compiler:
             out.segs, out.span = list(x.segs), x.span
             if out.buf.ld != x.span:
                 out = View(self.new_buf(x.n, 1, 1, x.span), 0, x.n, 1, 1, list(x.segs), x.span)
-            self.emit(ir.OP_GAP, name, [x], out)
+            splits = max(1, min(64, (x.h * x.w) // 2048))
+            sb = self.new_buf(x.n, splits, 1, x.span, esize=4)
+            scratch = View(sb, 0, x.n, splits, 1, [(0, x.span)], x.span)
+            self.emit(ir.OP_GAP, name, [x, None, scratch], out)
             self.env[name] = out
             return
         kh, kw = a["ksize"]
@@ -935,7 +939,8 @@ class Compiler:
         total = 0
         for b in ws:
             size = rup(b.nbytes, 256)
-            cands = sorted((p for p in placed if not (p[3] < b.first or p[2] > b.last)), key=lambda p: p[0])
+            cands = sorted((p for p in placed if not self.reuse or not (p[3] < b.first or p[2] > b.last)),
+                           key=lambda p: p[0])
             off = 0
             for p in cands:
                 if off + size <= p[0]:
@@ -960,7 +965,8 @@ class Compiler:
                 r["f"][idx] = val
             slots = ["in0", "in1", "in2"]
             for s, v in zip(slots, o["ins"]):
-                r[s] = self._final_view(v)
+                if v is not None:
+                    r[s] = self._final_view(v)
             r["out"] = self._final_view(o["out"])
             if o["out2"] is not None:
                 r["out2"] = self._final_view(o["out2"])
@@ -981,5 +987,6 @@ class Compiler:
         return r
 
 
-def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None):
-    return Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store).compile()
+def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True):
+    """reuse=False gives every buffer its own workspace range (debugging: all intermediates stay readable)."""
+    return Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse).compile()

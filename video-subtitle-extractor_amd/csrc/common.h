@@ -1,0 +1,49 @@
+// Shared device helpers for the vse HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vse_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_SWISH = 3, ACT_SIGMOID = 4, ACT_HSIGMOID = 5 };
+enum { OP_CONV = 1, OP_DWCONV, OP_POOL, OP_GAP, OP_SCALE, OP_BINARY, OP_RESIZE, OP_UNARY, OP_LAYERNORM, OP_ATTN,
+       OP_SOFTMAX, OP_LSTM };
+enum { F_RES = 1, F_PIXSHUF = 2, F_OUT_F32 = 4 };
+// p[] slots (keep in sync with ir.py)
+enum { P_KH = 0, P_KW, P_SH, P_SW, P_PH, P_PW, P_ACT, P_ACT2, P_COUT, P_KTOT, P_INSHIFT, P_RESSHIFT, P_CINP };
+enum { P_POOL_MAX = 6, P_POOL_CEIL = 7, P_POOL_EXCL = 8 };
+enum { FS_ACT_A = 0, FS_ACT_B, FS_POST_A, FS_POST_B, FS_PRE_A, FS_PRE_B, FS_EPS, FS_SCALE };
+
+__device__ __forceinline__ float vse_act(float x, int code, float a, float b) {
+    switch (code) {
+        case ACT_RELU: return fmaxf(x, 0.f);
+        case ACT_HSWISH: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+        case ACT_SWISH: return x / (1.f + __expf(-x));
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        case ACT_HSIGMOID: return fminf(fmaxf(x * a + b, 0.f), 1.f);
+        default: return x;
+    }
+}
+
+// Resolved (pointer-carrying) tensor view handed to kernels.
+struct TView {
+    char* ptr;
+    int n, h, w, c, ld, esize;
+};
+
+// Kernel launchers implemented in the .hip files; all enqueue on `st`.
+struct ConvArgs {
+    TView in, res, out;
+    const half_t* w;      // tiled [K/32][Np][32]
+    const float* bias;    // [Np]
+    int kh, kw, sh, sw, ph, pw, act, act2, Np, Kp, inshift, resshift, cinp, flags;
+    float act_a, act_b, post_a, post_b;
+};
+int launch_conv(const ConvArgs& a, hipStream_t st);
+int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const TView& in2, const TView& out,
+                     const TView& out2, const char* wbase, hipStream_t st);

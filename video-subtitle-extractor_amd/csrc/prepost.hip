@@ -1,0 +1,555 @@
+// Pre-/post-processing of the OCR hot path on the GPU (HBM-bound byte/integer work):
+//   det pre-process   uint8 BGR -> fixed-point bilinear resize -> normalise -> fp16 NHWC(8)
+//   DB post-process   threshold -> 8-connected components (atomic union-find) -> run end-points -> host
+//                     geometry (db_geometry.h) -> device polygon means -> host unclip/scale/filter
+//   rec pre-process   perspective bicubic crop from the original frame -> fixed-point bilinear resize to
+//                     height 48 -> normalise -> zero right-pad -> fp16 NHWC(8)
+//   CTC collapse      wavefront ballot scan over the arg-max sequence
+// These restate paddleocr 2.10 / OpenCV 4.11 behaviour as recalled in SURVEY.md App. C (not verifiable here).
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "db_geometry.h"
+
+extern "C" const char* vse_last_error(void);
+void vse_set_error(const char* msg);
+
+// ================================================================================================ bilinear (cv2)
+// OpenCV INTER_LINEAR for 8-bit images: 11-bit fixed-point coefficients, horizontal pass in int32, vertical
+// pass  ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2.
+struct LinCoef { int s0; short a0, a1; };
+__host__ __device__ inline LinCoef lin_coef(int d, int dst, int src) {
+    const double scale = (double)src / (double)dst;
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= src - 1) { f = 0.f; s = src - 1; }
+    LinCoef c;
+    c.s0 = s;
+    // cv::saturate_cast<short>(float) = round half to even
+    c.a0 = (short)rintf((1.f - f) * 2048.f);
+    c.a1 = (short)rintf(f * 2048.f);
+    return c;
+}
+__device__ __forceinline__ int cv_bilinear_u8(int p00, int p01, int p10, int p11, LinCoef cx, LinCoef cy) {
+    const int r0 = p00 * cx.a0 + p01 * cx.a1;
+    const int r1 = p10 * cx.a0 + p11 * cx.a1;
+    return ((((int)cy.a0 * (r0 >> 4)) >> 16) + (((int)cy.a1 * (r1 >> 4)) >> 16) + 2) >> 2;
+}
+
+__global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __restrict__ src, int n, int sh, int sw,
+                                                             long pitch, long fstride, half_t* __restrict__ dst, int dh,
+                                                             int dw, float m0, float m1, float m2, float sd0, float sd1,
+                                                             float sd2) {
+    const long total = (long)n * dh * dw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % dw);
+        const long t = i / dw;
+        const int y = (int)(t % dh);
+        const long f = t / dh;
+        const LinCoef cx = lin_coef(x, dw, sw), cy = lin_coef(y, dh, sh);
+        const int x1 = min(cx.s0 + 1, sw - 1), y1 = min(cy.s0 + 1, sh - 1);
+        const uint8_t* r0 = src + f * fstride + (long)cy.s0 * pitch;
+        const uint8_t* r1 = src + f * fstride + (long)y1 * pitch;
+        float v[3];
+        const float mean[3] = {m0, m1, m2}, sd[3] = {sd0, sd1, sd2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int u;
+            if (sw == dw && sh == dh) u = r0[cx.s0 * 3 + c];
+            else u = cv_bilinear_u8(r0[cx.s0 * 3 + c], r0[x1 * 3 + c], r1[cx.s0 * 3 + c], r1[x1 * 3 + c], cx, cy);
+            // paddleocr NormalizeImage: (img * (1/255) - mean) / std in float32
+            v[c] = ((float)u * (1.f / 255.f) - mean[c]) / sd[c];
+        }
+        half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], 0, 0, 0, 0, 0};
+        *reinterpret_cast<half8*>(dst + i * 8) = o;
+    }
+}
+
+extern "C" int vse_det_preprocess(vse_ctx*, const void* d_bgr, int n, int src_h, int src_w, int64_t pitch,
+                                  int64_t frame_stride, void* d_out, int dst_h, int dst_w, const float* mean3,
+                                  const float* std3, void* stream) {
+    if (!d_bgr || !d_out || n <= 0 || !mean3 || !std3) return VSE_E_INVAL;
+    const long total = (long)n * dst_h * dst_w;
+    int grid = (int)std::min<long>((total + 255) / 256, 65536);
+    hipLaunchKernelGGL(det_preprocess_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const uint8_t*>(d_bgr), n, src_h, src_w, (long)pitch, (long)frame_stride,
+                       reinterpret_cast<half_t*>(d_out), dst_h, dst_w, mean3[0], mean3[1], mean3[2], std3[0],
+                       std3[1], std3[2]);
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}
+
+// ================================================================================================ DB post-process
+// Labels are int32 pixel indices local to a frame (-1 = background).  Union-find with atomicMin: the root of a
+// component is its smallest pixel index = first pixel in raster order.
+__device__ __forceinline__ int uf_find(int* L, int a) {
+    int r = a;
+    while (true) {
+        const int p = L[r];
+        if (p == r) break;
+        r = p;
+    }
+    return r;
+}
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+    while (true) {
+        a = uf_find(L, a);
+        b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }   // a > b: hang a under b
+        const int old = atomicMin(&L[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void db_init_kernel(const float* __restrict__ prob, int* __restrict__ L, int n, int hw,
+                                                      float thresh) {
+    const long total = (long)n * hw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        L[i] = prob[i] > thresh ? (int)(i % hw) : -1;
+}
+__global__ __launch_bounds__(256) void db_merge_kernel(int* __restrict__ Lall, int n, int h, int w) {
+    const long hw = (long)h * w;
+    const long total = (long)n * hw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int* L = Lall + (i / hw) * hw;
+        const int p = (int)(i % hw);
+        if (L[p] < 0) continue;
+        const int x = p % w, y = p / w;
+        if (x > 0 && L[p - 1] >= 0) uf_union(L, p, p - 1);
+        if (y > 0) {
+            if (L[p - w] >= 0) uf_union(L, p, p - w);
+            if (x > 0 && L[p - w - 1] >= 0) uf_union(L, p, p - w - 1);
+            if (x < w - 1 && L[p - w + 1] >= 0) uf_union(L, p, p - w + 1);
+        }
+    }
+}
+// Emits one record per horizontal run END-POINT: {root, x | y << 16}.  cnt[f] counts records of frame f.
+__global__ __launch_bounds__(256) void db_runs_kernel(int* __restrict__ Lall, int n, int h, int w, int2* __restrict__ recs,
+                                                      int* __restrict__ cnt, int cap) {
+    const long hw = (long)h * w;
+    const long total = (long)n * hw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long f = i / hw;
+        int* L = Lall + f * hw;
+        const int p = (int)(i % hw);
+        if (L[p] < 0) continue;
+        const int x = p % w, y = p / w;
+        const bool left = (x == 0) || (L[p - 1] < 0);
+        const bool right = (x == w - 1) || (L[p + 1] < 0);
+        if (!(left || right)) continue;
+        const int root = uf_find(L, p);
+        const int slot = atomicAdd(&cnt[f], 1);
+        if (slot < cap) recs[f * cap + slot] = make_int2(root, x | (y << 16));
+    }
+}
+
+// Mean of prob over the lattice points inside (or on) a convex integer quad, restricted to its clipped bounding
+// rectangle — paddleocr box_score_fast (fillPoly mask + cv2.mean).  One block per candidate box.
+struct ScoreBox { int frame; int x0, y0, x1, y1; int qx[4], qy[4]; };
+__global__ __launch_bounds__(256) void db_score_kernel(const float* __restrict__ prob, int h, int w,
+                                                       const ScoreBox* __restrict__ boxes, float* __restrict__ out) {
+    __shared__ double ssum[256];
+    __shared__ int scnt[256];
+    const ScoreBox b = boxes[blockIdx.x];
+    const float* P = prob + (long)b.frame * h * w;
+    const int bw = b.x1 - b.x0 + 1, bh = b.y1 - b.y0 + 1;
+    double sum = 0.0;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < bw * bh; i += blockDim.x) {
+        const int lx = i % bw, ly = i / bw;   // mask-local coordinates (the quad is given mask-local too)
+        bool pos = true, neg = true;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ax = b.qx[e], ay = b.qy[e], bx = b.qx[(e + 1) & 3], by = b.qy[(e + 1) & 3];
+            const long cr = (long)(bx - ax) * (ly - ay) - (long)(by - ay) * (lx - ax);
+            pos &= (cr >= 0);
+            neg &= (cr <= 0);
+        }
+        if (pos || neg) {
+            sum += (double)P[(long)(b.y0 + ly) * w + b.x0 + lx];
+            ++cnt;
+        }
+    }
+    ssum[threadIdx.x] = sum;
+    scnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { ssum[threadIdx.x] += ssum[threadIdx.x + s]; scnt[threadIdx.x] += scnt[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = scnt[0] ? (float)(ssum[0] / scnt[0]) : 0.f;
+}
+
+#define DB_RUN_CAP 32768   // run end-point records per frame
+
+extern "C" size_t vse_db_workspace_bytes(int n, int h, int w) {
+    size_t b = (size_t)n * h * w * sizeof(int);          // labels
+    b += (size_t)n * DB_RUN_CAP * sizeof(int2);          // run records
+    b += (size_t)n * sizeof(int) + 256;                  // counters
+    b += (size_t)n * 1024 * (sizeof(ScoreBox) + sizeof(float)) + 256;   // score boxes + scores
+    return b + 1024;
+}
+
+extern "C" int vse_db_postprocess(vse_ctx*, const float* d_prob, int n, int h, int w, int src_h, int src_w,
+                                  const vse_db_params* prm, void* d_ws, size_t ws_bytes, vse_box* boxes, int max_boxes,
+                                  int* n_boxes, void* stream) {
+    if (!d_prob || !prm || !d_ws || !boxes || !n_boxes || n <= 0) return VSE_E_INVAL;
+    if (ws_bytes < vse_db_workspace_bytes(n, h, w)) return VSE_E_NOMEM;
+    if (w >= 65536 || h >= 32768) return VSE_E_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    char* ws = reinterpret_cast<char*>(d_ws);
+    int* L = reinterpret_cast<int*>(ws);
+    size_t off = (size_t)n * h * w * sizeof(int);
+    int2* recs = reinterpret_cast<int2*>(ws + off);
+    off += (size_t)n * DB_RUN_CAP * sizeof(int2);
+    int* cnt = reinterpret_cast<int*>(ws + off);
+    off += ((size_t)n * sizeof(int) + 255) / 256 * 256;
+    ScoreBox* sboxes = reinterpret_cast<ScoreBox*>(ws + off);
+    off += (size_t)n * 1024 * sizeof(ScoreBox);
+    float* scores = reinterpret_cast<float*>(ws + off);
+
+    const long total = (long)n * h * w;
+    const int grid = (int)std::min<long>((total + 255) / 256, 65536);
+    if (hipMemsetAsync(cnt, 0, n * sizeof(int), st) != hipSuccess) return VSE_E_HIP;
+    hipLaunchKernelGGL(db_init_kernel, dim3(grid), dim3(256), 0, st, d_prob, L, n, h * w, prm->thresh);
+    hipLaunchKernelGGL(db_merge_kernel, dim3(grid), dim3(256), 0, st, L, n, h, w);
+    hipLaunchKernelGGL(db_runs_kernel, dim3(grid), dim3(256), 0, st, L, n, h, w, recs, cnt, DB_RUN_CAP);
+    std::vector<int> hcnt(n);
+    if (hipMemcpyAsync(hcnt.data(), cnt, n * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return VSE_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
+    std::vector<std::vector<int2>> hrecs(n);
+    for (int f = 0; f < n; ++f) {
+        if (hcnt[f] > DB_RUN_CAP) {
+            vse_set_error("vse_db_postprocess: run-record capacity exceeded (noise-like probability map)");
+            return VSE_E_NOMEM;
+        }
+        hrecs[f].resize(hcnt[f]);
+        if (hcnt[f] && hipMemcpyAsync(hrecs[f].data(), recs + (size_t)f * DB_RUN_CAP, hcnt[f] * sizeof(int2),
+                                      hipMemcpyDeviceToHost, st) != hipSuccess)
+            return VSE_E_HIP;
+    }
+    if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
+
+    // ---- host geometry, pass 1: components -> candidate quads ----------------------------------------
+    struct Cand { int frame; dbgeo::Pt box[4]; };
+    std::vector<Cand> cands;
+    std::vector<ScoreBox> sb;
+    for (int f = 0; f < n; ++f) {
+        auto& r = hrecs[f];
+        std::sort(r.begin(), r.end(), [](const int2& a, const int2& b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
+        // components ordered by descending root = reverse raster order of their first pixel (cv2.findContours
+        // returns the most recently found contour first)
+        std::vector<std::pair<int, int>> comps;   // [begin,end) over r
+        for (size_t i = 0; i < r.size();) {
+            size_t j = i;
+            while (j < r.size() && r[j].x == r[i].x) ++j;
+            comps.emplace_back((int)i, (int)j);
+            i = j;
+        }
+        std::reverse(comps.begin(), comps.end());
+        int used = 0;
+        for (auto& ce : comps) {
+            if (used++ >= prm->max_candidates) break;
+            std::vector<dbgeo::IPt> pts;
+            pts.reserve(ce.second - ce.first);
+            for (int i = ce.first; i < ce.second; ++i) pts.push_back({r[i].y & 0xffff, r[i].y >> 16});
+            const auto hull = dbgeo::convex_hull(pts);
+            const auto mr = dbgeo::min_area_rect(hull);
+            Cand c;
+            c.frame = f;
+            const double sside = dbgeo::mini_box(mr, c.box);
+            if (sside < prm->min_size) continue;
+            // box_score_fast geometry
+            double xmin = c.box[0].x, xmax = c.box[0].x, ymin = c.box[0].y, ymax = c.box[0].y;
+            for (int k = 1; k < 4; ++k) {
+                xmin = std::min(xmin, c.box[k].x); xmax = std::max(xmax, c.box[k].x);
+                ymin = std::min(ymin, c.box[k].y); ymax = std::max(ymax, c.box[k].y);
+            }
+            // the reference casts the box to float32 before floor/ceil (np.float32 arrays)
+            ScoreBox s;
+            s.frame = f;
+            auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+            s.x0 = clampi((int)std::floor((float)xmin), 0, w - 1);
+            s.x1 = clampi((int)std::ceil((float)xmax), 0, w - 1);
+            s.y0 = clampi((int)std::floor((float)ymin), 0, h - 1);
+            s.y1 = clampi((int)std::ceil((float)ymax), 0, h - 1);
+            for (int k = 0; k < 4; ++k) {
+                s.qx[k] = (int)((float)c.box[k].x - (float)s.x0);   // astype(int32) truncation
+                s.qy[k] = (int)((float)c.box[k].y - (float)s.y0);
+            }
+            cands.push_back(c);
+            sb.push_back(s);
+        }
+    }
+    std::vector<float> hs(sb.size());
+    if (!sb.empty()) {
+        if (sb.size() > (size_t)n * 1024) return VSE_E_NOMEM;
+        if (hipMemcpyAsync(sboxes, sb.data(), sb.size() * sizeof(ScoreBox), hipMemcpyHostToDevice, st) != hipSuccess)
+            return VSE_E_HIP;
+        hipLaunchKernelGGL(db_score_kernel, dim3((unsigned)sb.size()), dim3(256), 0, st, d_prob, h, w, sboxes, scores);
+        if (hipMemcpyAsync(hs.data(), scores, sb.size() * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess)
+            return VSE_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
+    }
+    // ---- host geometry, pass 2: score filter -> unclip -> scale -> order -> size filter ----------------
+    int nb = 0;
+    for (size_t i = 0; i < cands.size(); ++i) {
+        if (prm->box_thresh > hs[i]) continue;
+        const auto grown = dbgeo::unclip_rect(cands[i].box, prm->unclip_ratio);
+        const auto hull = dbgeo::convex_hull(grown);
+        const auto mr = dbgeo::min_area_rect(hull);
+        dbgeo::Pt b2[4];
+        const double sside = dbgeo::mini_box(mr, b2);
+        if (sside < prm->min_size + 2) continue;
+        dbgeo::Pt q[4];
+        for (int k = 0; k < 4; ++k) {
+            // np.round (half to even) on float32 values, clip, astype(int32)
+            float fx = (float)b2[k].x / (float)w * (float)src_w;
+            float fy = (float)b2[k].y / (float)h * (float)src_h;
+            fx = std::min(std::max(std::nearbyintf(fx), 0.f), (float)src_w);
+            fy = std::min(std::max(std::nearbyintf(fy), 0.f), (float)src_h);
+            q[k] = {(double)(int)fx, (double)(int)fy};
+        }
+        dbgeo::Pt o[4];
+        dbgeo::order_clockwise(q, o);
+        for (int k = 0; k < 4; ++k) {   // clip_det_res
+            o[k].x = (double)(int)std::min(std::max(o[k].x, 0.0), (double)(src_w - 1));
+            o[k].y = (double)(int)std::min(std::max(o[k].y, 0.0), (double)(src_h - 1));
+        }
+        const int rw = (int)std::sqrt((o[0].x - o[1].x) * (o[0].x - o[1].x) + (o[0].y - o[1].y) * (o[0].y - o[1].y));
+        const int rh = (int)std::sqrt((o[0].x - o[3].x) * (o[0].x - o[3].x) + (o[0].y - o[3].y) * (o[0].y - o[3].y));
+        if (rw <= 3 || rh <= 3) continue;
+        if (nb >= max_boxes) return VSE_E_NOMEM;
+        vse_box& ob = boxes[nb++];
+        for (int k = 0; k < 4; ++k) { ob.pts[k][0] = (float)o[k].x; ob.pts[k][1] = (float)o[k].y; }
+        ob.score = hs[i];
+        ob.frame = cands[i].frame;
+    }
+    *n_boxes = nb;
+    return VSE_OK;
+}
+
+// ================================================================================================ rec pre-process
+// cv2.getPerspectiveTransform (8x8 linear system, Gaussian elimination with partial pivoting in double) and
+// its inverse, as warpPerspective (without WARP_INVERSE_MAP) applies it.
+static bool perspective_inverse(const float src[4][2], int cw, int ch, double minv[9]) {
+    const double dst[4][2] = {{0, 0}, {(double)cw, 0}, {(double)cw, (double)ch}, {0, (double)ch}};
+    double a[8][9];
+    for (int i = 0; i < 4; ++i) {
+        const double x = src[i][0], y = src[i][1], X = dst[i][0], Y = dst[i][1];
+        double r0[9] = {x, y, 1, 0, 0, 0, -x * X, -y * X, X};
+        double r1[9] = {0, 0, 0, x, y, 1, -x * Y, -y * Y, Y};
+        memcpy(a[i], r0, sizeof r0);
+        memcpy(a[i + 4], r1, sizeof r1);
+    }
+    for (int c = 0; c < 8; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 8; ++r)
+            if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (std::fabs(a[piv][c]) < 1e-12) return false;
+        if (piv != c)
+            for (int k = 0; k < 9; ++k) std::swap(a[piv][k], a[c][k]);
+        for (int r = 0; r < 8; ++r) {
+            if (r == c) continue;
+            const double f = a[r][c] / a[c][c];
+            for (int k = c; k < 9; ++k) a[r][k] -= f * a[c][k];
+        }
+    }
+    double m[9];
+    for (int i = 0; i < 8; ++i) m[i] = a[i][8] / a[i][i];
+    m[8] = 1.0;
+    // invert 3x3
+    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (std::fabs(det) < 1e-300) return false;
+    const double id = 1.0 / det;
+    minv[0] = (m[4] * m[8] - m[5] * m[7]) * id;
+    minv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    minv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    minv[3] = (m[5] * m[6] - m[3] * m[8]) * id;
+    minv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    minv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    minv[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+    minv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    minv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return true;
+}
+
+struct CropDev {
+    double minv[9];
+    long scratch_off;     // byte offset of this crop's uint8 image in the scratch
+    int frame, cw, ch;    // warp size
+    int iw, ih;           // image size after the optional rot90
+    int resized_w, rotate;
+};
+
+__device__ __forceinline__ void cubic_w(float x, float* c) {
+    const float A = -0.75f;
+    c[0] = ((A * (x + 1.f) - 5.f * A) * (x + 1.f) + 8.f * A) * (x + 1.f) - 4.f * A;
+    c[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+    c[2] = ((A + 2.f) * (1.f - x) - (A + 3.f)) * (1.f - x) * (1.f - x) + 1.f;
+    c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+// grid (ceil(maxpix/256), n_crops): bicubic perspective warp with replicate border into the scratch image
+// (already rotated: np.rot90(dst) -> out[i][j] = dst[j][cw-1-i]).
+__global__ __launch_bounds__(256) void crop_warp_kernel(const uint8_t* __restrict__ src, int sh, int sw, long pitch,
+                                                        long fstride, const CropDev* __restrict__ crops,
+                                                        uint8_t* __restrict__ scratch) {
+    const CropDev c = crops[blockIdx.y];
+    const int npx = c.cw * c.ch;
+    const uint8_t* S = src + c.frame * fstride;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+        const int x = i % c.cw, y = i / c.cw;
+        const double X0 = c.minv[0] * x + c.minv[1] * y + c.minv[2];
+        const double Y0 = c.minv[3] * x + c.minv[4] * y + c.minv[5];
+        double W = c.minv[6] * x + c.minv[7] * y + c.minv[8];
+        W = W != 0.0 ? 32.0 / W : 0.0;                       // INTER_TAB_SIZE = 32
+        const double fX = fmax(-2147483648.0, fmin(2147483647.0, X0 * W));
+        const double fY = fmax(-2147483648.0, fmin(2147483647.0, Y0 * W));
+        const int X = (int)rint(fX), Y = (int)rint(fY);      // cv::saturate_cast<int>(double) = lrint
+        const int sx = (X >> 5) - 1, sy = (Y >> 5) - 1;
+        float wx[4], wy[4];
+        cubic_w((float)(X & 31) * (1.f / 32.f), wx);
+        cubic_w((float)(Y & 31) * (1.f / 32.f), wy);
+        float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int yy = min(max(sy + r, 0), sh - 1);
+            const uint8_t* row = S + (long)yy * pitch;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int xx = min(max(sx + q, 0), sw - 1);
+                const float wgt = wy[r] * wx[q];
+                acc[0] += wgt * (float)row[xx * 3 + 0];
+                acc[1] += wgt * (float)row[xx * 3 + 1];
+                acc[2] += wgt * (float)row[xx * 3 + 2];
+            }
+        }
+        int ox = x, oy = y;
+        if (c.rotate) { oy = c.cw - 1 - x; ox = y; }
+        uint8_t* o = scratch + c.scratch_off + ((long)oy * c.iw + ox) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) o[k] = (uint8_t)min(max((int)rintf(acc[k]), 0), 255);
+    }
+}
+
+// grid (ceil(rec_h*rec_w/256), n_crops): cv2 fixed-point bilinear resize of the crop to (resized_w, rec_h),
+// (x/255 - 0.5)/0.5, zero right-pad, fp16 NHWC(8).
+__global__ __launch_bounds__(256) void crop_resize_kernel(const CropDev* __restrict__ crops, const uint8_t* __restrict__ scratch,
+                                                          half_t* __restrict__ dst, int rec_h, int rec_w) {
+    const CropDev c = crops[blockIdx.y];
+    const uint8_t* img = scratch + c.scratch_off;
+    const int npx = rec_h * rec_w;
+    half_t* out = dst + (long)blockIdx.y * npx * 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+        const int x = i % rec_w, y = i / rec_w;
+        half8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (x < c.resized_w) {
+            const LinCoef cx = lin_coef(x, c.resized_w, c.iw), cy = lin_coef(y, rec_h, c.ih);
+            const int x1 = min(cx.s0 + 1, c.iw - 1), y1 = min(cy.s0 + 1, c.ih - 1);
+            const uint8_t* r0 = img + (long)cy.s0 * c.iw * 3;
+            const uint8_t* r1 = img + (long)y1 * c.iw * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int u;
+                if (c.iw == c.resized_w && c.ih == rec_h) u = r0[cx.s0 * 3 + k];
+                else u = cv_bilinear_u8(r0[cx.s0 * 3 + k], r0[x1 * 3 + k], r1[cx.s0 * 3 + k], r1[x1 * 3 + k], cx, cy);
+                o[k] = (half_t)(((float)u / 255.f - 0.5f) / 0.5f);
+            }
+        }
+        *reinterpret_cast<half8*>(out + (long)i * 8) = o;
+    }
+}
+
+static inline size_t crop_bytes(int w, int h) { return ((size_t)w * h * 3 + 255) / 256 * 256; }
+
+extern "C" size_t vse_rec_preprocess_scratch_bytes(int n_crops, int max_crop_w, int max_crop_h) {
+    return (size_t)n_crops * (crop_bytes(max_crop_w, max_crop_h) + ((sizeof(CropDev) + 255) / 256 * 256)) + 4096;
+}
+
+extern "C" int vse_rec_preprocess(vse_ctx*, const void* d_bgr, int n_frames, int src_h, int src_w, int64_t pitch,
+                                  int64_t frame_stride, const vse_crop* crops, int n_crops, void* d_out, int rec_h,
+                                  int rec_w, void* d_scratch, size_t scratch_bytes, void* stream) {
+    if (!d_bgr || !crops || !d_out || !d_scratch || n_crops <= 0) return VSE_E_INVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    std::vector<CropDev> cd(n_crops);
+    size_t off = ((size_t)n_crops * sizeof(CropDev) + 255) / 256 * 256;
+    int maxpix = 0;
+    for (int i = 0; i < n_crops; ++i) {
+        const vse_crop& c = crops[i];
+        if (c.frame < 0 || c.frame >= n_frames || c.crop_w <= 0 || c.crop_h <= 0 || c.resized_w <= 0 || c.resized_w > rec_w)
+            return VSE_E_INVAL;
+        CropDev& d = cd[i];
+        if (!perspective_inverse(c.quad, c.crop_w, c.crop_h, d.minv)) {
+            // degenerate quad: identity-like mapping from the first corner
+            double id[9] = {1, 0, c.quad[0][0], 0, 1, c.quad[0][1], 0, 0, 1};
+            memcpy(d.minv, id, sizeof id);
+        }
+        d.frame = c.frame; d.cw = c.crop_w; d.ch = c.crop_h; d.rotate = c.rotate;
+        d.iw = c.rotate ? c.crop_h : c.crop_w;
+        d.ih = c.rotate ? c.crop_w : c.crop_h;
+        d.resized_w = c.resized_w;
+        d.scratch_off = (long)off;
+        off += crop_bytes(c.crop_w, c.crop_h);
+        maxpix = std::max(maxpix, c.crop_w * c.crop_h);
+    }
+    if (off > scratch_bytes) return VSE_E_NOMEM;
+    if (hipMemcpyAsync(d_scratch, cd.data(), n_crops * sizeof(CropDev), hipMemcpyHostToDevice, st) != hipSuccess)
+        return VSE_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;   // cd is a stack-lifetime pageable buffer
+    const CropDev* dcd = reinterpret_cast<const CropDev*>(d_scratch);
+    uint8_t* scr = reinterpret_cast<uint8_t*>(d_scratch);
+    dim3 g1(std::min((maxpix + 255) / 256, 1024), n_crops);
+    hipLaunchKernelGGL(crop_warp_kernel, g1, dim3(256), 0, st, reinterpret_cast<const uint8_t*>(d_bgr), src_h, src_w,
+                       (long)pitch, (long)frame_stride, dcd, scr);
+    dim3 g2((rec_h * rec_w + 255) / 256, n_crops);
+    hipLaunchKernelGGL(crop_resize_kernel, g2, dim3(256), 0, st, dcd, scr, reinterpret_cast<half_t*>(d_out), rec_h, rec_w);
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}
+
+// ================================================================================================ CTC collapse
+// One wave per sequence: lane l looks at t = base + l, keep = idx[t] != 0 && idx[t] != idx[t-1]; the 64-bit
+// ballot gives each kept element its output slot by a popcount of the lower lanes (wavefront scan).
+__global__ __launch_bounds__(256) void ctc_collapse_kernel(const int2* __restrict__ ip, int b, int t, int* __restrict__ out_idx,
+                                                           int* __restrict__ out_len, float* __restrict__ out_conf) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= b) return;
+    const int2* r = ip + (long)row * t;
+    int n = 0;
+    float sum = 0.f;
+    for (int base = 0; base < t; base += 64) {
+        const int tt = base + lane;
+        int idx = 0, prev = -1;
+        float p = 0.f;
+        if (tt < t) {
+            const int2 v = r[tt];
+            idx = v.x;
+            p = __int_as_float(v.y);
+            prev = tt > 0 ? r[tt - 1].x : -1;
+        }
+        const bool keep = (tt < t) && idx != 0 && idx != prev;
+        const unsigned long long m = __ballot(keep);
+        if (keep) out_idx[(long)row * t + n + __popcll(m & ((1ull << lane) - 1ull))] = idx;
+        float ps = keep ? p : 0.f;
+        for (int o = 32; o >= 1; o >>= 1) ps += __shfl_xor(ps, o);
+        sum += ps;
+        n += __popcll(m);
+    }
+    if (lane == 0) {
+        out_len[row] = n;
+        out_conf[row] = n ? sum / (float)n : 0.f;
+    }
+}
+
+extern "C" int vse_ctc_collapse(vse_ctx*, const void* d_idx_maxp, int b, int t, int32_t* d_out_idx, int32_t* d_out_len,
+                                float* d_out_conf, void* stream) {
+    if (!d_idx_maxp || !d_out_idx || !d_out_len || !d_out_conf || b <= 0 || t <= 0) return VSE_E_INVAL;
+    hipLaunchKernelGGL(ctc_collapse_kernel, dim3((b + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const int2*>(d_idx_maxp), b, t, d_out_idx, d_out_len, d_out_conf);
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}

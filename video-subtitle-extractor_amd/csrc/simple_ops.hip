@@ -1,0 +1,518 @@
+// HBM-bound NHWC fp16 kernels of the engine: depthwise conv, pooling, global average, SE gating, adds,
+// nearest resize / concat copies, unary affine+activation, LayerNorm, fused SVTR attention, class softmax with
+// arg-max, LSTM recurrence.  One thread handles one 16-byte (8-channel) vector of one pixel wherever the
+// layout allows it, so a wave reads/writes 1 KiB per instruction with consecutive lanes on consecutive
+// channel groups of the same pixel (coalesced NHWC).
+#include "common.h"
+
+#define GRID_CAP 16384
+
+static inline int grid_for(long items, int block) {
+    long g = (items + block - 1) / block;
+    if (g > GRID_CAP) g = GRID_CAP;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__device__ __forceinline__ half8 ld8(const TView& v, long pix, int c) {
+    return *reinterpret_cast<const half8*>(reinterpret_cast<const half_t*>(v.ptr) + pix * v.ld + c);
+}
+__device__ __forceinline__ void st8(const TView& v, long pix, int c, half8 x) {
+    *reinterpret_cast<half8*>(reinterpret_cast<half_t*>(v.ptr) + pix * v.ld + c) = x;
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise
+__global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, const half_t* __restrict__ w,
+                                                     const float* __restrict__ bias, int kh, int kw, int sh, int sw,
+                                                     int ph, int pw, int act, float act_a, float act_b, float post_a,
+                                                     float post_b) {
+    const int cg = in.c >> 3;
+    const long total = (long)out.n * out.h * out.w * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long pix = i / cg;
+        const int ow = (int)(pix % out.w);
+        long t = pix / out.w;
+        const int oh = (int)(t % out.h);
+        const long n = t / out.h;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias[g * 8 + e];
+        for (int dy = 0; dy < kh; ++dy) {
+            const int ih = oh * sh - ph + dy;
+            if (ih < 0 || ih >= in.h) continue;
+            for (int dx = 0; dx < kw; ++dx) {
+                const int iw = ow * sw - pw + dx;
+                if (iw < 0 || iw >= in.w) continue;
+                const half8 x = ld8(in, (n * in.h + ih) * in.w + iw, g * 8);
+                const half8 k = *reinterpret_cast<const half8*>(w + (long)(dy * kw + dx) * in.c + g * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)x[e] * (float)k[e];
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)(vse_act(acc[e], act, act_a, act_b) * post_a + post_b);
+        st8(out, pix, g * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ pooling
+__global__ __launch_bounds__(256) void pool_kernel(TView in, TView out, int kh, int kw, int sh, int sw, int ph, int pw,
+                                                   int is_max, int exclusive) {
+    const int cg = in.c >> 3;
+    const long total = (long)out.n * out.h * out.w * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        long pix = i / cg;
+        const int ow = (int)(pix % out.w);
+        long t = pix / out.w;
+        const int oh = (int)(t % out.h);
+        const long n = t / out.h;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = is_max ? -65504.f : 0.f;
+        int cnt = 0;
+        for (int dy = 0; dy < kh; ++dy) {
+            const int ih = oh * sh - ph + dy;
+            if (ih < 0 || ih >= in.h) continue;
+            for (int dx = 0; dx < kw; ++dx) {
+                const int iw = ow * sw - pw + dx;
+                if (iw < 0 || iw >= in.w) continue;
+                const half8 x = ld8(in, (n * in.h + ih) * in.w + iw, g * 8);
+                ++cnt;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = is_max ? fmaxf(acc[e], (float)x[e]) : acc[e] + (float)x[e];
+            }
+        }
+        half8 o;
+        if (is_max) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+        } else {
+            // exclusive: divide by the number of in-bounds taps; inclusive: by the window clipped to the padded input
+            float div = (float)cnt;
+            if (!exclusive) {
+                const int h1 = min(oh * sh - ph + kh, in.h + ph), w1 = min(ow * sw - pw + kw, in.w + pw);
+                div = (float)((h1 - (oh * sh - ph)) * (w1 - (ow * sw - pw)));
+            }
+            const float inv = 1.f / div;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)(acc[e] * inv);
+        }
+        st8(out, pix, g * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ global average
+// grid (n, ceil(cg/8), splits); block 256 = 8 channel groups x 32 pixel lanes.  Partials (fp32) go to `part`
+// [n][splits][c]; gap_finish reduces them.  With splits == 1 the partial pass writes the result directly.
+__global__ __launch_bounds__(256) void gap_partial_kernel(TView in, float* __restrict__ part, int splits) {
+    __shared__ float red[32][8][8];
+    const int cgl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int g = blockIdx.y * 8 + cgl;
+    const int n = blockIdx.x, s = blockIdx.z;
+    const int cg = in.c >> 3;
+    const long hw = (long)in.h * in.w;
+    const long per = (hw + splits - 1) / splits;
+    const long p0 = s * per, p1 = min(hw, p0 + per);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g < cg) {
+        for (long pp = p0 + pl; pp < p1; pp += 32) {
+            const half8 x = ld8(in, n * hw + pp, g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)x[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[pl][cgl][e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;   // 8 groups x 8 elems
+        float sum = 0.f;
+        for (int q = 0; q < 32; ++q) sum += red[q][c >> 3][c & 7];
+        const int ch = blockIdx.y * 64 + c;
+        if (ch < in.c) part[((long)n * splits + s) * in.c + ch] = sum;
+    }
+}
+__global__ void gap_finish_kernel(const float* __restrict__ part, TView out, int splits, float inv_hw) {
+    const long total = (long)out.n * out.c;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / out.c;
+        const int c = (int)(i % out.c);
+        float s = 0.f;
+        for (int q = 0; q < splits; ++q) s += part[(n * splits + q) * out.c + c];
+        reinterpret_cast<half_t*>(out.ptr)[n * out.ld + c] = (half_t)(s * inv_hw);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ SE gate
+__global__ __launch_bounds__(256) void scale_kernel(TView x, TView s, TView out, int add_x) {
+    const int cg = x.c >> 3;
+    const long hw = (long)x.h * x.w;
+    const long total = (long)x.n * hw * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long pix = i / cg;
+        const long n = pix / hw;
+        const half8 a = ld8(x, pix, g * 8);
+        const half8 b = ld8(s, n, g * 8);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (float)a[e] * (float)b[e];
+            o[e] = (half_t)(add_x ? v + (float)a[e] : v);
+        }
+        st8(out, pix, g * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ binary add/mul
+__global__ __launch_bounds__(256) void binary_kernel(TView x, TView y, TView out, int is_mul, int shift, int act) {
+    const int cg = x.c >> 3;
+    const long total = (long)x.n * x.h * x.w * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long pix = i / cg;
+        long ypix = pix;
+        if (shift) {
+            const int w = (int)(pix % x.w);
+            const long t = pix / x.w;
+            const int h = (int)(t % x.h);
+            const long n = t / x.h;
+            ypix = (n * y.h + (h >> shift)) * y.w + (w >> shift);
+        }
+        const half8 a = ld8(x, pix, g * 8);
+        const half8 b = ld8(y, ypix, g * 8);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = is_mul ? (float)a[e] * (float)b[e] : (float)a[e] + (float)b[e];
+            o[e] = (half_t)vse_act(v, act, 0.f, 0.f);
+        }
+        st8(out, pix, g * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ resize / copy
+__global__ __launch_bounds__(256) void resize_kernel(TView in, TView out, int shift) {
+    const int cg = out.c >> 3;
+    const long total = (long)out.n * out.h * out.w * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long pix = i / cg;
+        const int w = (int)(pix % out.w);
+        const long t = pix / out.w;
+        const int h = (int)(t % out.h);
+        const long n = t / out.h;
+        const long ipix = (n * in.h + (h >> shift)) * in.w + (w >> shift);
+        st8(out, pix, g * 8, ld8(in, ipix, g * 8));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ unary
+// out = act(x*pre_a+pre_b)*post_a+post_b.  Vector path when both sides are fp16 with 8-aligned spans; scalar
+// path otherwise (e.g. the final 1-channel fp32 probability map).
+__global__ __launch_bounds__(256) void unary_vec_kernel(TView in, TView out, int act, float act_a, float act_b,
+                                                        float pre_a, float pre_b, float post_a, float post_b) {
+    const int cg = out.c >> 3;
+    const long total = (long)out.n * out.h * out.w * cg;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const long pix = i / cg;
+        const half8 a = ld8(in, pix, g * 8);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o[e] = (half_t)(vse_act((float)a[e] * pre_a + pre_b, act, act_a, act_b) * post_a + post_b);
+        st8(out, pix, g * 8, o);
+    }
+}
+__global__ __launch_bounds__(256) void unary_scalar_kernel(TView in, TView out, int act, float act_a, float act_b,
+                                                           float pre_a, float pre_b, float post_a, float post_b) {
+    const long total = (long)out.n * out.h * out.w * out.c;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out.c);
+        const long pix = i / out.c;
+        float x;
+        if (in.esize == 2) x = (float)reinterpret_cast<const half_t*>(in.ptr)[pix * in.ld + c];
+        else x = reinterpret_cast<const float*>(in.ptr)[pix * in.ld + c];
+        const float y = vse_act(x * pre_a + pre_b, act, act_a, act_b) * post_a + post_b;
+        if (out.esize == 2) reinterpret_cast<half_t*>(out.ptr)[pix * out.ld + c] = (half_t)y;
+        else reinterpret_cast<float*>(out.ptr)[pix * out.ld + c] = y;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// 16 lanes per row (8 channels each; C <= 128), 4 rows per wave, two-pass mean/variance in fp32.
+__global__ __launch_bounds__(256) void layernorm_kernel(TView in, TView out, const float* __restrict__ gb, float eps) {
+    const int C = in.c;
+    const long rows = (long)in.n * in.h * in.w;
+    const int sub = threadIdx.x & 15;
+    const long row0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 4;
+    const long rstride = ((long)gridDim.x * blockDim.x) >> 4;
+    // the 16 lanes of a row group share r, so the width-16 shuffles only touch lanes with the same trip count
+    for (long r = row0; r < rows; r += rstride) {
+        const bool has = sub * 8 < C;
+        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (has) {
+            const half8 x = ld8(in, r, sub * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)x[e];
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+        for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 16);
+        const float mean = s / (float)C;
+        float q = 0.f;
+        if (has) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q += (v[e] - mean) * (v[e] - mean);
+        }
+        for (int o = 8; o >= 1; o >>= 1) q += __shfl_xor(q, o, 16);
+        const float rstd = rsqrtf(q / (float)C + eps);
+        if (has) {
+            half8 o8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o8[e] = (half_t)((v[e] - mean) * rstd * gb[sub * 8 + e] + gb[C + sub * 8 + e]);
+            st8(out, r, sub * 8, o8);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ attention
+// One block per (batch, head).  K and V of the head live in LDS as fp32 [T][hd]; thread t owns query row t and
+// runs an online-softmax pass over all keys.  T <= a few hundred, hd <= 16: tiny FLOPs, latency-bound.
+__global__ __launch_bounds__(256) void attn_kernel(TView qkv, TView out, int heads, int hd, float scale) {
+    extern __shared__ float kvs[];   // K [T][16] then V [T][16], head dim zero-padded to 16
+    const int T = qkv.w;
+    const int b = blockIdx.x / heads, hix = blockIdx.x % heads;
+    const int C = heads * hd;
+    float* Ks = kvs;
+    float* Vs = kvs + (long)T * 16;
+    const half_t* base = reinterpret_cast<const half_t*>(qkv.ptr) + (long)b * T * qkv.ld;
+    for (int i = threadIdx.x; i < T * 16; i += blockDim.x) {
+        const int t = i >> 4, d = i & 15;
+        const bool ok = d < hd;
+        Ks[i] = ok ? (float)base[(long)t * qkv.ld + C + hix * hd + d] : 0.f;
+        Vs[i] = ok ? (float)base[(long)t * qkv.ld + 2 * C + hix * hd + d] : 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        float q[16], o[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            q[d] = d < hd ? (float)base[(long)t * qkv.ld + hix * hd + d] * scale : 0.f;
+            o[d] = 0.f;
+        }
+        float mx = -1e30f, l = 0.f;
+        for (int j = 0; j < T; ++j) {
+            const float4v* kr = reinterpret_cast<const float4v*>(Ks + j * 16);
+            const float4v* vr = reinterpret_cast<const float4v*>(Vs + j * 16);
+            float s = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                const float4v k4 = kr[d4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += q[d4 * 4 + e] * k4[e];
+            }
+            const float nm = fmaxf(mx, s);
+            const float corr = __expf(mx - nm);
+            const float pj = __expf(s - nm);
+            l = l * corr + pj;
+#pragma unroll
+            for (int d4 = 0; d4 < 4; ++d4) {
+                const float4v v4 = vr[d4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[d4 * 4 + e] = o[d4 * 4 + e] * corr + pj * v4[e];
+            }
+            mx = nm;
+        }
+        const float inv = 1.f / l;
+        half_t* op = reinterpret_cast<half_t*>(out.ptr) + ((long)b * T + t) * out.ld + hix * hd;
+#pragma unroll
+        for (int d = 0; d < 16; ++d)
+            if (d < hd) op[d] = (half_t)(o[d] * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ class softmax
+// One block per (b,t) row of logits: max, sum-exp, arg-max (first index on ties, like numpy argmax);
+// writes {argmax:int32, maxprob:fp32} and optionally the full fp32 probability row.
+__global__ __launch_bounds__(256) void softmax_kernel(TView in, TView idxp, TView probs, int ncls, int want_probs) {
+    __shared__ float smax[4];
+    __shared__ int sidx[4];
+    __shared__ float ssum[4];
+    const long row = blockIdx.x;
+    const half_t* x = reinterpret_cast<const half_t*>(in.ptr) + row * in.ld;
+    float mx = -1e30f;
+    int mi = 0x7fffffff;
+    for (int c = threadIdx.x; c < ncls; c += blockDim.x) {
+        const float v = (float)x[c];
+        if (v > mx) { mx = v; mi = c; }
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float om = __shfl_xor(mx, o);
+        const int oi = __shfl_xor(mi, o);
+        if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smax[wave] = mx; sidx[wave] = mi; }
+    __syncthreads();
+    mx = smax[0]; mi = sidx[0];
+    for (int q = 1; q < 4; ++q)
+        if (smax[q] > mx || (smax[q] == mx && sidx[q] < mi)) { mx = smax[q]; mi = sidx[q]; }
+    float s = 0.f;
+    for (int c = threadIdx.x; c < ncls; c += blockDim.x) s += __expf((float)x[c] - mx);
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) ssum[wave] = s;
+    __syncthreads();
+    s = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+    const float inv = 1.f / s;
+    if (threadIdx.x == 0) {
+        int* ip = reinterpret_cast<int*>(idxp.ptr) + row * idxp.ld;
+        ip[0] = mi;
+        reinterpret_cast<float*>(ip)[1] = inv;   // max prob = exp(0)/sum
+    }
+    if (want_probs) {
+        float* pr = reinterpret_cast<float*>(probs.ptr) + row * probs.ld;
+        for (int c = threadIdx.x; c < ncls; c += blockDim.x) pr[c] = __expf((float)x[c] - mx) * inv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LSTM
+// One block per batch row; gates fp32 [B,1,T,4H] hold x.W_ih^T + b_ih + b_hh for every step (one MFMA GEMM up
+// front); this kernel adds h.W_hh^T and runs the cell.  W_hh^T is fp16 [H][4H] read through L2 every step.
+// H = 256 -> 1024 gate columns; thread j (of 256) owns hidden unit j and computes its 4 gates.
+__global__ __launch_bounds__(256) void lstm_kernel(TView gates, TView out, const half_t* __restrict__ whh, int H, int rev) {
+    extern __shared__ float hs[];   // h [H]
+    const int b = blockIdx.x;
+    const int T = gates.w;
+    const int j = threadIdx.x;
+    float c = 0.f;
+    if (j < H) hs[j] = 0.f;
+    __syncthreads();
+    for (int step = 0; step < T; ++step) {
+        const int t = rev ? T - 1 - step : step;
+        const float* g = reinterpret_cast<const float*>(gates.ptr) + ((long)b * T + t) * gates.ld;
+        float zi = 0.f, zf = 0.f, zg = 0.f, zo = 0.f;
+        if (j < H) {
+            zi = g[j]; zf = g[H + j]; zg = g[2 * H + j]; zo = g[3 * H + j];
+            for (int k = 0; k < H; ++k) {
+                const float hk = hs[k];
+                const half_t* wr = whh + (long)k * 4 * H;
+                zi += hk * (float)wr[j];
+                zf += hk * (float)wr[H + j];
+                zg += hk * (float)wr[2 * H + j];
+                zo += hk * (float)wr[3 * H + j];
+            }
+        }
+        __syncthreads();
+        if (j < H) {
+            const float i_ = 1.f / (1.f + __expf(-zi)), f_ = 1.f / (1.f + __expf(-zf)), o_ = 1.f / (1.f + __expf(-zo));
+            c = f_ * c + i_ * tanhf(zg);
+            const float h = o_ * tanhf(c);
+            hs[j] = h;
+            reinterpret_cast<half_t*>(out.ptr)[((long)b * T + t) * out.ld + j] = (half_t)h;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch
+int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const TView& in2, const TView& out,
+                     const TView& out2, const char* wbase, hipStream_t st) {
+    const int* p = op.p;
+    const float* f = op.f;
+    switch (op.kind) {
+        case OP_DWCONV: {
+            if ((in0.c & 7) || in0.esize != 2 || out.c != in0.c) return VSE_E_INVAL;
+            const long items = (long)out.n * out.h * out.w * (in0.c >> 3);
+            hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out,
+                               reinterpret_cast<const half_t*>(wbase + op.w_off),
+                               reinterpret_cast<const float*>(wbase + op.b_off), p[P_KH], p[P_KW], p[P_SH], p[P_SW],
+                               p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B]);
+            break;
+        }
+        case OP_POOL: {
+            if ((in0.c & 7) || out.c != in0.c) return VSE_E_INVAL;
+            const long items = (long)out.n * out.h * out.w * (in0.c >> 3);
+            hipLaunchKernelGGL(pool_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, p[P_KH], p[P_KW],
+                               p[P_SH], p[P_SW], p[P_PH], p[P_PW], p[P_POOL_MAX], p[P_POOL_EXCL]);
+            break;
+        }
+        case OP_GAP: {
+            if ((in0.c & 7) || out.c != in0.c || in2.ptr == nullptr) return VSE_E_INVAL;
+            const int splits = in2.h;   // scratch view [n, splits, 1, c] fp32
+            dim3 grid(in0.n, (in0.c + 63) / 64, splits);
+            hipLaunchKernelGGL(gap_partial_kernel, grid, dim3(256), 0, st, in0, reinterpret_cast<float*>(in2.ptr), splits);
+            const long items = (long)out.n * out.c;
+            hipLaunchKernelGGL(gap_finish_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st,
+                               reinterpret_cast<const float*>(in2.ptr), out, splits, 1.f / ((float)in0.h * in0.w));
+            break;
+        }
+        case OP_SCALE: {
+            const long items = (long)in0.n * in0.h * in0.w * (in0.c >> 3);
+            hipLaunchKernelGGL(scale_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, in1, out,
+                               (op.flags & F_RES) ? 1 : 0);
+            break;
+        }
+        case OP_BINARY: {
+            const long items = (long)in0.n * in0.h * in0.w * (in0.c >> 3);
+            hipLaunchKernelGGL(binary_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, in1, out, p[0], p[1], p[2]);
+            break;
+        }
+        case OP_RESIZE: {
+            if (in0.c < out.c) return VSE_E_INVAL;
+            const long items = (long)out.n * out.h * out.w * (out.c >> 3);
+            hipLaunchKernelGGL(resize_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, p[0]);
+            break;
+        }
+        case OP_UNARY: {
+            const bool vec = in0.esize == 2 && out.esize == 2 && !(out.c & 7) && !(in0.ld & 7) && !(out.ld & 7);
+            if (vec) {
+                const long items = (long)out.n * out.h * out.w * (out.c >> 3);
+                hipLaunchKernelGGL(unary_vec_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, p[0],
+                                   f[FS_ACT_A], f[FS_ACT_B], f[FS_PRE_A], f[FS_PRE_B], f[FS_POST_A], f[FS_POST_B]);
+            } else {
+                const long items = (long)out.n * out.h * out.w * out.c;
+                hipLaunchKernelGGL(unary_scalar_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, p[0],
+                                   f[FS_ACT_A], f[FS_ACT_B], f[FS_PRE_A], f[FS_PRE_B], f[FS_POST_A], f[FS_POST_B]);
+            }
+            break;
+        }
+        case OP_LAYERNORM: {
+            if (in0.c > 128 || (in0.c & 7)) return VSE_E_UNSUPPORTED;
+            const long rows = (long)in0.n * in0.h * in0.w;
+            hipLaunchKernelGGL(layernorm_kernel, dim3(grid_for(rows * 16, 256)), dim3(256), 0, st, in0, out,
+                               reinterpret_cast<const float*>(wbase + op.w_off), f[FS_EPS]);
+            break;
+        }
+        case OP_ATTN: {
+            const int heads = p[0], hd = p[1];
+            if (hd > 16) return VSE_E_UNSUPPORTED;
+            const size_t lds = (size_t)2 * in0.w * 16 * sizeof(float);
+            if (lds > 160 * 1024) return VSE_E_UNSUPPORTED;
+            hipLaunchKernelGGL(attn_kernel, dim3(in0.n * heads), dim3(256), lds, st, in0, out, heads, hd, f[FS_SCALE]);
+            break;
+        }
+        case OP_SOFTMAX: {
+            const long rows = (long)in0.n * in0.h * in0.w;
+            hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)rows), dim3(256), 0, st, in0, out, out2, p[0],
+                               out2.ptr != nullptr ? 1 : 0);
+            break;
+        }
+        case OP_LSTM: {
+            const int H = p[0];
+            if (H > 256) return VSE_E_UNSUPPORTED;
+            hipLaunchKernelGGL(lstm_kernel, dim3(in0.n), dim3(256), H * sizeof(float), st, in0, out,
+                               reinterpret_cast<const half_t*>(wbase + op.w_off), H, p[1]);
+            break;
+        }
+        default:
+            return VSE_E_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}

@@ -1,0 +1,212 @@
+// C-ABI runtime: context, weight arenas, plan creation and the op dispatch loop (see include/vse_hip.h).
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+static thread_local std::string g_err;
+static void set_err(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+void vse_set_error(const char* msg) { g_err = msg ? msg : ""; }
+#define HIP_TRY(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return VSE_E_HIP;                                                          \
+        }                                                                              \
+    } while (0)
+
+struct vse_ctx {
+    int device;
+    std::vector<void*> weights;       // device blobs
+    std::vector<size_t> weight_bytes;
+    void* zero_page;                  // 4 KiB of zeros (gather target for nothing yet; keeps pointers valid)
+};
+
+struct vse_plan {
+    vse_ctx* ctx;
+    int weights_id;
+    std::vector<vse_op> ops;
+    size_t ws_bytes;
+    int max_ext;
+};
+
+extern "C" {
+
+const char* vse_last_error(void) { return g_err.c_str(); }
+size_t vse_sizeof_op(void) { return sizeof(vse_op); }
+size_t vse_sizeof_view(void) { return sizeof(vse_view); }
+int vse_abi_version(void) { return 1; }
+
+int vse_init(int device_id, vse_ctx** out) {
+    if (!out) return VSE_E_INVAL;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device_id < 0 || device_id >= count) {
+        set_err("device %d not present (%d visible)", device_id, count);
+        return VSE_E_INVAL;
+    }
+    HIP_TRY(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+        set_err("libvse_hip is built for gfx950 (MI355X) only; device %d is %s", device_id, prop.gcnArchName);
+        return VSE_E_UNSUPPORTED;
+    }
+    vse_ctx* c = new vse_ctx();
+    c->device = device_id;
+    c->zero_page = nullptr;
+    HIP_TRY(hipMalloc(&c->zero_page, 4096));
+    HIP_TRY(hipMemset(c->zero_page, 0, 4096));
+    *out = c;
+    return VSE_OK;
+}
+
+void vse_destroy(vse_ctx* c) {
+    if (!c) return;
+    for (void* w : c->weights)
+        if (w) (void)hipFree(w);
+    if (c->zero_page) (void)hipFree(c->zero_page);
+    delete c;
+}
+
+int vse_weights_upload(vse_ctx* c, const void* host_blob, size_t nbytes) {
+    if (!c || !host_blob || !nbytes) return VSE_E_INVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, nbytes + 256));
+    HIP_TRY(hipMemcpy(d, host_blob, nbytes, hipMemcpyHostToDevice));
+    c->weights.push_back(d);
+    c->weight_bytes.push_back(nbytes);
+    return (int)c->weights.size() - 1;
+}
+
+int vse_weights_free(vse_ctx* c, int id) {
+    if (!c || id < 0 || id >= (int)c->weights.size()) return VSE_E_INVAL;
+    if (c->weights[id]) (void)hipFree(c->weights[id]);
+    c->weights[id] = nullptr;
+    return VSE_OK;
+}
+
+int vse_plan_create(vse_ctx* c, int weights_id, const vse_op* ops, int n_ops, size_t ws_bytes, vse_plan** out) {
+    if (!c || !ops || n_ops <= 0 || !out) return VSE_E_INVAL;
+    if (weights_id < 0 || weights_id >= (int)c->weights.size() || !c->weights[weights_id]) {
+        set_err("bad weights id %d", weights_id);
+        return VSE_E_INVAL;
+    }
+    vse_plan* p = new vse_plan();
+    p->ctx = c;
+    p->weights_id = weights_id;
+    p->ops.assign(ops, ops + n_ops);
+    p->ws_bytes = ws_bytes;
+    p->max_ext = -1;
+    const size_t wbytes = c->weight_bytes[weights_id];
+    for (int i = 0; i < n_ops; ++i) {
+        const vse_op& o = ops[i];
+        if (o.kind < OP_CONV || o.kind > OP_LSTM) {
+            set_err("op %d: unknown kind %d", i, o.kind);
+            delete p;
+            return VSE_E_INVAL;
+        }
+        const vse_view* vs[5] = {&o.in0, &o.in1, &o.in2, &o.out, &o.out2};
+        for (const vse_view* v : vs) {
+            if (v->n == 0) continue;
+            if (v->arena >= 2) p->max_ext = std::max(p->max_ext, v->arena - 2);
+            if (v->arena == 0) {
+                const size_t end = (size_t)v->off + ((size_t)v->n * v->h * v->w - 1) * v->ld * v->esize + (size_t)v->c * v->esize;
+                if (end > ws_bytes) {
+                    set_err("op %d: view exceeds workspace (%zu > %zu)", i, end, ws_bytes);
+                    delete p;
+                    return VSE_E_INVAL;
+                }
+            }
+        }
+        if ((size_t)o.w_off > wbytes || (size_t)o.b_off > wbytes) {
+            set_err("op %d: weight offset out of range", i);
+            delete p;
+            return VSE_E_INVAL;
+        }
+    }
+    *out = p;
+    return VSE_OK;
+}
+
+void vse_plan_destroy(vse_plan* p) { delete p; }
+
+static inline TView resolve(const vse_view& v, char* ws, char* wts, void* const* ext) {
+    TView t;
+    t.ptr = nullptr;
+    t.n = v.n; t.h = v.h; t.w = v.w; t.c = v.c; t.ld = v.ld; t.esize = v.esize;
+    if (v.n == 0) return t;
+    char* base = v.arena == 0 ? ws : (v.arena == 1 ? wts : reinterpret_cast<char*>(ext[v.arena - 2]));
+    t.ptr = base + v.off;
+    return t;
+}
+
+static int run_op(vse_plan* p, int i, char* ws, void* const* ext, hipStream_t st) {
+    const vse_op& o = p->ops[i];
+    char* wts = reinterpret_cast<char*>(p->ctx->weights[p->weights_id]);
+    const TView in0 = resolve(o.in0, ws, wts, ext), in1 = resolve(o.in1, ws, wts, ext),
+                in2 = resolve(o.in2, ws, wts, ext), out = resolve(o.out, ws, wts, ext),
+                out2 = resolve(o.out2, ws, wts, ext);
+    int rc;
+    if (o.kind == OP_CONV) {
+        ConvArgs a;
+        a.in = in0; a.res = in1; a.out = out;
+        a.w = reinterpret_cast<const half_t*>(wts + o.w_off);
+        a.bias = reinterpret_cast<const float*>(wts + o.b_off);
+        a.kh = o.p[P_KH]; a.kw = o.p[P_KW]; a.sh = o.p[P_SH]; a.sw = o.p[P_SW]; a.ph = o.p[P_PH]; a.pw = o.p[P_PW];
+        a.act = o.p[P_ACT]; a.act2 = o.p[P_ACT2]; a.Np = o.p[P_COUT]; a.Kp = o.p[P_KTOT];
+        a.inshift = o.p[P_INSHIFT]; a.resshift = o.p[P_RESSHIFT]; a.cinp = o.p[P_CINP]; a.flags = o.flags;
+        a.act_a = o.f[FS_ACT_A]; a.act_b = o.f[FS_ACT_B]; a.post_a = o.f[FS_POST_A]; a.post_b = o.f[FS_POST_B];
+        rc = launch_conv(a, st);
+    } else {
+        rc = launch_simple_op(o, in0, in1, in2, out, out2, wts, st);
+    }
+    if (rc != VSE_OK) set_err("op %d (kind %d) failed to launch: rc=%d (%s)", i, o.kind, rc, hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
+int vse_plan_run(vse_plan* p, void* ws, void* const* ext, int n_ext, void* stream) {
+    if (!p || !ext || n_ext <= p->max_ext) {
+        set_err("vse_plan_run: need %d external pointers", p ? p->max_ext + 1 : 0);
+        return VSE_E_INVAL;
+    }
+    if (!ws && p->ws_bytes) return VSE_E_INVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int i = 0; i < (int)p->ops.size(); ++i) {
+        int rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, st);
+        if (rc != VSE_OK) return rc;
+    }
+    return VSE_OK;
+}
+
+int vse_plan_profile(vse_plan* p, void* ws, void* const* ext, int n_ext, void* stream, float* ms) {
+    if (!p || !ext || !ms || n_ext <= p->max_ext) return VSE_E_INVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int n = (int)p->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipEventRecord(ev[0], st));
+    for (int i = 0; i < n; ++i) {
+        int rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, st);
+        if (rc != VSE_OK) return rc;
+        HIP_TRY(hipEventRecord(ev[i + 1], st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < n; ++i) HIP_TRY(hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return VSE_OK;
+}
+
+}  // extern "C"

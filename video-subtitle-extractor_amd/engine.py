@@ -1,0 +1,284 @@
+"""ctypes binding of libvse_hip.so (include/vse_hip.h) + plan cache on top of the graph compiler.
+
+PyTorch is plumbing here: device memory (torch.empty on cuda), streams and torch.distributed.  All compute
+goes through the C ABI; there is NO fallback — if the library or a gfx950 GPU is missing, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import compiler, ir
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvse_hip.so")
+
+EXPORTS = [
+    "vse_init", "vse_destroy", "vse_last_error", "vse_sizeof_op", "vse_sizeof_view", "vse_abi_version",
+    "vse_weights_upload", "vse_weights_free", "vse_plan_create", "vse_plan_destroy", "vse_plan_run",
+    "vse_plan_profile", "vse_det_preprocess", "vse_db_workspace_bytes", "vse_db_postprocess",
+    "vse_rec_preprocess", "vse_rec_preprocess_scratch_bytes", "vse_ctc_collapse",
+]
+
+
+class VseError(RuntimeError):
+    pass
+
+
+class DbParams(C.Structure):
+    _fields_ = [("thresh", C.c_float), ("box_thresh", C.c_float), ("unclip_ratio", C.c_float),
+                ("max_candidates", C.c_int), ("min_size", C.c_int)]
+
+
+class Box(C.Structure):
+    _fields_ = [("pts", C.c_float * 2 * 4), ("score", C.c_float), ("frame", C.c_int)]
+
+
+class Crop(C.Structure):
+    _fields_ = [("quad", C.c_float * 2 * 4), ("frame", C.c_int), ("crop_w", C.c_int), ("crop_h", C.c_int),
+                ("resized_w", C.c_int), ("rotate", C.c_int)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the C-ABI library and bind signatures.  Works without a GPU (used by the CPU test-suite to check
+    that every symbol of include/vse_hip.h is exported and that the record layouts agree)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise VseError(f"{path} not found: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
+                       "there is no CPU fallback for the OCR hot path")
+    lib = C.CDLL(path)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise VseError(f"libvse_hip.so does not export {name}")
+    lib.vse_last_error.restype = C.c_char_p
+    lib.vse_sizeof_op.restype = C.c_size_t
+    lib.vse_sizeof_view.restype = C.c_size_t
+    lib.vse_db_workspace_bytes.restype = C.c_size_t
+    lib.vse_db_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.vse_rec_preprocess_scratch_bytes.restype = C.c_size_t
+    lib.vse_rec_preprocess_scratch_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.vse_init.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.vse_destroy.argtypes = [C.c_void_p]
+    lib.vse_destroy.restype = None
+    lib.vse_weights_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.vse_weights_free.argtypes = [C.c_void_p, C.c_int]
+    lib.vse_plan_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.vse_plan_destroy.argtypes = [C.c_void_p]
+    lib.vse_plan_destroy.restype = None
+    lib.vse_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+    lib.vse_plan_profile.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+                                     C.POINTER(C.c_float)]
+    lib.vse_det_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                       C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                       C.c_void_p]
+    lib.vse_db_postprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(DbParams), C.c_void_p, C.c_size_t, C.POINTER(Box), C.c_int,
+                                       C.POINTER(C.c_int), C.c_void_p]
+    lib.vse_rec_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                       C.POINTER(Crop), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]
+    lib.vse_ctc_collapse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
+    if lib.vse_sizeof_op() != ir.OP_DT.itemsize or lib.vse_sizeof_view() != ir.VIEW_DT.itemsize:
+        raise VseError(f"ABI mismatch: vse_op {lib.vse_sizeof_op()} vs {ir.OP_DT.itemsize}, "
+                       f"vse_view {lib.vse_sizeof_view()} vs {ir.VIEW_DT.itemsize}")
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise VseError(f"{what} failed (rc={rc}): {load_library().vse_last_error().decode(errors='replace')}")
+    return rc
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise VseError("no HIP device visible: the OCR hot path runs only on MI355X (gfx950); no CPU fallback")
+    return torch
+
+
+class Context:
+    """One per (process, device)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.torch = _torch()
+        self.device = device
+        self.handle = C.c_void_p()
+        _check(self.lib.vse_init(device, C.byref(self.handle)), "vse_init")
+        self.tdev = self.torch.device("cuda", device)
+
+    def stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    def close(self):
+        if self.handle:
+            self.lib.vse_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    # ---- stand-alone stages ---------------------------------------------------------------------------
+    def det_preprocess(self, frames_u8, dst_h, dst_w, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        """frames_u8: cuda uint8 [N,H,W,3] (contiguous or row-pitched view) -> fp16 [N,dst_h,dst_w,8]."""
+        t = self.torch
+        assert frames_u8.dtype == t.uint8 and frames_u8.dim() == 4 and frames_u8.shape[3] == 3
+        assert frames_u8.stride(3) == 1 and frames_u8.stride(2) == 3
+        n, h, w, _ = frames_u8.shape
+        out = t.empty((n, dst_h, dst_w, 8), dtype=t.float16, device=self.tdev)
+        m = (C.c_float * 3)(*mean)
+        s = (C.c_float * 3)(*std)
+        _check(self.lib.vse_det_preprocess(self.handle, C.c_void_p(frames_u8.data_ptr()), n, h, w,
+                                           frames_u8.stride(1), frames_u8.stride(0), C.c_void_p(out.data_ptr()),
+                                           dst_h, dst_w, m, s, self.stream()), "vse_det_preprocess")
+        return out
+
+    def db_postprocess(self, prob, src_h, src_w, thresh=0.3, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000,
+                       min_size=3, max_boxes=None):
+        """prob: cuda fp32 [N,H,W] -> list (per frame) of (ndarray[k,4,2] float32, ndarray[k] float32)."""
+        t = self.torch
+        assert prob.dtype == t.float32 and prob.is_contiguous()
+        n, h, w = prob.shape
+        nbytes = self.lib.vse_db_workspace_bytes(n, h, w)
+        if getattr(self, "_db_ws", None) is None or self._db_ws.numel() < nbytes:
+            self._db_ws = t.empty(nbytes, dtype=t.uint8, device=self.tdev)
+        max_boxes = max_boxes or n * 1024
+        boxes = (Box * max_boxes)()
+        nb = C.c_int(0)
+        prm = DbParams(thresh, box_thresh, unclip_ratio, max_candidates, min_size)
+        _check(self.lib.vse_db_postprocess(self.handle, C.c_void_p(prob.data_ptr()), n, h, w, src_h, src_w,
+                                           C.byref(prm), C.c_void_p(self._db_ws.data_ptr()), nbytes, boxes,
+                                           max_boxes, C.byref(nb), self.stream()), "vse_db_postprocess")
+        arr = np.frombuffer(boxes, dtype=np.dtype([("pts", "<f4", (4, 2)), ("score", "<f4"), ("frame", "<i4")]),
+                            count=nb.value)
+        out = []
+        for f in range(n):
+            sel = arr[arr["frame"] == f]
+            out.append((sel["pts"].copy(), sel["score"].copy()))
+        return out
+
+    def rec_preprocess(self, frames_u8, crops, rec_h, rec_w):
+        """crops: list of dict(quad[4][2], frame, crop_w, crop_h, resized_w, rotate) -> fp16 [n,rec_h,rec_w,8]."""
+        t = self.torch
+        n = len(crops)
+        arr = (Crop * n)()
+        mw = mh = 1
+        for i, c in enumerate(crops):
+            for k in range(4):
+                arr[i].quad[k][0] = float(c["quad"][k][0])
+                arr[i].quad[k][1] = float(c["quad"][k][1])
+            arr[i].frame, arr[i].crop_w, arr[i].crop_h = c["frame"], c["crop_w"], c["crop_h"]
+            arr[i].resized_w, arr[i].rotate = c["resized_w"], c["rotate"]
+            mw, mh = max(mw, c["crop_w"]), max(mh, c["crop_h"])
+        nbytes = self.lib.vse_rec_preprocess_scratch_bytes(n, mw, mh)
+        if getattr(self, "_crop_ws", None) is None or self._crop_ws.numel() < nbytes:
+            self._crop_ws = t.empty(nbytes, dtype=t.uint8, device=self.tdev)
+        out = t.empty((n, rec_h, rec_w, 8), dtype=t.float16, device=self.tdev)
+        nf, h, w, _ = frames_u8.shape
+        _check(self.lib.vse_rec_preprocess(self.handle, C.c_void_p(frames_u8.data_ptr()), nf, h, w,
+                                           frames_u8.stride(1), frames_u8.stride(0), arr, n,
+                                           C.c_void_p(out.data_ptr()), rec_h, rec_w,
+                                           C.c_void_p(self._crop_ws.data_ptr()), nbytes, self.stream()),
+               "vse_rec_preprocess")
+        return out
+
+    def ctc_collapse(self, idx_maxp):
+        """idx_maxp: cuda [B,1,T,2] (int32 idx / fp32 prob bit-pairs, as float32 tensor) ->
+        (idx int32 [B,T], len int32 [B], conf fp32 [B]) cuda tensors."""
+        t = self.torch
+        b, tt = idx_maxp.shape[0], idx_maxp.shape[2]
+        oi = t.zeros((b, tt), dtype=t.int32, device=self.tdev)
+        ol = t.empty((b,), dtype=t.int32, device=self.tdev)
+        oc = t.empty((b,), dtype=t.float32, device=self.tdev)
+        _check(self.lib.vse_ctc_collapse(self.handle, C.c_void_p(idx_maxp.data_ptr()), b, tt,
+                                         C.c_void_p(oi.data_ptr()), C.c_void_p(ol.data_ptr()),
+                                         C.c_void_p(oc.data_ptr()), self.stream()), "vse_ctc_collapse")
+        return oi, ol, oc
+
+
+class Net:
+    """One model (descriptor + fp32 weights) with plans compiled per static input shape."""
+
+    def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True):
+        self.ctx = ctx
+        self.desc = desc
+        self.weights = weights
+        self.fetch_cols = fetch_cols
+        self.want_probs = want_probs
+        self.store = compiler.WeightStore()
+        self.plans = {}
+        self.wid = None
+        self.wbytes = 0
+        self.ws = None
+
+    def program(self, n, h, w):
+        key = (n, h, w)
+        if key not in self.plans:
+            prog = compiler.compile_model(self.desc, self.weights, n, h, w, self.fetch_cols, self.want_probs,
+                                          self.store)
+            self.plans[key] = [prog, None]
+        return self.plans[key][0]
+
+    def _ensure(self, key):
+        prog, handle = self.plans[key]
+        lib = self.ctx.lib
+        if self.wid is None or len(self.store.blob) != self.wbytes:
+            # (re-)upload the shared weight blob; plans created against an older blob are rebuilt lazily
+            blob = self.store.array()
+            if self.wid is not None:
+                for k, (p_, h_) in self.plans.items():
+                    if h_ is not None:
+                        lib.vse_plan_destroy(h_)
+                        self.plans[k][1] = None
+                lib.vse_weights_free(self.ctx.handle, self.wid)
+            self.wid = _check(lib.vse_weights_upload(self.ctx.handle, blob.ctypes.data_as(C.c_void_p), blob.nbytes),
+                              "vse_weights_upload")
+            self.wbytes = len(self.store.blob)
+            handle = None
+        if handle is None:
+            h = C.c_void_p()
+            ops = np.ascontiguousarray(prog.ops)
+            _check(lib.vse_plan_create(self.ctx.handle, self.wid, ops.ctypes.data_as(C.c_void_p), len(ops),
+                                       prog.ws_bytes, C.byref(h)), "vse_plan_create")
+            self.plans[key][1] = h
+            handle = h
+        t = self.ctx.torch
+        if self.ws is None or self.ws.numel() < prog.ws_bytes:
+            self.ws = t.zeros(max(prog.ws_bytes, 256), dtype=t.uint8, device=self.ctx.tdev)
+        return prog, handle
+
+    def _ext(self, prog, x):
+        t = self.ctx.torch
+        outs = [t.empty((o["n"], o["h"], o["w"], o["ld"]), dtype=t.float32, device=self.ctx.tdev)
+                for o in prog.outputs]
+        ptrs = (C.c_void_p * (1 + len(outs)))(x.data_ptr(), *[o.data_ptr() for o in outs])
+        return outs, ptrs
+
+    def run(self, x):
+        """x: cuda fp16 [N,H,W,8] NHWC (3 real channels).  Returns list of fp32 cuda tensors (prog.outputs order)."""
+        t = self.ctx.torch
+        assert x.dtype == t.float16 and x.is_contiguous() and x.shape[3] == 8, (x.dtype, x.shape)
+        n, h, w, _ = x.shape
+        self.program(n, h, w)
+        prog, handle = self._ensure((n, h, w))
+        outs, ptrs = self._ext(prog, x)
+        _check(self.ctx.lib.vse_plan_run(handle, C.c_void_p(self.ws.data_ptr()), ptrs, len(ptrs), self.ctx.stream()),
+               "vse_plan_run")
+        return outs
+
+    def profile(self, x):
+        """Per-op milliseconds (HIP events) for one run; returns (ms ndarray, program)."""
+        n, h, w, _ = x.shape
+        self.program(n, h, w)
+        prog, handle = self._ensure((n, h, w))
+        outs, ptrs = self._ext(prog, x)
+        ms = (C.c_float * len(prog.ops))()
+        _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(self.ws.data_ptr()), ptrs, len(ptrs),
+                                             self.ctx.stream(), ms), "vse_plan_profile")
+        return np.array(ms[:], dtype=np.float32), prog
