@@ -1,0 +1,144 @@
+"""GPU pre/post-processing kernels vs the CPU oracle: integer/byte work is compared bit-exactly."""
+import numpy as np
+import pytest
+
+from oracle import net_ref
+from oracle import pipeline_ref as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("hw", [(1080, 1920), (720, 1280), (360, 640), (544, 960), (97, 131)])
+def test_det_preprocess_bit_exact(ctx, hw):
+    import torch
+    rng = np.random.default_rng(hw[0])
+    n = 2
+    frames = rng.integers(0, 256, (n,) + hw + (3,), dtype=np.uint8)
+    rh, rw = P.det_resize_shape(*hw)
+    got = ctx.det_preprocess(torch.from_numpy(frames).cuda(), rh, rw).cpu().numpy()
+    assert got.shape == (n, rh, rw, 8) and np.all(got[..., 3:] == 0)
+    for f in range(n):
+        x, _ = P.det_preprocess(frames[f])
+        ref = x[0].transpose(1, 2, 0).astype(np.float16)          # the engine stores fp16
+        assert np.array_equal(got[f, ..., :3], ref)
+
+
+def test_det_preprocess_row_pitched_view(ctx):
+    """The reference passes sliced views (frame[cropped:], subtitle_ocr.py:283): non-owning, offset start."""
+    import torch
+    rng = np.random.default_rng(9)
+    frames = rng.integers(0, 256, (1, 200, 320, 3), dtype=np.uint8)
+    dev = torch.from_numpy(frames).cuda()
+    view = dev[:, 100:]
+    got = ctx.det_preprocess(view, 96, 320).cpu().numpy()
+    ref, _ = P.det_preprocess(frames[0, 100:])
+    assert ref.shape[2:] == (96, 320)
+    assert np.array_equal(got[0, ..., :3], ref[0].transpose(1, 2, 0).astype(np.float16))
+
+
+def _synthetic_maps(seed, n=3, h=160, w=256):
+    rng = np.random.default_rng(seed)
+    maps = np.zeros((n, h, w), np.float32)
+    for f in range(n):
+        for _ in range(int(rng.integers(1, 6))):
+            x0, y0 = int(rng.integers(5, w - 80)), int(rng.integers(5, h - 30))
+            bw, bh = int(rng.integers(8, 70)), int(rng.integers(3, 20))
+            ang = rng.uniform(-0.3, 0.3)
+            ys, xs = np.mgrid[0:h, 0:w]
+            u = (xs - x0) * np.cos(ang) + (ys - y0) * np.sin(ang)
+            v = -(xs - x0) * np.sin(ang) + (ys - y0) * np.cos(ang)
+            m = (u >= 0) & (u < bw) & (v >= 0) & (v < bh)
+            maps[f][m] = np.maximum(maps[f][m], rng.uniform(0.35, 0.99))
+        maps[f] += rng.uniform(0, 0.25, (h, w)).astype(np.float32) * (maps[f] == 0)
+    return maps
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_db_postprocess_matches_oracle(ctx, seed):
+    import torch
+    maps = _synthetic_maps(seed)
+    n, h, w = maps.shape
+    src_h, src_w = 2 * h + 7, 2 * w + 3
+    got = ctx.db_postprocess(torch.from_numpy(maps).cuda(), src_h, src_w)
+    total = 0
+    for f in range(n):
+        rb, rs = P.db_postprocess(maps[f], src_h, src_w)
+        gb, gs = got[f]
+        assert gb.shape == rb.shape, (f, gb, rb)
+        assert np.array_equal(gb, rb), (f, gb, rb)                 # integer pixel coordinates: exact
+        assert np.abs(gs - rs).max() < 1e-6 if len(rs) else True
+        total += len(rb)
+    assert total > 0
+
+
+def test_db_postprocess_on_real_detector_map(ctx):
+    import torch
+    from vse_amd import synth
+    frames = synth.make_frames(2, 540, 960, seed=11)
+    desc, w = net_ref.get_weights("V3_ch_det_fast")
+    maps = []
+    for f in frames:
+        x, _ = P.det_preprocess(f)
+        maps.append(net_ref.run_graph(desc, w, x)[0].numpy()[0, 0])
+    maps = np.stack(maps)
+    got = ctx.db_postprocess(torch.from_numpy(maps).cuda(), 540, 960)
+    nb = 0
+    for f in range(2):
+        rb, rs = P.db_postprocess(maps[f], 540, 960)
+        assert np.array_equal(got[f][0], rb)
+        nb += len(rb)
+    assert nb >= 2
+    empty = ctx.db_postprocess(torch.zeros((1, 64, 64), device="cuda"), 64, 64)
+    assert empty[0][0].shape == (0, 4, 2)
+
+
+def test_rec_preprocess_matches_oracle(ctx):
+    import torch
+    from vse_amd import pipeline, synth
+    frames, truth = synth.make_frames(2, 540, 960, seed=21, return_truth=True)
+    dev = torch.from_numpy(frames).cuda()
+    quads, specs = [], []
+    rng = np.random.default_rng(0)
+    for f, tr in enumerate(truth):
+        for (x0, y0, x1, y1, _t) in tr:
+            j = rng.uniform(-2, 2, (4, 2))
+            q = np.array([[x0, y0], [x1, y0 + 3], [x1, y1 + 3], [x0, y1]], np.float32) + j.astype(np.float32)
+            quads.append((f, q))
+    quads.append((0, np.array([[100, 50], [130, 50], [130, 200], [100, 200]], np.float32)))     # tall -> rot90
+    img_w = 640
+    for f, q in quads:
+        cw, ch, rot = pipeline.crop_geometry(q)
+        iw, ih = (ch, cw) if rot else (cw, ch)
+        rw = P.rec_resized_width(iw, ih, img_w)
+        specs.append(dict(quad=q, frame=f, crop_w=cw, crop_h=ch, resized_w=rw, rotate=rot))
+    got = ctx.rec_preprocess(dev, specs, 48, img_w).cpu().numpy()
+    for k, (f, q) in enumerate(quads):
+        crop = P.get_rotate_crop_image(frames[f], q)
+        ref = P.resize_norm_img(crop, img_w).transpose(1, 2, 0)
+        g = got[k, ..., :3].astype(np.float32)
+        # uint8 crop pixels can differ by 1 LSB where the bicubic sum lands on .5 (float association order);
+        # after the 48-high resize that is < 1/127.5 in normalised units
+        assert np.abs(g - ref).max() <= 2.0 / 127.5 + 1e-3, (k, np.abs(g - ref).max())
+        assert (np.abs(g - ref) > 1e-3).mean() < 0.01
+        assert np.all(got[k, :, specs[k]["resized_w"]:, :] == 0)
+
+
+def test_ctc_collapse_matches_oracle(ctx):
+    import torch
+    rng = np.random.default_rng(4)
+    b, t, c = 37, 150, 40
+    probs = rng.dirichlet(np.ones(c) * 0.3, size=(b, t)).astype(np.float32)
+    probs[0] = 0
+    probs[0, :, 0] = 1.0                                        # all blank
+    probs[1] = 0
+    probs[1, :, 5] = 1.0                                        # one long run -> a single symbol
+    idx = probs.argmax(-1).astype(np.int32)
+    mp = probs.max(-1).astype(np.float32)
+    pairs = np.stack([idx.view(np.float32), mp], -1).reshape(b, 1, t, 2)
+    oi, ol, oc = ctx.ctc_collapse(torch.from_numpy(np.ascontiguousarray(pairs)).cuda())
+    oi, ol, oc = oi.cpu().numpy(), ol.cpu().numpy(), oc.cpu().numpy()
+    for r in range(b):
+        ids, conf = P.ctc_greedy(probs[r])
+        assert oi[r, :ol[r]].tolist() == ids
+        assert abs(oc[r] - conf) < 1e-5
+    assert ol[0] == 0 and oc[0] == 0.0 and ol[1] == 1

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Per-op timing of one model on the GPU (HIP events inside vse_plan_profile).
+usage: python tools/gpu_profile_net.py MODEL N H W [--top K]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from vse_amd import engine, ir, modelzoo
+
+
+def op_macs(r):
+    if int(r["kind"]) != ir.OP_CONV:
+        return 0.0
+    p = r["p"]
+    o = r["out"]
+    m = int(o["n"]) * int(o["h"]) * int(o["w"])
+    if int(r["flags"]) & ir.F_PIXSHUF:
+        m //= 4
+    return m * float(p[ir.P_COUT]) * float(p[ir.P_KTOT])   # padded (executed) MACs
+
+
+def main():
+    mid = sys.argv[1]
+    n, h, w = (int(v) for v in sys.argv[2:5])
+    top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 25
+    desc, wts = modelzoo.get_model(mid)
+    ctx = engine.Context(0)
+    net = engine.Net(ctx, desc, wts, want_probs=False)
+    x = (torch.rand((n, h, w, 8), device="cuda") * 2 - 1).half()
+    x[..., 3:] = 0
+    for _ in range(2):
+        net.run(x)
+    torch.cuda.synchronize()
+    ms, prog = net.profile(x)
+    ms2, _ = net.profile(x)
+    ms = np.minimum(ms, ms2)
+    tot = ms.sum()
+    print(f"{mid} N={n} {h}x{w}: {len(ms)} ops, total {tot:.3f} ms, algorithmic {prog.gmacs:.2f} GMAC -> "
+          f"{2 * prog.gmacs / tot:.1f} TFLOP/s effective, ws {prog.ws_bytes / 1e9:.2f} GB")
+    bykind = {}
+    for k, r in enumerate(prog.ops):
+        bykind.setdefault(int(r["kind"]), [0.0, 0])
+        bykind[int(r["kind"])][0] += ms[k]
+        bykind[int(r["kind"])][1] += 1
+    print("by kind:", {k: (round(v[0], 3), v[1]) for k, v in sorted(bykind.items())})
+    order = np.argsort(-ms)[:top]
+    for k in order:
+        r = prog.ops[k]
+        p = r["p"]
+        o = r["out"]
+        macs = op_macs(r)
+        extra = ""
+        if int(r["kind"]) == ir.OP_CONV:
+            extra = (f"k{p[0]}x{p[1]} s{p[2]} cin{p[ir.P_CINP]} N{p[ir.P_COUT]} K{p[ir.P_KTOT]} "
+                     f"{2 * macs / ms[k] / 1e9:.0f} TF/s(padded)")
+        print(f"  op{k:3d} kind={int(r['kind']):2d} {ms[k]:8.3f} ms {100 * ms[k] / tot:5.1f}%  out[{o['n']},{o['h']},{o['w']},{o['c']}] "
+              f"{prog.names[k][:28]:28s} {extra}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+"""Host orchestration of the per-frame OCR hot path on top of the C-ABI engine (Python, as the reference's is).
+
+frames (uint8 BGR, device-resident) -> det pre-process -> DB det net -> DB post-process -> box ordering ->
+perspective crops + rec pre-process -> CTC rec net -> arg-max / CTC collapse -> (boxes, (text, score)).
+
+Replaces paddleocr's TextDetector / TextRecognizer / TextSystem as called from backend/tools/subtitle_detect.py:25
+and backend/tools/ocr.py:27.  Unlike the reference (one frame per call) every stage takes a BATCH of
+frames: frames are independent, so det runs N frames per launch and rec runs the crops of all N frames.
+
+Two recognition batching modes:
+  * "reference": per frame, crops sorted by w/h, chunks of rec_batch_num, each chunk padded to its own
+    max width — bit-for-bit the reference's grouping (batch composition changes logits).
+  * "bucketed": crops of all frames sorted by width and grouped into width buckets (multiples of `bucket`)
+    for throughput; padding differs from the reference grouping, so logits near the right edge may differ.
+"""
+import math
+
+import numpy as np
+
+from . import engine
+
+
+def det_resize_shape(h, w, limit_side_len=960):
+    """paddleocr DetResizeForTest type0, limit_type='max' (SURVEY App. C.1)."""
+    ratio = float(limit_side_len) / max(h, w) if max(h, w) > limit_side_len else 1.0
+    rh, rw = int(h * ratio), int(w * ratio)
+    return max(int(round(rh / 32) * 32), 32), max(int(round(rw / 32) * 32), 32)
+
+
+def sorted_boxes(boxes):
+    """paddleocr predict_system.sorted_boxes: top-to-bottom, then left-to-right within 10 px rows."""
+    bs = sorted(list(boxes), key=lambda b: (b[0][1], b[0][0]))
+    for i in range(len(bs) - 1):
+        for j in range(i, -1, -1):
+            if abs(bs[j + 1][0][1] - bs[j][0][1]) < 10 and bs[j + 1][0][0] < bs[j][0][0]:
+                bs[j], bs[j + 1] = bs[j + 1], bs[j]
+            else:
+                break
+    return bs
+
+
+def crop_geometry(q):
+    q = np.asarray(q, dtype=np.float32)
+    cw = int(max(np.linalg.norm(q[0] - q[1]), np.linalg.norm(q[2] - q[3])))
+    ch = int(max(np.linalg.norm(q[0] - q[3]), np.linalg.norm(q[1] - q[2])))
+    rotate = 1 if (cw > 0 and ch * 1.0 / cw >= 1.5) else 0
+    return cw, ch, rotate
+
+
+class OcrPipeline:
+    def __init__(self, ctx, det_model, rec_model, charset, rec_batch_num=6, rec_h=48, rec_base_w=320,
+                 limit_side_len=960, db_thresh=0.3, db_box_thresh=0.6, db_unclip_ratio=1.5, drop_score=0.0,
+                 rec_mode="reference", bucket=64):
+        """det_model / rec_model: (descriptor, weights dict)."""
+        self.ctx = ctx
+        self.det = engine.Net(ctx, det_model[0], det_model[1], fetch_cols=(0,))
+        self.rec = engine.Net(ctx, rec_model[0], rec_model[1], want_probs=False)
+        self.charset = charset
+        self.rec_batch_num = rec_batch_num
+        self.rec_h = rec_h
+        self.rec_base_w = rec_base_w
+        self.limit = limit_side_len
+        self.db = dict(thresh=db_thresh, box_thresh=db_box_thresh, unclip_ratio=db_unclip_ratio)
+        self.drop_score = drop_score
+        self.rec_mode = rec_mode
+        self.bucket = bucket
+
+    # ---- detection ---------------------------------------------------------------------------------------
+    def det_maps(self, frames):
+        """frames: cuda uint8 [N,H,W,3] -> cuda fp32 prob maps [N,h,w]."""
+        n, h, w, _ = frames.shape
+        rh, rw = det_resize_shape(h, w, self.limit)
+        x = self.ctx.det_preprocess(frames, rh, rw)
+        out = self.det.run(x)[0]            # [N,rh,rw,1] fp32
+        return out.view(n, rh, rw)
+
+    def detect(self, frames):
+        """-> list per frame of float32 [k,4,2] boxes (paddleocr TextDetector output, unsorted)."""
+        n, h, w, _ = frames.shape
+        prob = self.det_maps(frames)
+        res = self.ctx.db_postprocess(prob, h, w, **self.db)
+        return [r[0] for r in res]
+
+    # ---- recognition -------------------------------------------------------------------------------------
+    def _crop_specs(self, boxes_per_frame):
+        specs = []
+        for f, boxes in enumerate(boxes_per_frame):
+            for k, q in enumerate(boxes):
+                cw, ch, rot = crop_geometry(q)
+                iw, ih = (ch, cw) if rot else (cw, ch)
+                specs.append(dict(frame=f, slot=k, quad=np.asarray(q, np.float32), crop_w=max(cw, 1),
+                                  crop_h=max(ch, 1), rotate=rot, ratio=(iw / float(ih)) if ih > 0 else 1.0,
+                                  iw=max(iw, 1), ih=max(ih, 1)))
+        return specs
+
+    def _groups(self, specs):
+        """-> list of (list of spec indices, img_w)."""
+        groups = []
+        base = self.rec_base_w / float(self.rec_h)
+        if self.rec_mode == "reference":
+            by_frame = {}
+            for i, s in enumerate(specs):
+                by_frame.setdefault(s["frame"], []).append(i)
+            for f in sorted(by_frame):
+                idx = by_frame[f]
+                order = [idx[j] for j in np.argsort(np.array([specs[i]["ratio"] for i in idx]), kind="stable")]
+                for b in range(0, len(order), self.rec_batch_num):
+                    chunk = order[b:b + self.rec_batch_num]
+                    mx = max([base] + [specs[i]["ratio"] for i in chunk])
+                    groups.append((chunk, int(self.rec_h * mx)))
+        else:
+            def wneed(s):
+                return max(self.rec_base_w, int(math.ceil(self.rec_h * s["ratio"])))
+            buckets = {}
+            for i, s in enumerate(specs):
+                wb = (wneed(s) + self.bucket - 1) // self.bucket * self.bucket
+                buckets.setdefault(wb, []).append(i)
+            for wb in sorted(buckets):
+                groups.append((buckets[wb], wb))
+        return groups
+
+    def recognize(self, frames, boxes_per_frame):
+        """boxes_per_frame: list (len N) of sequences of 4x2 quads (already in the order results are wanted).
+        -> list per frame of [(text, score)]."""
+        t = self.ctx.torch
+        specs = self._crop_specs(boxes_per_frame)
+        results = [[("", 0.0)] * len(b) for b in boxes_per_frame]
+        if not specs:
+            return results
+        pending = []
+        for idx, img_w in self._groups(specs):
+            crops = []
+            for i in idx:
+                s = specs[i]
+                rw = min(img_w, int(math.ceil(self.rec_h * s["ratio"])))
+                crops.append(dict(quad=s["quad"], frame=s["frame"], crop_w=s["crop_w"], crop_h=s["crop_h"],
+                                  resized_w=max(rw, 1), rotate=s["rotate"]))
+            x = self.ctx.rec_preprocess(frames, crops, self.rec_h, img_w)
+            idx_maxp = self.rec.run(x)[-1]                 # [B,1,T,2]
+            oi, ol, oc = self.ctx.ctc_collapse(idx_maxp)
+            pending.append((idx, oi, ol, oc))
+        for idx, oi, ol, oc in pending:                      # one sync per group at the end
+            oi, ol, oc = oi.cpu().numpy(), ol.cpu().numpy(), oc.cpu().numpy()
+            for k, i in enumerate(idx):
+                s = specs[i]
+                ids = oi[k, :ol[k]]
+                text = "".join(self.charset[j] for j in ids)
+                results[s["frame"]][s["slot"]] = (text, float(oc[k]))
+        return results
+
+    # ---- TextSystem.__call__(img, cls=False) for a batch ------------------------------------------------
+    def ocr(self, frames):
+        """-> list per frame of (list of float32 [4,2] boxes, list of (text, score)) — paddleocr TextSystem output."""
+        det = self.detect(frames)
+        ordered = [sorted_boxes(b) for b in det]
+        rec = self.recognize(frames, ordered)
+        out = []
+        for boxes, res in zip(ordered, rec):
+            fb, fr = [], []
+            for b, r in zip(boxes, res):
+                if r[1] >= self.drop_score:
+                    fb.append(b)
+                    fr.append(r)
+            out.append((fb, fr))
+        return out

@@ -1,0 +1,321 @@
+"""Drop-in replacements for the reference's OCR call sites, backed by the HIP engine.
+
+Mirrors (same names, argument meaning, return shapes, error behaviour):
+  SubtitleDetect().detect_subtitle(img) -> (ndarray[N,4,2] float32, elapse)     backend/tools/subtitle_detect.py:5-26
+  OcrRecogniser().predict(img) -> (list of 4 (x,y) int tuples, list of (text, score))   backend/tools/ocr.py:9-113
+  get_coordinates(dt_box) -> list of (xmin,xmax,ymin,ymax)                       backend/tools/ocr.py:115-134
+  PaddleModelConfig(hardware_accelerator)                                        backend/tools/paddle_model_config.py:7-106
+  HardwareAccelerator                                                            backend/tools/hardware_accelerator.py:4-93
+  TextDetector(args)(img), TextRecognizer(args)(img_list), PaddleOCR(**kw)(img, cls=False)   (paddleocr 2.10 API)
+plus batch variants (`detect_subtitle_batch`, `predict_batch`) that the reference lacks (it never batches, F4).
+
+`config` is a plain namespace with the knobs the reference reads from qfluentwidgets (backend/config.py:52-90).
+"""
+import os
+import time
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import engine, modelzoo, pipeline
+
+config = SimpleNamespace(language="ch", mode="fast", recBatchNumber=6, maxBatchSize=10, dropScore=75,
+                         subtitleAreaDeviationRate=0, hardwareAcceleration=True, device=0,
+                         allow_standin_weights=False, weights_dir=None)
+
+LATIN_LANG = ['af', 'az', 'bs', 'cs', 'cy', 'da', 'de', 'es', 'et', 'fr', 'ga', 'hr', 'hu', 'id', 'is', 'it', 'ku',
+              'la', 'lt', 'lv', 'mi', 'ms', 'mt', 'nl', 'no', 'oc', 'pi', 'pl', 'pt', 'ro', 'rs_latin', 'sk', 'sl',
+              'sq', 'sv', 'sw', 'tl', 'tr', 'uz', 'vi', 'latin', 'german', 'french']
+ARABIC_LANG = ['ar', 'fa', 'ug', 'ur']
+CYRILLIC_LANG = ['ru', 'rs_cyrillic', 'be', 'bg', 'uk', 'mn', 'abq', 'ady', 'kbd', 'ava', 'dar', 'inh', 'che', 'lbe',
+                 'lez', 'tab', 'cyrillic']
+DEVANAGARI_LANG = ['hi', 'mr', 'ne', 'bh', 'mai', 'ang', 'bho', 'mah', 'sck', 'new', 'gom', 'sa', 'bgc', 'devanagari']
+OTHER_LANG = ['ch', 'japan', 'korean', 'en', 'ta', 'kn', 'te', 'ka', 'chinese_cht']
+
+
+class HardwareAccelerator:
+    """backend/tools/hardware_accelerator.py: here the only accelerator is a gfx950 HIP device."""
+    _instance = None
+
+    @classmethod
+    def instance(cls):
+        if cls._instance is None:
+            cls._instance = HardwareAccelerator()
+            cls._instance.initialize()
+        return cls._instance
+
+    def __init__(self):
+        self._hip = False
+        self._enabled = True
+
+    def initialize(self):
+        try:
+            import torch
+            self._hip = bool(torch.cuda.is_available())
+        except Exception:
+            self._hip = False
+
+    def has_accelerator(self):
+        return self._enabled and self._hip
+
+    def has_cuda(self):          # name kept for call-compatibility (backend/tools/ocr.py:92)
+        return self.has_accelerator()
+
+    @property
+    def onnx_providers(self):
+        return []
+
+    @property
+    def accelerator_name(self):
+        return "MI355X (HIP)" if self.has_accelerator() else "CPU"
+
+    def set_enabled(self, enable):
+        self._enabled = enable
+
+
+class PaddleModelConfig:
+    """Model choice matrix of backend/tools/paddle_model_config.py:53-91 over the model ids under models/."""
+
+    def __init__(self, hardware_accelerator):
+        self.hardware_accelerator = hardware_accelerator
+        lang = config.language
+        self.REC_CHAR_TYPE = lang
+        self.MODEL_VERSION = 'V4'
+        self.REC_IMAGE_SHAPE = '3,48,320'
+        ver = 'V4'
+        det, rec = f'{lang}_det', f'{lang}_rec'
+        if lang in LATIN_LANG + ARABIC_LANG + CYRILLIC_LANG + DEVANAGARI_LANG + OTHER_LANG:
+            if config.mode == 'fast':
+                det, rec = 'ch_det_fast', f'{lang}_rec_fast'
+            elif config.mode == 'auto':
+                if hardware_accelerator.has_accelerator():
+                    det = 'ch_det'
+                    rec = 'ch_rec' if lang == 'en' else f'{lang}_rec'
+                else:
+                    det, rec = 'ch_det_fast', f'{lang}_rec_fast'
+            else:
+                det, rec = 'ch_det', f'{lang}_rec'
+            if not self._exists(ver, rec):
+                rec = f'{lang}_rec_fast'
+            if not self._exists(ver, rec):
+                ver, rec = 'V3', f'{lang}_rec'
+            if not self._exists(ver, rec):
+                ver, rec = 'V3', f'{lang}_rec_fast'
+            if lang in LATIN_LANG:
+                rec = 'latin_rec_fast'
+            elif lang in ARABIC_LANG:
+                rec = 'arabic_rec_fast'
+            elif lang in CYRILLIC_LANG:
+                rec = 'cyrillic_rec_fast'
+            elif lang in DEVANAGARI_LANG:
+                rec = 'devanagari_rec_fast'
+            self.MODEL_VERSION = ver
+            self.REC_IMAGE_SHAPE = '3,32,320' if ver == 'V2' else '3,48,320'
+        self.DET_MODEL_PATH = f'V4_{det}'        # det path is computed while MODEL_VERSION == 'V4' (App. D)
+        self.REC_MODEL_PATH = f'{ver}_{rec}'
+
+    @staticmethod
+    def _exists(ver, name):
+        return os.path.exists(os.path.join(modelzoo.MODELS_DIR, f'{ver}_{name}.json'))
+
+    def convertToOnnxModelIfNeeded(self, model_dir, *a, **k):   # identity: no ONNX path here
+        return model_dir
+
+
+def charset_for(lang, ncls):
+    """['blank'] + dictionary + [' '].  Only the 95-entry `en` dictionary order is known here;
+    other languages get a stand-in table (the dictionary files live inside the paddleocr wheel)."""
+    if lang == "en" and ncls == 97:
+        chars = [chr(c) for c in range(0x30, 0x7F)] + [chr(c) for c in range(0x21, 0x30)] + [" "]
+        return ["blank"] + chars + [" "]
+    return ["blank"] + [chr(0x4E00 + i) for i in range(ncls - 2)] + [" "]
+
+
+def _load_model(model_id):
+    desc = modelzoo.load_descriptor(model_id)
+    cands = [os.path.join(d, model_id + ".npz") for d in (config.weights_dir, modelzoo.MODELS_DIR) if d]
+    for p in cands:
+        if os.path.exists(p):
+            return desc, modelzoo.load_weights_npz(p)
+    if config.allow_standin_weights:
+        return desc, modelzoo.random_weights(desc)
+    raise FileNotFoundError(f"weights for {model_id} not found ({cands}); the reference checkout ships them only for "
+                            "V3_ch_det_fast — convert inference.pdiparams with tools/pdmodel_convert.py")
+
+
+def _ncls(desc):
+    last = [op for op in desc["ops"] if op["type"] in ("matmul_v2", "matmul")][-1]
+    return desc["params"][last["in"]["Y"][0]]["dims"][1]
+
+
+_ctx = None
+
+
+def _context():
+    global _ctx
+    if _ctx is None:
+        _ctx = engine.Context(config.device)
+    return _ctx
+
+
+def _to_device(img):
+    import torch
+    if isinstance(img, torch.Tensor):
+        return img if img.dim() == 4 else img[None]
+    a = np.ascontiguousarray(img)          # accepts sliced views like frame[cropped:] (subtitle_ocr.py:283)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("expected uint8 BGR HxWx3 image")
+    return torch.from_numpy(a).to(_context().tdev)[None]
+
+
+class SubtitleDetect:
+    """backend/tools/subtitle_detect.py:5-26."""
+
+    def __init__(self):
+        hw = HardwareAccelerator.instance()
+        mc = PaddleModelConfig(hw)
+        self.text_detector = TextDetector(SimpleNamespace(det_model_dir=mc.DET_MODEL_PATH, det_algorithm='DB'))
+
+    def detect_subtitle(self, img):
+        return self.text_detector(img)
+
+    def detect_subtitle_batch(self, frames):
+        return self.text_detector.batch(frames)
+
+
+class TextDetector:
+    def __init__(self, args):
+        if getattr(args, "det_algorithm", "DB") != "DB":
+            raise NotImplementedError("only DB detection exists in the reference (SURVEY F9)")
+        model = _load_model(args.det_model_dir)
+        ctx = _context()
+        self.pipe = pipeline.OcrPipeline.__new__(pipeline.OcrPipeline)
+        self.pipe.ctx = ctx
+        self.pipe.det = engine.Net(ctx, model[0], model[1], fetch_cols=(0,))
+        self.pipe.limit = getattr(args, "det_limit_side_len", 960)
+        self.pipe.db = dict(thresh=getattr(args, "det_db_thresh", 0.3), box_thresh=getattr(args, "det_db_box_thresh", 0.6),
+                            unclip_ratio=getattr(args, "det_db_unclip_ratio", 1.5))
+
+    def __call__(self, img):
+        t0 = time.time()
+        boxes = self.pipe.detect(_to_device(img))[0]
+        return np.asarray(boxes, dtype=np.float32).reshape(-1, 4, 2), time.time() - t0
+
+    def batch(self, frames):
+        return self.pipe.detect(frames)
+
+
+class PaddleOCR:
+    """PaddleOCR(**kwargs)(img, cls=False) -> (boxes, rec_res, time_dict) as used at backend/tools/ocr.py:27,91-113."""
+
+    def __init__(self, det_model_dir=None, rec_model_dir=None, rec_batch_num=6, drop_score=0.5, lang="ch",
+                 use_angle_cls=False, rec_image_shape="3,48,320", rec_mode="reference", **_ignored):
+        if use_angle_cls:
+            raise NotImplementedError("angle classifier is never enabled by the reference (ocr.py:104)")
+        det = _load_model(det_model_dir)
+        rec = _load_model(rec_model_dir)
+        shp = [int(v) for v in rec_image_shape.split(",")]
+        self.pipe = pipeline.OcrPipeline(_context(), det, rec, charset_for(lang, _ncls(rec[0])),
+                                         rec_batch_num=rec_batch_num, rec_h=shp[1], rec_base_w=shp[2],
+                                         drop_score=drop_score, rec_mode=rec_mode)
+
+    def __call__(self, img, cls=False):
+        t0 = time.time()
+        boxes, res = self.pipe.ocr(_to_device(img))[0]
+        return boxes, res, {"all": time.time() - t0}
+
+    def batch(self, frames):
+        return self.pipe.ocr(frames)
+
+
+class OcrRecogniser:
+    """backend/tools/ocr.py:9-113."""
+
+    def __init__(self):
+        self.recogniser = None
+        self.hardware_accelerator = HardwareAccelerator()
+
+    @staticmethod
+    def y_round(y):
+        y_min = y + 10 - y % 10
+        y_max = y - y % 10
+        return y_min if abs(y - y_min) < abs(y - y_max) else y_max
+
+    def init_model(self):
+        mc = PaddleModelConfig(self.hardware_accelerator)
+        return PaddleOCR(det_model_dir=mc.DET_MODEL_PATH, rec_model_dir=mc.REC_MODEL_PATH,
+                         rec_batch_num=config.recBatchNumber, drop_score=0, lang=mc.REC_CHAR_TYPE,
+                         use_angle_cls=False, rec_image_shape=mc.REC_IMAGE_SHAPE)
+
+    def predict(self, image):
+        if not self.recogniser:
+            self.recogniser = self.init_model()
+        detection_box, recognise_result, _ = self.recogniser(image, cls=False)
+        return self.arrange(detection_box, recognise_result)
+
+    def predict_batch(self, frames):
+        if not self.recogniser:
+            self.recogniser = self.init_model()
+        return [self.arrange(b, r) for b, r in self.recogniser.batch(frames)]
+
+    @classmethod
+    def arrange(cls, detection_box, recognise_result):
+        """Line grouping / ordering of ocr.py:28-86 (a3)."""
+        if len(detection_box) == 0:
+            return detection_box, recognise_result
+        coords = [list(_aabb(q)) for q in detection_box] if isinstance(detection_box, list) else []
+        lines = []
+        for c in coords:
+            yr = cls.y_round(c[2])
+            if len(lines) < 1 or (yr not in lines and yr + 10 not in lines and yr - 10 not in lines):
+                lines.append(yr)
+        lines = sorted(lines)
+        for c in coords:
+            for j in lines:
+                if abs(j - cls.y_round(c[2])) <= 10:
+                    c[2] = j
+        pairs = list(zip(coords, recognise_result))
+        ranked = []
+        for line in lines:
+            row = [p for p in pairs if p[0][2] == line]
+            for l in range(1, len(row)):             # bubble sort by xmin, like the reference (stable, O(n^2))
+                for j in range(0, len(row) - l):
+                    if row[j][0][0] > row[j + 1][0][0]:
+                        row[j], row[j + 1] = row[j + 1], row[j]
+            ranked += row
+        dt_box = [[(c[0], c[2]), (c[1], c[2]), (c[1], c[3]), (c[0], c[3])] for c, _ in ranked]
+        return dt_box, [r for _, r in ranked]
+
+
+def _aabb(q):
+    q = list(q)
+    x1, y1 = int(q[0][0]), int(q[0][1])
+    x2, y2 = int(q[1][0]), int(q[1][1])
+    x3, y3 = int(q[2][0]), int(q[2][1])
+    x4, y4 = int(q[3][0]), int(q[3][1])
+    return max(x1, x4), min(x2, x3), max(y1, y2), min(y3, y4)
+
+
+def get_coordinates(dt_box):
+    """backend/tools/ocr.py:115-134 — note: returns [] unless `dt_box` is a python list (callers pass .tolist())."""
+    out = []
+    if isinstance(dt_box, list):
+        for q in dt_box:
+            out.append(_aabb(q))
+    return out
+
+
+def subtitle_area_keep(coordinate, prob, sub_area, deviation_rate=None, drop_score=None):
+    """Area / confidence filter of extract_subtitles (backend/tools/subtitle_ocr.py:42-67) on axis-aligned rectangles.
+    coordinate = (xmin,xmax,ymin,ymax); sub_area has .xmin .xmax .ymin .ymax."""
+    deviation_rate = config.subtitleAreaDeviationRate if deviation_rate is None else deviation_rate
+    drop_score = config.dropScore / 100.0 if drop_score is None else drop_score
+    xmin, xmax, ymin, ymax = coordinate
+    ix0, ix1 = max(xmin, sub_area.xmin), min(xmax, sub_area.xmax)
+    iy0, iy1 = max(ymin, sub_area.ymin), min(ymax, sub_area.ymax)
+    if ix0 > ix1 or iy0 > iy1:
+        return False
+    inter = max(0, ix1 - ix0) * max(0, iy1 - iy0)
+    a_area = (sub_area.xmax - sub_area.xmin) * (sub_area.ymax - sub_area.ymin)
+    b_area = (xmax - xmin) * (ymax - ymin)
+    return (a_area + b_area - inter) / a_area - 1 <= deviation_rate and prob > drop_score
