@@ -579,10 +579,19 @@ class Compiler:
         mat, coutp, Kp = self.pack_conv_weights(w4, ep["scale"], x)
         bias = np.zeros(coutp, np.float32)
         bias[:cout] = ep["shift"]
-        out = self.alloc_out(ep["out_name"], x.n, x.h, x.w, cout)
+        # logits that feed the final class softmax stay fp32 (fp16 ulp at |logit|~10 is 8e-3: too coarse for the
+        # 1e-3 tolerance on the recogniser's probabilities)
+        cons = self._live_consumers(ep["out_name"])
+        to_softmax = len(cons) == 1 and self.ops[cons[0]]["type"] == "softmax"
+        flags = 0
+        if to_softmax:
+            ob = self.new_buf(x.n, x.h, x.w, coutp, esize=4)
+            out = View(ob, 0, x.n, x.h, x.w, [(0, cout)], coutp)
+            flags |= ir.F_OUT_F32
+        else:
+            out = self.alloc_out(ep["out_name"], x.n, x.h, x.w, cout)
         out.tag = x.tag
         ins = [x]
-        flags = 0
         if ep["res"] is not None:
             r = ep["res"]
             assert (r.n, r.h, r.w, r.c) == (x.n, x.h, x.w, cout) and r.up == 0

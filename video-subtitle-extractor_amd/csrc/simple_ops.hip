@@ -341,12 +341,13 @@ __global__ __launch_bounds__(256) void attn_kernel(TView qkv, TView out, int hea
 // ------------------------------------------------------------------------------------------------ class softmax
 // One block per (b,t) row of logits: max, sum-exp, arg-max (first index on ties, like numpy argmax);
 // writes {argmax:int32, maxprob:fp32} and optionally the full fp32 probability row.
+template <typename T>
 __global__ __launch_bounds__(256) void softmax_kernel(TView in, TView idxp, TView probs, int ncls, int want_probs) {
     __shared__ float smax[4];
     __shared__ int sidx[4];
     __shared__ float ssum[4];
     const long row = blockIdx.x;
-    const half_t* x = reinterpret_cast<const half_t*>(in.ptr) + row * in.ld;
+    const T* x = reinterpret_cast<const T*>(in.ptr) + row * in.ld;
     float mx = -1e30f;
     int mi = 0x7fffffff;
     for (int c = threadIdx.x; c < ncls; c += blockDim.x) {
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(256) void softmax_kernel(TView in, TView idxp, TVie
     for (int q = 1; q < 4; ++q)
         if (smax[q] > mx || (smax[q] == mx && sidx[q] < mi)) { mx = smax[q]; mi = sidx[q]; }
     float s = 0.f;
-    for (int c = threadIdx.x; c < ncls; c += blockDim.x) s += __expf((float)x[c] - mx);
+    for (int c = threadIdx.x; c < ncls; c += blockDim.x) s += expf((float)x[c] - mx);
     for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) ssum[wave] = s;
     __syncthreads();
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) void softmax_kernel(TView in, TView idxp, TVie
     }
     if (want_probs) {
         float* pr = reinterpret_cast<float*>(probs.ptr) + row * probs.ld;
-        for (int c = threadIdx.x; c < ncls; c += blockDim.x) pr[c] = __expf((float)x[c] - mx) * inv;
+        for (int c = threadIdx.x; c < ncls; c += blockDim.x) pr[c] = expf((float)x[c] - mx) * inv;
     }
 }
 
@@ -500,8 +501,12 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
         }
         case OP_SOFTMAX: {
             const long rows = (long)in0.n * in0.h * in0.w;
-            hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)rows), dim3(256), 0, st, in0, out, out2, p[0],
-                               out2.ptr != nullptr ? 1 : 0);
+            if (in0.esize == 4)
+                hipLaunchKernelGGL(softmax_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, in0, out, out2, p[0],
+                                   out2.ptr != nullptr ? 1 : 0);
+            else
+                hipLaunchKernelGGL(softmax_kernel<half_t>, dim3((unsigned)rows), dim3(256), 0, st, in0, out, out2, p[0],
+                                   out2.ptr != nullptr ? 1 : 0);
             break;
         }
         case OP_LSTM: {

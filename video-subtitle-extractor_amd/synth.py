@@ -47,7 +47,7 @@ def make_frames(n, height=1080, width=1920, seed=0, p_two_lines=0.2, return_trut
     grad = np.linspace(0, 40, height, dtype=np.float32)[:, None, None]
     scale = height / 1080.0
     for f in range(n):
-        base = rng.integers(30, 91, size=(height // 4, width // 4, 3), dtype=np.uint8)
+        base = rng.integers(30, 91, size=((height + 3) // 4, (width + 3) // 4, 3), dtype=np.uint8)
         img = np.repeat(np.repeat(base, 4, 0), 4, 1)[:height, :width].astype(np.float32) + grad
         lines = 2 if rng.random() < p_two_lines else 1
         gh = int(rng.integers(54, 67) * scale)
