@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: OCR frames/sec (DB detect + CTC recognise) on synthetic 1080p frames (BASELINE.json).
+
+A "step" = one pass of the hot path over one batch of 64 device-resident 1080p frames per GPU:
+  det pre-process -> V4/ch_det (server DB detector, 389.4 GFLOP/frame @544x960) -> DB post-process ->
+  perspective crops of the text lines -> V4/ch_rec (server recogniser, SVTR neck + CTC) -> arg-max + CTC collapse
+  -> text decode -> (N>1: one variable-length gather of the records to rank 0).
+
+Weights: the reference checkout ships no weights for the V4 server models, so they are seeded random
+stand-ins of the exact architectures ("data": "synthetic").  A random detector's probability map carries no
+information about the frame, so the recogniser is fed the generator's ground-truth line boxes (1-2 lines/frame,
+SURVEY §8(d) C2), while the DB post-process still runs on the detector's real output every step.
+`--boxes db --models fast-real` runs the fully data-driven path with the one real-weight detector instead.
+
+Contract: python bench.py --gpus N --steps K --warmup W ; for N>1 launched by torch.distributed.run, one rank per
+GPU.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--models", default="server", choices=["server", "fast", "fast-real"])
+    ap.add_argument("--boxes", default="gt", choices=["gt", "db"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def empty_det_head(desc, weights, bias=-8.0):
+    """Push the (random-weight) detector's output below the 0.3 bitmap threshold so that the DB post-process sees a
+    sparse map, as it does on real subtitles, instead of coin-flip noise."""
+    last_sig = [op for op in desc["ops"] if op["type"] == "sigmoid"][-1]
+    prod = {o: op for op in desc["ops"] for outs in op["out"].values() for o in outs}
+    op = prod[last_sig["in"]["X"][0]]
+    assert op["type"] == "elementwise_add"
+    b = op["in"]["Y"][0]
+    weights[b] = np.full_like(weights[b], bias)
+    return weights
+
+
+def gt_quads(truth):
+    out = []
+    for tr in truth:
+        qs = []
+        for (x0, y0, x1, y1, _t) in tr:
+            qs.append(np.array([[x0 - 4, y0 - 4], [x1 + 4, y0 - 4], [x1 + 4, y1 + 4], [x0 - 4, y1 + 4]], np.float32))
+        out.append(qs)
+    return out
+
+
+def cpu_baseline(args, frames, truth, det, rec, charset):
+    """The oracle (CPU restatement, torch fp32, all host threads) on a bounded sample of the same workload."""
+    import torch
+    from oracle import net_ref, pipeline_ref as P
+    nthreads = os.cpu_count() or 1
+    torch.set_num_threads(nthreads)
+    n = 2
+    t0 = time.time()
+    for f in range(n):
+        x, _ = P.det_preprocess(frames[f])
+        prob = net_ref.run_graph(det[0], det[1], x)[0].numpy()[0, 0]
+        P.db_postprocess(prob, frames.shape[1], frames.shape[2])
+        quads = gt_quads([truth[f]])[0]
+        crops = [P.get_rotate_crop_image(frames[f], q) for q in quads]
+        for idx, img_w in P.rec_batches(crops, 6):
+            batch = np.stack([P.resize_norm_img(crops[i], img_w) for i in idx])
+            probs = net_ref.run_graph(rec[0], rec[1], batch)[0].numpy()
+            for k in range(len(idx)):
+                ids, _ = P.ctc_greedy(probs[k])
+                P.decode_text(ids, charset)
+    dt = time.time() - t0
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n} of the same synthetic {frames.shape[1]}p frames, batch 1 per frame like the reference, "
+                      f"oracle/ (torch-CPU fp32 restatement; Paddle itself is not installable here)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from vse_amd import engine, modelzoo, parallel, pipeline, shim, synth
+
+    ctx = engine.Context(local)
+    if args.models == "server":
+        det_id, rec_id, lang = "V4_ch_det", "V4_ch_rec", "ch"
+    elif args.models == "fast":
+        det_id, rec_id, lang = "V4_ch_det_fast", "V4_ch_rec_fast", "ch"
+    else:
+        det_id, rec_id, lang = "V3_ch_det_fast", "V4_en_rec_fast", "en"
+    det = modelzoo.get_model(det_id, seed=0)
+    rec = modelzoo.get_model(rec_id, seed=1)
+    if not modelzoo.has_real_weights(det_id):
+        det = (det[0], empty_det_head(det[0], det[1]))
+    charset = shim.charset_for(lang, shim._ncls(rec[0]))
+    pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="bucketed", bucket=64, batch_round=8)
+
+    frames_np, truth = synth.make_frames(args.batch, args.height, args.width, seed=100 + rank, return_truth=True)
+    frames = torch.from_numpy(frames_np).to(ctx.tdev)          # inputs resident in HBM before the timed region
+    quads = gt_quads(truth)
+    lo = rank * args.batch
+
+    def step():
+        maps = pipe.det_maps(frames)
+        db = ctx.db_postprocess(maps, args.height, args.width, **pipe.db)
+        boxes = [pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads
+        res = pipe.recognize(frames, boxes)
+        recs = [(lo + f, np.asarray(boxes[f], np.float32).reshape(-1, 4, 2), res[f]) for f in range(args.batch)]
+        return parallel.gather_records(recs, device=ctx.tdev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=ctx.tdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        n_lines = sum(len(q) for q in quads)
+        total_frames = world * args.batch * args.steps
+        result = {
+            "metric": "OCR frames/sec (det+rec) @1080p", "value": round(total_frames / dt, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.batch}x{args.height}p frames/GPU/step, precise mode: {det_id} @544x960 + "
+                                   f"{rec_id}, {n_lines} text lines/batch, rec boxes={args.boxes}, rec batching=bucketed(64px)",
+                       "frames_per_gpu_step": args.batch, "det_model": det_id, "rec_model": rec_id,
+                       "weights": "real" if modelzoo.has_real_weights(det_id) else "seeded random (reference blobs missing)",
+                       "records_gathered": len(out) if out is not None else 0},
+        }
+        if not args.no_roofline:
+            result["roofline"] = roofline(pipe, frames, args)
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import pipeline_ref as P
+            cs = P.standin_charset(shim._ncls(rec[0])) if lang != "en" else P.en_charset()
+            result["cpu_baseline"] = cpu_baseline(args, frames_np, truth, det, rec, cs)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def roofline(pipe, frames, args):
+    """Dominant kernel = the conv_mfma_kernel instantiation with the largest total time in the detector step.
+    achieved = algorithmic conv FLOPs routed to it / its summed launch durations (HIP events on the launch stream)."""
+    import torch
+    from vse_amd import ir, pipeline as pl
+    n, h, w, _ = frames.shape
+    rh, rw = pl.det_resize_shape(h, w, pipe.limit)
+    x = pipe.ctx.det_preprocess(frames, rh, rw)
+    best = None
+    for _ in range(3):
+        ms, prog, variants = pipe.det.profile(x)
+        best = ms if best is None else np.minimum(best, ms)
+    agg = {}
+    for k, r in enumerate(prog.ops):
+        if int(r["kind"]) != ir.OP_CONV:
+            continue
+        a = agg.setdefault(variants[k], [0.0, 0.0, 0])
+        a[0] += best[k]
+        a[1] += prog.op_gmacs[k]
+        a[2] += 1
+    bn, (tms, gmac, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+    tile = {128: "128,128,2,2", 64: "128,64,2,2", 32: "256,32,4,1"}[bn]
+    achieved = 2.0 * gmac / tms          # GMAC/ms*2 = TFLOP/s
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": f"conv_mfma_kernel<{tile}>", "launches_per_step": cnt,
+            "avg_launch_us": round(1e3 * tms / cnt, 2), "algorithmic_gflop_per_step": round(2 * gmac, 1),
+            "all_conv_tflops": round(2.0 * sum(v[1] for v in agg.values()) / sum(v[0] for v in agg.values()), 2),
+            "det_step_ms": round(float(best.sum()), 3)}
+
+
+if __name__ == "__main__":
+    main()

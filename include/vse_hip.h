@@ -81,6 +81,10 @@ int vse_plan_run(vse_plan* plan, void* ws, void* const* ext, int n_ext, void* st
 /* Per-op timing of one run with HIP events on `stream` (synchronises); ms[n_ops] filled. */
 int vse_plan_profile(vse_plan* plan, void* ws, void* const* ext, int n_ext, void* stream, float* ms);
 
+/* Which kernel instantiation op `i` dispatches to: for conv ops the BN of conv_mfma_kernel<BM,BN,..> (128/64/32),
+ * 0 for every other op kind.  Lets the bench attribute measured time to the kernel names rocprofv3 reports. */
+int vse_plan_op_variant(vse_plan* plan, int i);
+
 /* ---- det pre-processing ----------------------------------------------------------------------------- */
 /* uint8 BGR frames [n, src_h, src_w, 3] (row pitch `pitch` bytes, frame stride `frame_stride` bytes) ->
  * bilinear resize to [dst_h, dst_w] with OpenCV's fixed-point INTER_LINEAR arithmetic -> (x/255-mean)/std ->

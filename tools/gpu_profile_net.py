@@ -31,8 +31,8 @@ def main():
     for _ in range(2):
         net.run(x)
     torch.cuda.synchronize()
-    ms, prog = net.profile(x)
-    ms2, _ = net.profile(x)
+    ms, prog, _ = net.profile(x)
+    ms2, _, _ = net.profile(x)
     ms = np.minimum(ms, ms2)
     tot = ms.sum()
     print(f"{mid} N={n} {h}x{w}: {len(ms)} ops, total {tot:.3f} ms, algorithmic {prog.gmacs:.2f} GMAC -> "

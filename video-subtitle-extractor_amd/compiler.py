@@ -93,6 +93,7 @@ class Program:
     outputs: List[dict] = field(default_factory=list)   # [{name, n,h,w,c,ld,esize,kind}]
     names: List[str] = field(default_factory=list)      # debug: op -> originating tensor name
     gmacs: float = 0.0              # algorithmic MACs of conv/linear ops (for the roofline)
+    op_gmacs: List[float] = field(default_factory=list)   # per op, aligned with `ops`
 
 
 class WeightStore:
@@ -255,8 +256,14 @@ class Compiler:
             if v is not None:
                 v.buf.first = min(v.buf.first, idx)
                 v.buf.last = max(v.buf.last, idx)
+        rec["gmac"] = 0.0
         self.ir_ops.append(rec)
         return rec
+
+    def add_gmacs(self, g):
+        """Algorithmic (unpadded) MACs of the op emitted last, in units of 1e9."""
+        self.gmacs += g
+        self.ir_ops[-1]["gmac"] += g
 
     def add_weights(self, key, arr):
         """Append to the weight blob (256-byte aligned); identical keys are shared across plans."""
@@ -503,7 +510,7 @@ class Compiler:
                          ir.P_INSHIFT: 0, ir.P_RESSHIFT: 0, ir.P_CINP: inv.span},
                       f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                          ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
-            self.gmacs += inv.n * inv.h * inv.w * cin * cout * 4 / 1e9
+            self.add_gmacs(inv.n * inv.h * inv.w * cin * cout * 4 / 1e9)
             self.env[ep["out_name"]] = out
             return
         cout, cin, kh, kw = w.shape
@@ -533,7 +540,7 @@ class Compiler:
                      ir.P_INSHIFT: inv.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                      ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
-        self.gmacs += inv.n * oh * ow * cin * cout * kh * kw / 1e9
+        self.add_gmacs(inv.n * oh * ow * cin * cout * kh * kw / 1e9)
         self.env[ep["out_name"]] = out
 
     def lower_dwconv(self, i, inv, w, sh, sw, ph, pw):
@@ -559,7 +566,7 @@ class Compiler:
                      ir.P_ACT: ep["act"]},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                      ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
-        self.gmacs += inv.n * oh * ow * c * kh * kw / 1e9
+        self.add_gmacs(inv.n * oh * ow * c * kh * kw / 1e9)
         self.env[ep["out_name"]] = out
 
     def lower_linear(self, i):
@@ -605,7 +612,7 @@ class Compiler:
                      ir.P_INSHIFT: 0, ir.P_RESSHIFT: 0, ir.P_CINP: x.span},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                      ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
-        self.gmacs += x.n * x.h * x.w * cin * cout / 1e9
+        self.add_gmacs(x.n * x.h * x.w * cin * cout / 1e9)
         self.env[ep["out_name"]] = out
 
     # -------------------------------------------------------------------------------------------- attention
@@ -873,11 +880,11 @@ class Compiler:
                              ir.P_ACT: 0, ir.P_ACT2: 0, ir.P_COUT: coutp, ir.P_KTOT: Kp, ir.P_INSHIFT: 0,
                              ir.P_RESSHIFT: 0, ir.P_CINP: cur.span},
                           f={ir.FS_POST_A: 1.0}, w_off=w_off, b_off=b_off)
-                self.gmacs += cur.n * cur.w * cur.c * 4 * H / 1e9
+                self.add_gmacs(cur.n * cur.w * cur.c * 4 * H / 1e9)
                 whh_off = self.add_weights(("lstm_hh", wl[2 * c + 1]), w_hh.T.copy().astype(np.float16))  # [H][4H]
                 ov = View(outb, d * H, cur.n, 1, cur.w, [(0, H)], H)
                 self.emit(ir.OP_LSTM, key, [gates], ov, p={ir.P_HID: H, ir.P_REVERSE: d}, w_off=whh_off)
-                self.gmacs += cur.n * cur.w * H * 4 * H / 1e9
+                self.add_gmacs(cur.n * cur.w * H * 4 * H / 1e9)
             cur = View(outb, 0, cur.n, 1, cur.w, [(0, ndir * H)], ndir * H, 0, "tbc")
         self.env[name] = cur
 
@@ -982,7 +989,8 @@ class Compiler:
             r["w_off"], r["b_off"], r["aux_off"] = o["w_off"], o["b_off"], o["aux_off"]
             names.append(o["name"])
         return Program(ops=recs, weights=self.store, ws_bytes=int(ws_bytes), in_shape=(self.N, self.H, self.Wd, 8),
-                       outputs=self.outputs, names=names, gmacs=self.gmacs)
+                       outputs=self.outputs, names=names, gmacs=self.gmacs,
+                       op_gmacs=[o["gmac"] for o in self.ir_ops])
 
     def _final_view(self, v: View):
         r = self.vrec(v)

@@ -45,5 +45,6 @@ struct ConvArgs {
     float act_a, act_b, post_a, post_b;
 };
 int launch_conv(const ConvArgs& a, hipStream_t st);
+int conv_tile_bn(int Np);   // which conv_mfma_kernel instantiation (BN = 128 / 64 / 32) serves Np output channels
 int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const TView& in2, const TView& out,
                      const TView& out2, const char* wbase, hipStream_t st);

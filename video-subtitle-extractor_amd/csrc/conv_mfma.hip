@@ -223,6 +223,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 }
 
+int conv_tile_bn(int Np) {
+    // tile selection: minimise padded-N waste, prefer the widest tile on ties
+    auto padded = [&](int bn) { return ((Np + bn - 1) / bn) * bn; };
+    if (Np <= 32) return 32;
+    if (padded(64) < padded(128)) return 64;
+    return 128;
+}
+
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     ConvParams p;
     p.in = reinterpret_cast<const half_t*>(a.in.ptr);
@@ -260,11 +268,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int mul = (a.flags & F_PIXSHUF) ? 2 : 1;
     if (a.out.h != p.OH * mul || a.out.w != p.OW * mul || a.out.n != a.in.n) return VSE_E_INVAL;
 
-    // tile selection: minimise padded-N waste, prefer the widest tile on ties
-    auto waste = [&](int bn) { return ((a.Np + bn - 1) / bn) * bn; };
-    int bn = 128;
-    if (a.Np <= 32) bn = 32;
-    else if (waste(64) < waste(128)) bn = 64;
+    const int bn = conv_tile_bn(a.Np);
     dim3 block(256);
     if (bn == 128) {
         dim3 grid((unsigned)((p.M + 127) / 128), (a.Np + 127) / 128);

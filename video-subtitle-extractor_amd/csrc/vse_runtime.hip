@@ -191,6 +191,12 @@ int vse_plan_run(vse_plan* p, void* ws, void* const* ext, int n_ext, void* strea
     return VSE_OK;
 }
 
+int vse_plan_op_variant(vse_plan* p, int i) {
+    if (!p || i < 0 || i >= (int)p->ops.size()) return VSE_E_INVAL;
+    const vse_op& o = p->ops[i];
+    return o.kind == OP_CONV ? conv_tile_bn(o.p[P_COUT]) : 0;
+}
+
 int vse_plan_profile(vse_plan* p, void* ws, void* const* ext, int n_ext, void* stream, float* ms) {
     if (!p || !ext || !ms || n_ext <= p->max_ext) return VSE_E_INVAL;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

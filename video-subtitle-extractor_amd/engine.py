@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libvse_hip.so")
 EXPORTS = [
     "vse_init", "vse_destroy", "vse_last_error", "vse_sizeof_op", "vse_sizeof_view", "vse_abi_version",
     "vse_weights_upload", "vse_weights_free", "vse_plan_create", "vse_plan_destroy", "vse_plan_run",
-    "vse_plan_profile", "vse_det_preprocess", "vse_db_workspace_bytes", "vse_db_postprocess",
+    "vse_plan_profile", "vse_plan_op_variant", "vse_det_preprocess", "vse_db_workspace_bytes", "vse_db_postprocess",
     "vse_rec_preprocess", "vse_rec_preprocess_scratch_bytes", "vse_ctc_collapse",
 ]
 
@@ -74,6 +74,7 @@ def load_library(path=None):
     lib.vse_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
     lib.vse_plan_profile.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
                                      C.POINTER(C.c_float)]
+    lib.vse_plan_op_variant.argtypes = [C.c_void_p, C.c_int]
     lib.vse_det_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                        C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        C.c_void_p]
@@ -281,4 +282,5 @@ class Net:
         ms = (C.c_float * len(prog.ops))()
         _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(self.ws.data_ptr()), ptrs, len(ptrs),
                                              self.ctx.stream(), ms), "vse_plan_profile")
-        return np.array(ms[:], dtype=np.float32), prog
+        variants = [self.ctx.lib.vse_plan_op_variant(handle, i) for i in range(len(prog.ops))]
+        return np.array(ms[:], dtype=np.float32), prog, variants

@@ -50,7 +50,7 @@ def crop_geometry(q):
 class OcrPipeline:
     def __init__(self, ctx, det_model, rec_model, charset, rec_batch_num=6, rec_h=48, rec_base_w=320,
                  limit_side_len=960, db_thresh=0.3, db_box_thresh=0.6, db_unclip_ratio=1.5, drop_score=0.0,
-                 rec_mode="reference", bucket=64):
+                 rec_mode="reference", bucket=64, batch_round=1, max_rec_batch=64):
         """det_model / rec_model: (descriptor, weights dict)."""
         self.ctx = ctx
         self.det = engine.Net(ctx, det_model[0], det_model[1], fetch_cols=(0,))
@@ -64,6 +64,8 @@ class OcrPipeline:
         self.drop_score = drop_score
         self.rec_mode = rec_mode
         self.bucket = bucket
+        self.batch_round = batch_round        # bucketed mode: pad group sizes to a multiple (bounds the plan cache)
+        self.max_rec_batch = max_rec_batch
 
     # ---- detection ---------------------------------------------------------------------------------------
     def det_maps(self, frames):
@@ -116,7 +118,9 @@ class OcrPipeline:
                 wb = (wneed(s) + self.bucket - 1) // self.bucket * self.bucket
                 buckets.setdefault(wb, []).append(i)
             for wb in sorted(buckets):
-                groups.append((buckets[wb], wb))
+                idx = buckets[wb]
+                for b in range(0, len(idx), self.max_rec_batch):
+                    groups.append((idx[b:b + self.max_rec_batch], wb))
         return groups
 
     def recognize(self, frames, boxes_per_frame):
@@ -135,6 +139,9 @@ class OcrPipeline:
                 rw = min(img_w, int(math.ceil(self.rec_h * s["ratio"])))
                 crops.append(dict(quad=s["quad"], frame=s["frame"], crop_w=s["crop_w"], crop_h=s["crop_h"],
                                   resized_w=max(rw, 1), rotate=s["rotate"]))
+            if self.rec_mode != "reference" and self.batch_round > 1:
+                while len(crops) % self.batch_round:
+                    crops.append(crops[-1])           # dummy rows; their results are never read
             x = self.ctx.rec_preprocess(frames, crops, self.rec_h, img_w)
             idx_maxp = self.rec.run(x)[-1]                 # [B,1,T,2]
             oi, ol, oc = self.ctx.ctc_collapse(idx_maxp)
