@@ -106,6 +106,8 @@ class WeightStore:
     def add(self, key, arr):
         if key in self.index:
             return self.index[key]
+        if callable(arr):
+            arr = arr()
         off = rup(len(self.blob), 256)
         self.blob.extend(b"\0" * (off - len(self.blob)))
         self.blob.extend(np.ascontiguousarray(arr).tobytes())
@@ -518,7 +520,7 @@ class Compiler:
         oh = (inv.h + 2 * ph - kh) // sh + 1
         ow = (inv.w + 2 * pw - kw) // sw + 1
         ep = self.absorb_epilogue(outname, i, cout, out_dims=(inv.n, oh, ow))
-        mat, coutp, Kp = self.pack_conv_weights(w, ep["scale"], inv)
+        coutp, Kp = rup(cout, 8), rup(kh * kw * inv.span, 32)
         bias = np.zeros(coutp, np.float32)
         bias[:cout] = ep["shift"]
         out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
@@ -532,7 +534,8 @@ class Compiler:
             flags |= ir.F_RES
             ins.append(res)
             resshift = res.up
-        w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]), self.tile_weights(mat))
+        w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]),
+                                 lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0]))
         b_off = self.add_weights(("convb", wname, ep["out_name"]), bias)
         self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
@@ -583,7 +586,7 @@ class Compiler:
         # attention qkv projection?  (linear -> reshape [0,-1,3,heads,hd])
         ep = self.absorb_epilogue(outname, i, cout, out_dims=(x.n, x.h, x.w))
         w4 = w.T.reshape(cout, cin, 1, 1)
-        mat, coutp, Kp = self.pack_conv_weights(w4, ep["scale"], x)
+        coutp, Kp = rup(cout, 8), rup(x.span, 32)
         bias = np.zeros(coutp, np.float32)
         bias[:cout] = ep["shift"]
         # logits that feed the final class softmax stay fp32 (fp16 ulp at |logit|~10 is 8e-3: too coarse for the
@@ -604,7 +607,8 @@ class Compiler:
             assert (r.n, r.h, r.w, r.c) == (x.n, x.h, x.w, cout) and r.up == 0
             ins.append(r)
             flags |= ir.F_RES
-        w_off = self.add_weights(("lin", wname, tuple(x.segs), ep["out_name"]), self.tile_weights(mat))
+        w_off = self.add_weights(("lin", wname, tuple(x.segs), ep["out_name"]),
+                                 lambda: self.tile_weights(self.pack_conv_weights(w4, ep["scale"], x)[0]))
         b_off = self.add_weights(("linb", wname, ep["out_name"]), bias)
         self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
                   p={ir.P_KH: 1, ir.P_KW: 1, ir.P_SH: 1, ir.P_SW: 1, ir.P_PH: 0, ir.P_PW: 0,
