@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--models", default="server", choices=["server", "fast", "fast-real"])
     ap.add_argument("--boxes", default="gt", choices=["gt", "db"])
+    ap.add_argument("--bucket", type=int, default=256, help="rec width bucket (px)")
+    ap.add_argument("--batch-round", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -132,7 +134,8 @@ def main():
     if not modelzoo.has_real_weights(det_id):
         det = (det[0], empty_det_head(det[0], det[1]))
     charset = shim.charset_for(lang, shim._ncls(rec[0]))
-    pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="bucketed", bucket=64, batch_round=8)
+    pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="bucketed", bucket=args.bucket,
+                                batch_round=args.batch_round)
 
     frames_np, truth = synth.make_frames(args.batch, args.height, args.width, seed=100 + rank, return_truth=True)
     frames = torch.from_numpy(frames_np).to(ctx.tdev)          # inputs resident in HBM before the timed region
@@ -178,13 +181,13 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.batch}x{args.height}p frames/GPU/step, precise mode: {det_id} @544x960 + "
-                                   f"{rec_id}, {n_lines} text lines/batch, rec boxes={args.boxes}, rec batching=bucketed(64px)",
+                                   f"{rec_id}, {n_lines} text lines/batch, rec boxes={args.boxes}, rec batching=bucketed({args.bucket}px)",
                        "frames_per_gpu_step": args.batch, "det_model": det_id, "rec_model": rec_id,
                        "weights": "real" if modelzoo.has_real_weights(det_id) else "seeded random (reference blobs missing)",
                        "records_gathered": len(out) if out is not None else 0},
         }
         if not args.no_roofline:
-            result["roofline"] = roofline(pipe, frames, args)
+            result["roofline"] = roofline(pipe, step)
             log("roofline pass done")
         if not args.no_cpu_baseline and world == 1:
             from oracle import pipeline_ref as P
@@ -197,36 +200,45 @@ def main():
     return result
 
 
-def roofline(pipe, frames, args):
-    """Dominant kernel = the conv_mfma_kernel instantiation with the largest total time in the detector step.
-    achieved = algorithmic conv FLOPs routed to it / its summed launch durations (HIP events on the launch stream)."""
-    import torch
-    from vse_amd import ir, pipeline as pl
-    n, h, w, _ = frames.shape
-    rh, rw = pl.det_resize_shape(h, w, pipe.limit)
-    x = pipe.ctx.det_preprocess(frames, rh, rw)
-    best = None
-    for _ in range(3):
-        ms, prog, variants = pipe.det.profile(x)
-        best = ms if best is None else np.minimum(best, ms)
+def roofline(pipe, step, repeats=2):
+    """Dominant kernel = the conv_mfma_kernel instantiation with the largest total time over one whole step
+    (detector + every recogniser launch).  Every op of every plan is bracketed by HIP events recorded on the stream
+    the kernels are launched on (vse_plan_profile); achieved = algorithmic conv FLOPs routed to that kernel / its
+    summed launch durations; avg_launch_us is directly comparable with rocprofv3 --stats' AverageNs for it."""
+    from vse_amd import ir
     agg = {}
-    for k, r in enumerate(prog.ops):
-        if int(r["kind"]) != ir.OP_CONV:
-            continue
-        a = agg.setdefault(variants[k], [0.0, 0.0, 0])
-        a[0] += best[k]
-        a[1] += prog.op_gmacs[k]
-        a[2] += 1
+    for _ in range(repeats):
+        pipe.profile_sink = []
+        step()
+        for ms, prog, variants in pipe.profile_sink:
+            for k, r in enumerate(prog.ops):
+                if int(r["kind"]) != ir.OP_CONV:
+                    continue
+                a = agg.setdefault(variants[k], [0.0, 0.0, 0])
+                a[0] += float(ms[k])
+                a[1] += float(prog.op_gmacs[k])
+                a[2] += 1
+        pipe.profile_sink = None
     bn, (tms, gmac, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
-    tile = {128: "128,128,2,2", 64: "128,64,2,2", 32: "256,32,4,1"}[bn]
+    tile = {128: "128, 128, 2, 2", 64: "128, 64, 2, 2", 32: "256, 32, 4, 1"}[bn]
     achieved = 2.0 * gmac / tms          # GMAC/ms*2 = TFLOP/s
-    achieved, tms, gmac = float(achieved), float(tms), float(gmac)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    kname = f"conv_mfma_kernel<{tile}>"
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        if kname in tj.get("kernels", {}):
+            traffic = tj["kernels"][kname]["hbm_bytes_per_launch"]
+    all_ms = sum(v[0] for v in agg.values())
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": f"conv_mfma_kernel<{tile}>", "launches_per_step": cnt,
-            "avg_launch_us": round(1e3 * tms / cnt, 2), "algorithmic_gflop_per_step": round(2 * gmac, 1),
-            "all_conv_tflops": round(float(2.0 * sum(v[1] for v in agg.values()) / sum(v[0] for v in agg.values())), 2),
-            "det_step_ms": round(float(best.sum()), 3)}
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
+            "kernel": kname, "launches_per_step": cnt // repeats,
+            "avg_launch_us": round(1e3 * tms / cnt, 2),
+            "algorithmic_gflop_per_launch": round(2 * gmac / cnt, 2),
+            "share_of_conv_time": round(tms / all_ms, 3),
+            "all_conv_tflops": round(2.0 * sum(v[1] for v in agg.values()) / all_ms, 2),
+            "conv_ms_per_step": round(all_ms / repeats, 3)}
 
 
 if __name__ == "__main__":

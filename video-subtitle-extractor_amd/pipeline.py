@@ -66,6 +66,12 @@ class OcrPipeline:
         self.bucket = bucket
         self.batch_round = batch_round        # bucketed mode: pad group sizes to a multiple (bounds the plan cache)
         self.max_rec_batch = max_rec_batch
+        self.profile_sink = None              # list: when set, every net run is profiled per op and appended here
+
+    def _run(self, net, x):
+        if self.profile_sink is not None:
+            self.profile_sink.append(net.profile(x))
+        return net.run(x)
 
     # ---- detection ---------------------------------------------------------------------------------------
     def det_maps(self, frames):
@@ -73,7 +79,7 @@ class OcrPipeline:
         n, h, w, _ = frames.shape
         rh, rw = det_resize_shape(h, w, self.limit)
         x = self.ctx.det_preprocess(frames, rh, rw)
-        out = self.det.run(x)[0]            # [N,rh,rw,1] fp32
+        out = self._run(self.det, x)[0]     # [N,rh,rw,1] fp32
         return out.view(n, rh, rw)
 
     def detect(self, frames):
@@ -143,7 +149,7 @@ class OcrPipeline:
                 while len(crops) % self.batch_round:
                     crops.append(crops[-1])           # dummy rows; their results are never read
             x = self.ctx.rec_preprocess(frames, crops, self.rec_h, img_w)
-            idx_maxp = self.rec.run(x)[-1]                 # [B,1,T,2]
+            idx_maxp = self._run(self.rec, x)[-1]          # [B,1,T,2]
             oi, ol, oc = self.ctx.ctc_collapse(idx_maxp)
             pending.append((idx, oi, ol, oc))
         for idx, oi, ol, oc in pending:                      # one sync per group at the end
