@@ -220,7 +220,7 @@ def roofline(pipe, step, repeats=2):
                 a[2] += 1
         pipe.profile_sink = None
     bn, (tms, gmac, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
-    tile = {128: "128, 128, 2, 2", 64: "128, 64, 2, 2", 32: "256, 32, 4, 1"}[bn]
+    tile = {128: "128, 128, 2, 2", 64: "256, 64, 4, 1", 32: "256, 32, 4, 1"}[bn]
     achieved = 2.0 * gmac / tms          # GMAC/ms*2 = TFLOP/s
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")

@@ -120,8 +120,9 @@ class Emulator:
         Np, Kp, cinp = int(p[ir.P_COUT]), int(p[ir.P_KTOT]), int(p[ir.P_CINP])
         x = self._up(self.read(r["in0"]), int(p[ir.P_INSHIFT]))
         assert x.shape[3] == cinp
-        wt = self.wread(int(r["w_off"]), (Kp // 32) * Np * 32, np.float16).astype(np.float32)
-        wmat = wt.reshape(Kp // 32, Np, 32).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]
+        KT = ir.KT
+        wt = self.wread(int(r["w_off"]), (Kp // KT) * Np * KT, np.float16).astype(np.float32)
+        wmat = wt.reshape(Kp // KT, Np, KT).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]
         w4 = torch.from_numpy(np.ascontiguousarray(wmat.reshape(Np, kh, kw, cinp).transpose(0, 3, 1, 2)))
         bias = torch.from_numpy(self.wread(int(r["b_off"]), Np, np.float32).copy())
         y = F.conv2d(x.permute(0, 3, 1, 2), w4, bias, (sh, sw), (ph, pw)).permute(0, 2, 3, 1)

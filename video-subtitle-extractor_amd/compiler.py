@@ -5,7 +5,7 @@ Host-side only (numpy).  The output `Program` is what the C-ABI runtime executes
 not a translation of the Paddle executor):
 
   * activations are NHWC fp16 with channels padded to a multiple of 8, so every implicit-GEMM gather is
-    a 16-byte vector per (tap, 8-channel group); weights are pre-tiled [K/32][Cout][32] fp16 in exactly
+    a 16-byte vector per (tap, 8-channel group); weights are pre-tiled [K/64][Cout][64] fp16 in exactly
     the order the conv kernel streams them through LDS;
   * batch-norm, conv bias and the PP-LCNetV3 "learnable affine" scalars before the activation are folded
     into the weights/bias in fp32 at compile time; activation, post-activation affine, residual add
@@ -445,7 +445,7 @@ class Compiler:
 
     # -------------------------------------------------------------------------------------------- conv lowering
     def pack_conv_weights(self, w, scale, inv: View, pixshuf=False):
-        """w: [Cout,Cin,kh,kw] fp32 (already transposed for convT).  Returns (blob fp16 [K/32][Np][32], Np, Kp)."""
+        """w: [Cout,Cin,kh,kw] fp32 (already transposed for convT).  Returns (matrix [Np][Kp], Np, Kp)."""
         cout, cin, kh, kw = w.shape
         w = w.astype(np.float64) * scale.reshape(-1, 1, 1, 1)
         cinp = inv.span
@@ -453,16 +453,16 @@ class Compiler:
         full = np.zeros((coutp, kh, kw, cinp), np.float64)
         full[:cout][:, :, :, inv.chmap()] = np.transpose(w, (0, 2, 3, 1))
         K = kh * kw * cinp
-        Kp = rup(K, 32)
+        Kp = rup(K, ir.KT)
         mat = np.zeros((coutp, Kp), np.float64)
         mat[:, :K] = full.reshape(coutp, K)
         return mat, coutp, Kp
 
     @staticmethod
     def tile_weights(mat):
-        """[Np][Kp] -> [Kp/32][Np][32] fp16."""
+        """[Np][Kp] -> [Kp/KT][Np][KT] fp16."""
         npad, kp = mat.shape
-        t = mat.reshape(npad, kp // 32, 32).transpose(1, 0, 2)
+        t = mat.reshape(npad, kp // ir.KT, ir.KT).transpose(1, 0, 2)
         return np.ascontiguousarray(t).astype(np.float16)
 
     def lower_conv(self, i):
@@ -496,7 +496,7 @@ class Compiler:
                     blk = np.zeros((coutp, inv.span))
                     blk[:cout][:, cm] = wt[:, :, dy, dx].T
                     w2[(dy * 2 + dx) * coutp:(dy * 2 + dx + 1) * coutp] = blk
-            Kp = rup(inv.span, 32)
+            Kp = rup(inv.span, ir.KT)
             mat = np.zeros((4 * coutp, Kp))
             mat[:, :inv.span] = w2
             bias = np.zeros(4 * coutp, np.float32)
@@ -520,7 +520,7 @@ class Compiler:
         oh = (inv.h + 2 * ph - kh) // sh + 1
         ow = (inv.w + 2 * pw - kw) // sw + 1
         ep = self.absorb_epilogue(outname, i, cout, out_dims=(inv.n, oh, ow))
-        coutp, Kp = rup(cout, 8), rup(kh * kw * inv.span, 32)
+        coutp, Kp = rup(cout, 8), rup(kh * kw * inv.span, ir.KT)
         bias = np.zeros(coutp, np.float32)
         bias[:cout] = ep["shift"]
         out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
@@ -586,7 +586,7 @@ class Compiler:
         # attention qkv projection?  (linear -> reshape [0,-1,3,heads,hd])
         ep = self.absorb_epilogue(outname, i, cout, out_dims=(x.n, x.h, x.w))
         w4 = w.T.reshape(cout, cin, 1, 1)
-        coutp, Kp = rup(cout, 8), rup(x.span, 32)
+        coutp, Kp = rup(cout, 8), rup(x.span, ir.KT)
         bias = np.zeros(coutp, np.float32)
         bias[:cout] = ep["shift"]
         # logits that feed the final class softmax stay fp32 (fp16 ulp at |logit|~10 is 8e-3: too coarse for the

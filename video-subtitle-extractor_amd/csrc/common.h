@@ -39,8 +39,9 @@ struct TView {
 // Kernel launchers implemented in the .hip files; all enqueue on `st`.
 struct ConvArgs {
     TView in, res, out;
-    const half_t* w;      // tiled [K/32][Np][32]
+    const half_t* w;      // tiled [K/64][Np][64]
     const float* bias;    // [Np]
+    const half_t* zero;   // >= 64 bytes of device zeros
     int kh, kw, sh, sw, ph, pw, act, act2, Np, Kp, inshift, resshift, cinp, flags;
     float act_a, act_b, post_a, post_b;
 };

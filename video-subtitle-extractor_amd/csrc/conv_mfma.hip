@@ -5,12 +5,13 @@
 //     lane ends up holding 4 *consecutive output channels* of one pixel per accumulator quad -> 8-byte
 //     NHWC stores, per-channel bias as a float4, residual loads of the same shape.
 //   * v_mfma_f32_32x32x16_f16: lane l supplies row/col (l&31) and k-slice 8*(l>>5)..+7 of both operands.
-//   * block = 256 threads = 4 waves arranged WM x WN over a BM(pixels) x BN(couts) tile, BK = 32 per step,
-//     register-staged double-buffered LDS with 80-byte rows (16-byte pad => conflict-free ds_read_b128).
+//   * block = 256 threads = 4 waves arranged WM x WN over a BM(pixels) x BN(couts) tile, BK = 64 per step
+//     (16 MFMAs per wave between barriers), one LDS stage with 144-byte rows (conflict-free b128 reads and
+//     writes); the next K tile is prefetched into registers under the MFMAs and written after the barrier.
 //   * activations are gathered as one 16-byte vector per (pixel, tap, 8-channel group): cin is padded to a
 //     multiple of 8 by the compiler, so a vector never straddles taps; image borders, K padding and the
 //     M tail are predicated to zero.  A nearest-upsampled input (FPN) is gathered with (y>>s, x>>s).
-//   * weights arrive pre-tiled [K/32][Np][32] so a BN x 32 tile is one contiguous, fully coalesced chunk.
+//   * weights arrive pre-tiled [K/64][Np][64] so a BN x 64 tile is one contiguous, fully coalesced chunk.
 //   * epilogue: + bias (BN folded) -> activation -> scalar affine -> (+ residual, optionally upsampled)
 //     -> activation2 -> fp16 (or fp32) store; 2x2/stride-2 transposed conv = same GEMM with a
 //     pixel-shuffle store.
@@ -21,6 +22,7 @@ struct ConvParams {
     const half_t* w;
     const float* bias;
     const half_t* res;
+    const half_t* zero;      // 4 KiB of zeros: gather target for padding / out-of-range lanes
     void* out;
     int H, W, Hs, Ws, in_ld, cinp, inshift;
     int OH, OW;
@@ -35,22 +37,37 @@ struct ConvParams {
     unsigned ntn;       // number of cout tiles
 };
 
-#define LDS_ROW 40   // halfs per LDS row (32 data + 8 pad)
+#define BK 32          // K elements per pipeline stage
+#define STAGES 3       // LDS ring: tile k is consumed while tiles k+1 and k+2 are in flight
+#define ROWB 64        // bytes per LDS row (BK halfs, no padding: LDS-DMA writes are lane-linear)
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One 16-byte LDS-DMA per lane: global -> LDS without touching VGPRs.  The LDS destination of a wave instruction
+// is wave-uniform base + lane*16 (1 KiB = 16 rows of 64 B), so the bank-conflict swizzle is applied on the SOURCE
+// side: physical 16-byte slot s of row r holds logical k-vector  s ^ ((r >> 2) & 3)  (both sides use the same
+// involution; ds_read_b128 of 16 consecutive rows at one logical k-vector then touches 16 distinct bank groups).
+__device__ __forceinline__ void glds16(const void* g, half_t* l) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int NA = BM / 64;                 // 16-byte activation vectors per thread per K step
-    constexpr int NB = (BN * 4 + 255) / 256;    // 16-byte weight vectors per thread per K step
+    constexpr int BNR = BN < 64 ? 64 : BN;      // weight rows staged per tile (>= one wave instruction per wave)
+    constexpr int NA = BM / 64;                 // LDS-DMA instructions per wave per stage, activations
+    constexpr int NB = BNR / 64;                // ... weights
+    constexpr int LPT = NA + NB;                // VMEM ops per thread per stage (vmcnt bookkeeping)
+    constexpr int STAGE_HALFS = (BM + BNR) * BK;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile shape");
 
-    __shared__ __attribute__((aligned(16))) half_t As[2][BM][LDS_ROW];
-    __shared__ __attribute__((aligned(16))) half_t Bs[2][BN][LDS_ROW];
+    __shared__ __attribute__((aligned(16))) half_t lds[STAGES * STAGE_HALFS];   // the ONLY LDS object
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (each XCD has a private 4 MiB L2).  Give every
     // XCD one CONTIGUOUS range of logical tiles (bijective for any tile count) and walk the N tiles of one pixel
@@ -64,13 +81,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const long m0 = (long)mtile * BM;
     const int n0 = ntile * BN;
 
-    // ---- per-thread gather state -------------------------------------------------------------------
-    const int kv = tid & 3;
+    // ---- per-thread gather state ---------------------------------------------------------------------------
+    // wave instruction j of this wave covers tile rows (j*4 + wave)*16 .. +15; lane l -> row +(l>>2), physical slot
+    // l&3, i.e. logical k-vector kv = (l&3) ^ ((l>>4)&3)  (row>>2 & 3 == l>>4 & 3 because the 16-row base is 16-aligned)
+    const int kv = (lane & 3) ^ ((lane >> 4) & 3);
+    const int rsub = lane >> 2;
     int ih0[NA], iw0[NA];
     long pbase[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const long m = m0 + (tid >> 2) + 64 * j;
+        const long m = m0 + (j * 4 + wave) * 16 + rsub;
         if (m < p.M) {
             const int ow = (int)(m % p.OW);
             const long t = m / p.OW;
@@ -90,48 +110,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         kc -= p.cinp;
         if (++dx == p.kw) { dx = 0; ++dy; }
     }
+    const half_t* wrow[NB];
+    bool wok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + (j * 4 + wave) * 16 + rsub;
+        wok[j] = ((j * 4 + wave) * 16 + rsub < BN) && (n < p.Np);
+        wrow[j] = p.w + (long)n * 64 + kv * 8;        // weights are tiled [Kp/64][Np][64]
+    }
 
-    half8 ra[NA], rb[NB];
-    const half8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    auto load_tiles = [&](int kt) {
+    // issue the LDS-DMAs of K tile `kt` into ring slot `st` (always exactly LPT VMEM ops per thread)
+    auto issue = [&](int kt, int st) {
+        half_t* base = lds + st * STAGE_HALFS;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int ih = ih0[j] + dy, iw = iw0[j] + dx;
             const bool ok = (dy < p.kh) && (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.W);
-            if (ok) {
-                const long pix = pbase[j] + (long)(ih >> p.inshift) * p.Ws + (iw >> p.inshift);
-                ra[j] = *reinterpret_cast<const half8*>(p.in + pix * p.in_ld + kc);
-            } else {
-                ra[j] = zero8;
-            }
+            const half_t* src = p.zero;
+            if (ok) src = p.in + (pbase[j] + (long)(ih >> p.inshift) * p.Ws + (iw >> p.inshift)) * p.in_ld + kc;
+            glds16(src, base + (j * 4 + wave) * 16 * BK);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int v = tid + 256 * j;
-            const int row = v >> 2;
-            const int n = n0 + row;
-            if (row < BN && n < p.Np) {
-                rb[j] = *reinterpret_cast<const half8*>(p.w + ((long)kt * p.Np + n) * 32 + (v & 3) * 8);
-            } else {
-                rb[j] = zero8;
-            }
+            const half_t* src = wok[j] ? wrow[j] + (long)(kt >> 1) * p.Np * 64 + (kt & 1) * 32 : p.zero;
+            glds16(src, base + BM * BK + (j * 4 + wave) * 16 * BK);
         }
-        // advance the (tap, channel) cursor by one K step
-        kc += 32;
+        kc += BK;
         while (kc >= p.cinp) {
             kc -= p.cinp;
             if (++dx == p.kw) { dx = 0; ++dy; }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NA; ++j)
-            *reinterpret_cast<half8*>(&As[buf][(tid >> 2) + 64 * j][kv * 8]) = ra[j];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int v = tid + 256 * j;
-            if ((v >> 2) < BN) *reinterpret_cast<half8*>(&Bs[buf][v >> 2][(v & 3) * 8]) = rb[j];
         }
     };
 
@@ -143,34 +150,62 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
+    issue(0, 0);
+    if (p.nk > 1) issue(1, 1);
 
     const int frow = lane & 31;
-    const int fk = (lane >> 5) * 8;
-    int cur = 0;
+    const int fj = lane >> 5;                      // logical k-vector within a 16-wide k sub-step
+    // fragment byte offsets inside a stage (row*64 + swizzled slot*16), fixed per thread
+    int xoff[TM][2], woff[TN][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r = wm * WTM + i * 32 + frow;
+            xoff[i][ks] = r * BK + (((ks * 2 + fj) ^ ((r >> 2) & 3)) << 3);
+        }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r = wn * WTN + j * 32 + frow;
+            woff[j][ks] = BM * BK + r * BK + (((ks * 2 + fj) ^ ((r >> 2) & 3)) << 3);
+        }
+
+    int st = 0;
     for (int kt = 0; kt < p.nk; ++kt) {
-        const bool more = (kt + 1 < p.nk);
-        if (more) load_tiles(kt + 1);
+        // tile kt has landed once at most the LPT ops of tile kt+1 are still outstanding (vmcnt counts in order)
+        if (kt + 1 < p.nk) {
+            if constexpr (LPT == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (LPT == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if constexpr (LPT == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (LPT == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();              // every thread's part of tile kt is in LDS; compute(kt-1) is over
+        asm volatile("" ::: "memory");
+        if (kt + 2 < p.nk) {
+            int s2 = st + 2;
+            if (s2 >= STAGES) s2 -= STAGES;
+            issue(kt + 2, s2);                     // refill the slot compute(kt-1) just released
+        }
+        const half_t* base = lds + st * STAGE_HALFS;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 wf[TN], xf[TM];
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                wf[j] = *reinterpret_cast<const half8*>(&Bs[cur][wn * WTN + j * 32 + frow][ks * 16 + fk]);
+            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(base + woff[j][ks]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                xf[i] = *reinterpret_cast<const half8*>(&As[cur][wm * WTM + i * 32 + frow][ks * 16 + fk]);
+            for (int i = 0; i < TM; ++i) xf[i] = *reinterpret_cast<const half8*>(base + xoff[i][ks]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
         }
-        if (more) store_tiles(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (++st == STAGES) st = 0;
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------
@@ -260,7 +295,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.OW = (p.W + 2 * a.pw - a.kw) / a.sw + 1;
     p.M = (long)a.in.n * p.OH * p.OW;
     p.Np = a.Np;
-    p.nk = a.Kp / 32;
+    p.nk = a.Kp / BK;
+    p.zero = a.zero;
     p.out_ld = a.out.ld;
     p.out_f32 = (a.flags & F_OUT_F32) ? 1 : 0;
     p.res_ld = a.res.ld;
@@ -273,20 +309,21 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.coutp = (a.flags & F_PIXSHUF) ? a.Np / 4 : a.Np;
     if (a.in.esize != 2 || (a.in.ld & 7) || (a.cinp & 7) || a.in.c != a.cinp) return VSE_E_INVAL;
     if ((a.flags & F_RES) && (a.res.esize != 2 || (a.res.ld & 3))) return VSE_E_INVAL;
-    if ((a.out.ld & 3) || (a.Np & 7)) return VSE_E_INVAL;
+    if ((a.out.ld & 3) || (a.Np & 7) || (a.Kp % BK)) return VSE_E_INVAL;
     // sanity on the output view: [n, OH(*2), OW(*2)]
     const int mul = (a.flags & F_PIXSHUF) ? 2 : 1;
     if (a.out.h != p.OH * mul || a.out.w != p.OW * mul || a.out.n != a.in.n) return VSE_E_INVAL;
 
     const int bn = conv_tile_bn(a.Np);
     dim3 block(256);
-    const int bm = bn == 32 ? 256 : 128;
+    const int bm = bn == 128 ? 128 : 256;
+    if (!a.zero) return VSE_E_INVAL;
     p.ntn = (unsigned)((a.Np + bn - 1) / bn);
     const unsigned long long tiles = (unsigned long long)((p.M + bm - 1) / bm) * p.ntn;
     if (tiles == 0 || tiles > 0x7fffffffull) return VSE_E_INVAL;
     dim3 grid((unsigned)tiles);
     if (bn == 128) hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
-    else if (bn == 64) hipLaunchKernelGGL((conv_mfma_kernel<128, 64, 2, 2>), grid, block, 0, st, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv_mfma_kernel<256, 64, 4, 1>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv_mfma_kernel<256, 32, 4, 1>), grid, block, 0, st, p);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }

@@ -165,6 +165,7 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, hipStream_t st
         a.in = in0; a.res = in1; a.out = out;
         a.w = reinterpret_cast<const half_t*>(wts + o.w_off);
         a.bias = reinterpret_cast<const float*>(wts + o.b_off);
+        a.zero = reinterpret_cast<const half_t*>(p->ctx->zero_page);
         a.kh = o.p[P_KH]; a.kw = o.p[P_KW]; a.sh = o.p[P_SH]; a.sw = o.p[P_SW]; a.ph = o.p[P_PH]; a.pw = o.p[P_PW];
         a.act = o.p[P_ACT]; a.act2 = o.p[P_ACT2]; a.Np = o.p[P_COUT]; a.Kp = o.p[P_KTOT];
         a.inshift = o.p[P_INSHIFT]; a.resshift = o.p[P_RESSHIFT]; a.cinp = o.p[P_CINP]; a.flags = o.flags;

@@ -5,6 +5,8 @@ include/vse_hip.h (checked by tests/test_abi.py through vse_sizeof_op()).
 """
 import numpy as np
 
+KT = 64           # K tile of the packed conv weights: [Kp/KT][Np][KT] fp16, Kp a multiple of KT
+
 # op kinds ---------------------------------------------------------------------------------------
 OP_CONV = 1       # implicit-GEMM MFMA conv (also linear / 2x2 s2 transposed conv via pixel-shuffle store)
 OP_DWCONV = 2     # depthwise kxk conv
@@ -49,7 +51,7 @@ OP_DT = np.dtype([
 P_KH, P_KW, P_SH, P_SW, P_PH, P_PW = 0, 1, 2, 3, 4, 5
 P_ACT, P_ACT2 = 6, 7
 P_COUT = 8          # GEMM N (physical out channels incl. padding; x4 for pixel-shuffle)
-P_KTOT = 9          # padded K (multiple of 32)
+P_KTOT = 9          # padded K (multiple of KT)
 P_INSHIFT = 10      # nearest-upsample shift applied when gathering the input
 P_RESSHIFT = 11     # nearest-upsample shift applied when reading the residual
 P_CINP = 12         # physical input channels (multiple of 8)
