@@ -220,11 +220,11 @@ def roofline(pipe, step, repeats=2):
                 a[2] += 1
         pipe.profile_sink = None
     bn, (tms, gmac, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
-    tile = {128: "128, 128, 2, 2", 64: "256, 64, 4, 1", 32: "256, 32, 4, 1"}[bn]
+    kname = {128: "conv_mfma_kernel<128, 128, 2, 2>", 64: "conv_mfma_kernel<256, 64, 4, 1>",
+             32: "conv_mfma_kernel<256, 32, 4, 1>", 1064: "conv_patch_kernel<64>", 1128: "conv_patch_kernel<128>"}[bn]
     achieved = 2.0 * gmac / tms          # GMAC/ms*2 = TFLOP/s
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    kname = f"conv_mfma_kernel<{tile}>"
     if os.path.exists(tpath):
         tj = json.load(open(tpath))
         if kname in tj.get("kernels", {}):

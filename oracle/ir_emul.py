@@ -121,8 +121,13 @@ class Emulator:
         x = self._up(self.read(r["in0"]), int(p[ir.P_INSHIFT]))
         assert x.shape[3] == cinp
         KT = ir.KT
-        wt = self.wread(int(r["w_off"]), (Kp // KT) * Np * KT, np.float16).astype(np.float32)
-        wmat = wt.reshape(Kp // KT, Np, KT).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]
+        if int(r["flags"]) & ir.F_PATCH:
+            taps = kh * kw
+            wt = self.wread(int(r["w_off"]), taps * cinp * Np, np.float16).astype(np.float32)
+            wmat = wt.reshape(cinp // 32, taps, Np, 32).transpose(2, 1, 0, 3).reshape(Np, taps * cinp)
+        else:
+            wt = self.wread(int(r["w_off"]), (Kp // KT) * Np * KT, np.float16).astype(np.float32)
+            wmat = wt.reshape(Kp // KT, Np, KT).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]
         w4 = torch.from_numpy(np.ascontiguousarray(wmat.reshape(Np, kh, kw, cinp).transpose(0, 3, 1, 2)))
         bias = torch.from_numpy(self.wread(int(r["b_off"]), Np, np.float32).copy())
         y = F.conv2d(x.permute(0, 3, 1, 2), w4, bias, (sh, sw), (ph, pw)).permute(0, 2, 3, 1)

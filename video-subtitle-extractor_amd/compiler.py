@@ -139,6 +139,7 @@ class Compiler:
         self.ir_ops: List[dict] = []
         self.store = store if store is not None else WeightStore()
         self.reuse = reuse
+        self.use_patch = True
         self.done = set()
         self.outputs = []
         self.gmacs = 0.0
@@ -465,6 +466,13 @@ class Compiler:
         t = mat.reshape(npad, kp // ir.KT, ir.KT).transpose(1, 0, 2)
         return np.ascontiguousarray(t).astype(np.float16)
 
+    @staticmethod
+    def patch_weights(mat, taps, cinp):
+        """[Np][Kp] (K order tap-major, channel-minor) -> [cinp/32][taps][Np][32] fp16 for conv_patch_kernel."""
+        npad = mat.shape[0]
+        m = mat[:, :taps * cinp].reshape(npad, taps, cinp // 32, 32).transpose(2, 1, 0, 3)
+        return np.ascontiguousarray(m).astype(np.float16)
+
     def lower_conv(self, i):
         op = self.ops[i]
         a = op["attrs"]
@@ -526,6 +534,13 @@ class Compiler:
         out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
         res = ep["res"]
         flags = 0
+        # k x k stride-1 convs on maps that tile well into 8x32 output patches go to the LDS-resident-patch kernel
+        tile_eff = (oh * ow) / float(-(-oh // 8) * 8 * -(-ow // 32) * 32)
+        patch = ((sh, sw) == (1, 1) and kh * kw >= 3 and inv.span % 32 == 0 and (8 + kh - 1) * (32 + kw - 1) <= 640
+                 and tile_eff >= 0.7 and self.use_patch)
+        if patch:
+            flags |= ir.F_PATCH
+            Kp = kh * kw * inv.span
         ins = [inv]
         resshift = 0
         if res is not None:
@@ -534,8 +549,13 @@ class Compiler:
             flags |= ir.F_RES
             ins.append(res)
             resshift = res.up
-        w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]),
-                                 lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0]))
+        if patch:
+            w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"]),
+                                     lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh * kw,
+                                                                inv.span))
+        else:
+            w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]),
+                                     lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0]))
         b_off = self.add_weights(("convb", wname, ep["out_name"]), bias)
         self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,

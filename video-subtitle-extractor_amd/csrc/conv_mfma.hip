@@ -15,42 +15,12 @@
 //   * epilogue: + bias (BN folded) -> activation -> scalar affine -> (+ residual, optionally upsampled)
 //     -> activation2 -> fp16 (or fp32) store; 2x2/stride-2 transposed conv = same GEMM with a
 //     pixel-shuffle store.
-#include "common.h"
 
-struct ConvParams {
-    const half_t* in;
-    const half_t* w;
-    const float* bias;
-    const half_t* res;
-    const half_t* zero;      // 4 KiB of zeros: gather target for padding / out-of-range lanes
-    void* out;
-    int H, W, Hs, Ws, in_ld, cinp, inshift;
-    int OH, OW;
-    long M;
-    int kh, kw, sh, sw, ph, pw;
-    int Np, nk;
-    int out_ld, out_f32;
-    int res_ld, resshift, res_hs, res_ws;
-    int act, act2;
-    float act_a, act_b, post_a, post_b;
-    int flags, coutp;
-    unsigned ntn;       // number of cout tiles
-};
+#include "conv_common.h"
 
 #define BK 32          // K elements per pipeline stage
 #define STAGES 3       // LDS ring: tile k is consumed while tiles k+1 and k+2 are in flight
 #define ROWB 64        // bytes per LDS row (BK halfs, no padding: LDS-DMA writes are lane-linear)
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// One 16-byte LDS-DMA per lane: global -> LDS without touching VGPRs.  The LDS destination of a wave instruction
-// is wave-uniform base + lane*16 (1 KiB = 16 rows of 64 B), so the bank-conflict swizzle is applied on the SOURCE
-// side: physical 16-byte slot s of row r holds logical k-vector  s ^ ((r >> 2) & 3)  (both sides use the same
-// involution; ds_read_b128 of 16 consecutive rows at one logical k-vector then touches 16 distinct bank groups).
-__device__ __forceinline__ void glds16(const void* g, half_t* l) {
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
-}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
@@ -209,62 +179,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------
-    const bool pixshuf = p.flags & F_PIXSHUF;
-    const bool has_res = p.flags & F_RES;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const long m = m0 + wm * WTM + i * 32 + frow;
+        const long m = m0 + wm * WTM + i * 32 + (lane & 31);
         if (m >= p.M) continue;
-        int ow = 0, oh = 0;
-        long n = 0;
-        if (pixshuf || (has_res && p.resshift)) {
-            ow = (int)(m % p.OW);
-            const long t = m / p.OW;
-            oh = (int)(t % p.OH);
-            n = t / p.OH;
-        }
-        long res_pix = m;
-        if (has_res && p.resshift)
-            res_pix = (n * p.res_hs + (oh >> p.resshift)) * p.res_ws + (ow >> p.resshift);
+        const int ow = (int)(m % p.OW);
+        const long t = m / p.OW;
+        const int oh = (int)(t % p.OH);
+        const long n = t / p.OH;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int c0 = n0 + wn * WTN + j * 32 + q * 8 + (lane >> 5) * 4;
-                if (c0 >= p.Np) continue;
-                const float4v b4 = *reinterpret_cast<const float4v*>(p.bias + c0);
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][j][q * 4 + e] + b4[e];
-                    x = vse_act(x, p.act, p.act_a, p.act_b);
-                    v[e] = x * p.post_a + p.post_b;
-                }
-                long opix = m;
-                int oc = c0;
-                if (pixshuf) {
-                    const int quad = c0 / p.coutp;
-                    oc = c0 - quad * p.coutp;
-                    opix = (n * (2 * p.OH) + 2 * oh + (quad >> 1)) * (2L * p.OW) + 2 * ow + (quad & 1);
-                }
-                if (has_res) {
-                    const half4 r4 = *reinterpret_cast<const half4*>(p.res + res_pix * p.res_ld + oc);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-                }
-                if (p.act2 != ACT_NONE) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = vse_act(v[e], p.act2, 0.f, 0.f);
-                }
-                if (p.out_f32) {
-                    float4v o = {v[0], v[1], v[2], v[3]};
-                    *reinterpret_cast<float4v*>(reinterpret_cast<float*>(p.out) + opix * p.out_ld + oc) = o;
-                } else {
-                    half4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.out) + opix * p.out_ld + oc) = o;
-                }
-            }
-        }
+        for (int j = 0; j < TN; ++j) conv_epilogue_tile(p, acc[i][j], m, n, oh, ow, n0 + wn * WTN + j * 32, lane);
     }
 }
 
@@ -309,11 +233,13 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.coutp = (a.flags & F_PIXSHUF) ? a.Np / 4 : a.Np;
     if (a.in.esize != 2 || (a.in.ld & 7) || (a.cinp & 7) || a.in.c != a.cinp) return VSE_E_INVAL;
     if ((a.flags & F_RES) && (a.res.esize != 2 || (a.res.ld & 3))) return VSE_E_INVAL;
-    if ((a.out.ld & 3) || (a.Np & 7) || (a.Kp % BK)) return VSE_E_INVAL;
+    if ((a.out.ld & 3) || (a.Np & 7)) return VSE_E_INVAL;
     // sanity on the output view: [n, OH(*2), OW(*2)]
     const int mul = (a.flags & F_PIXSHUF) ? 2 : 1;
     if (a.out.h != p.OH * mul || a.out.w != p.OW * mul || a.out.n != a.in.n) return VSE_E_INVAL;
 
+    if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
+    if (a.Kp % 64) return VSE_E_INVAL;
     const int bn = conv_tile_bn(a.Np);
     dim3 block(256);
     const int bm = bn == 128 ? 128 : 256;

@@ -195,7 +195,9 @@ int vse_plan_run(vse_plan* p, void* ws, void* const* ext, int n_ext, void* strea
 int vse_plan_op_variant(vse_plan* p, int i) {
     if (!p || i < 0 || i >= (int)p->ops.size()) return VSE_E_INVAL;
     const vse_op& o = p->ops[i];
-    return o.kind == OP_CONV ? conv_tile_bn(o.p[P_COUT]) : 0;
+    if (o.kind != OP_CONV) return 0;
+    if (o.flags & F_PATCH) return o.p[P_COUT] <= 64 ? 1064 : 1128;   // conv_patch_kernel<64|128>
+    return conv_tile_bn(o.p[P_COUT]);
 }
 
 int vse_plan_profile(vse_plan* p, void* ws, void* const* ext, int n_ext, void* stream, float* ms) {
