@@ -123,8 +123,11 @@ class Emulator:
         KT = ir.KT
         if int(r["flags"]) & ir.F_PATCH:
             taps = kh * kw
-            wt = self.wread(int(r["w_off"]), taps * cinp * Np, np.float16).astype(np.float32)
-            wmat = wt.reshape(cinp // 32, taps, Np, 32).transpose(2, 1, 0, 3).reshape(Np, taps * cinp)
+            tp, c32 = taps + taps % 2, (cinp + 31) // 32 * 32
+            wt = self.wread(int(r["w_off"]), tp * c32 * Np, np.float16).astype(np.float32)
+            wfull = wt.reshape(c32 // 32, tp, Np, 32).transpose(2, 1, 0, 3).reshape(Np, tp, c32)
+            assert not wfull[:, taps:].any() and not wfull[:, :, cinp:].any()
+            wmat = np.ascontiguousarray(wfull[:, :taps, :cinp]).reshape(Np, taps * cinp)
         else:
             wt = self.wread(int(r["w_off"]), (Kp // KT) * Np * KT, np.float16).astype(np.float32)
             wmat = wt.reshape(Kp // KT, Np, KT).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]

@@ -468,9 +468,14 @@ class Compiler:
 
     @staticmethod
     def patch_weights(mat, taps, cinp):
-        """[Np][Kp] (K order tap-major, channel-minor) -> [cinp/32][taps][Np][32] fp16 for conv_patch_kernel."""
+        """[Np][Kp] (K order tap-major, channel-minor) -> [ceil(cinp/32)][taps even][Np][32] fp16 for conv_patch_kernel
+        (zero weights for the channel tail and for the tap appended to an odd tap count)."""
         npad = mat.shape[0]
-        m = mat[:, :taps * cinp].reshape(npad, taps, cinp // 32, 32).transpose(2, 1, 0, 3)
+        c32 = rup(cinp, 32)
+        tp = taps + taps % 2
+        full = np.zeros((npad, tp, c32), mat.dtype)
+        full[:, :taps, :cinp] = mat[:, :taps * cinp].reshape(npad, taps, cinp)
+        m = full.reshape(npad, tp, c32 // 32, 32).transpose(2, 1, 0, 3)
         return np.ascontiguousarray(m).astype(np.float16)
 
     def lower_conv(self, i):
@@ -535,12 +540,14 @@ class Compiler:
         res = ep["res"]
         flags = 0
         # k x k stride-1 convs on maps that tile well into 8x32 output patches go to the LDS-resident-patch kernel
-        tile_eff = (oh * ow) / float(-(-oh // 8) * 8 * -(-ow // 32) * 32)
-        patch = ((sh, sw) == (1, 1) and kh * kw >= 3 and inv.span % 32 == 0 and (8 + kh - 1) * (32 + kw - 1) <= 640
-                 and tile_eff >= 0.7 and self.use_patch)
+        th = 16 if ((16 + kh - 1) * (32 + kw - 1) <= 640 and -(-oh // 16) * 16 <= -(-oh // 8) * 8) else 8
+        tile_eff = (oh * ow) / float(-(-oh // th) * th * -(-ow // 32) * 32)
+        # (one block per CU: the fixed prologue/epilogue only amortises over a long enough K loop)
+        patch = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 640
+                 and tile_eff >= 0.7 and kh * kw * cin >= 580 and self.use_patch)
         if patch:
             flags |= ir.F_PATCH
-            Kp = kh * kw * inv.span
+            Kp = (kh * kw + (kh * kw) % 2) * rup(inv.span, 32)      # taps padded to even, channels to 32
         ins = [inv]
         resshift = 0
         if res is not None:

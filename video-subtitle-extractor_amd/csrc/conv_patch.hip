@@ -7,29 +7,32 @@
 // Activation bytes crossing L2->LDS drop by ~kh*kw / halo overhead (9x9: 81 taps / 2.5 = 32x; 3x3: 9 / 1.33 = 6.8x);
 // what is left to stream per (chunk, tap) step is the [BN][32] weight tile (4-8 KiB), through a 4-deep LDS-DMA ring.
 //
-//   block  = 512 threads = 8 waves: 4 (pixel rows 2w,2w+1) x 2 (cout halves); wave tile = 64 px x BN/2 couts
+//   tile   = TH x 32 output pixels x BN couts, TH = 16 when the halo patch fits 640 pixels (3x3, 1xk), else 8
+//   block  = 512 threads = 8 waves; TH=8: 4 (pixel rows 2w,2w+1) x 2 (cout halves); TH=16: 8 x 1 (all couts):
+//            wave tile = 64 px x {BN/2 | BN} couts, up to 32 MFMAs per wave between barriers
 //   LDS    = 2 x 40 KiB patch (double-buffered across channel chunks) + 4 x 8 KiB weight ring = 112 KiB, one object
-//   sync   = ONE raw s_barrier per (chunk, tap) step; LDS-DMA completion by counted s_waitcnt vmcnt(N):
-//            per step every thread issues exactly 1 weight DMA (+5 patch DMAs at tap 0, zero-page dummies included),
-//            so N is a literal: 7 at taps 1,2 (the patch DMAs of the NEXT chunk are younger than the stage waited
-//            for), 2 otherwise (look-ahead 3 steps)
+//   step   = TWO filter taps (16 MFMAs per wave between barriers; odd tap counts get one zero-weight tap appended)
+//   sync   = ONE raw s_barrier per step; LDS-DMA completion by counted s_waitcnt vmcnt(N): per step every thread
+//            issues exactly 2 weight DMAs (+5 patch DMAs at step 0 of a chunk, zero-page dummies included), so N is
+//            a literal: 9 at steps 1,2 of a chunk (the patch DMAs of the NEXT chunk are younger than the stage
+//            waited for), 4 otherwise (look-ahead 3 steps)
 //   banks  = 64-byte rows; 16-byte slot s of row/pixel q holds logical k-vector s ^ ((q >> 2) & 3), applied on the
 //            DMA source side; 16 consecutive pixels at ANY alignment then hit 16 distinct bank groups (shifted taps
 //            stay conflict-free)
 //   weights are packed [chunk][tap][Np][32] by the compiler for this kernel (F_PATCH) so the stream is sequential.
 #include "conv_common.h"
 
-#define PTH 8
 #define PTW 32
 #define PNPL 5            // patch DMAs per thread per chunk: 5 * 512 threads * 16 B = 640 pixels * 64 B
 #define PPIX 640
 #define PRING 4
 #define PATCH_HALFS (PPIX * 32)
-#define WSTAGE_HALFS (128 * 32)
+#define WSTAGE_HALFS (2 * 128 * 32)   // two taps per ring stage
 
-template <int BN>
+template <int PTH, int BN>
 __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
-    constexpr int TN = BN / 64;                     // 32-cout MFMA tiles per wave
+    constexpr int WCO = PTH == 16 ? 1 : 2;          // waves along cout
+    constexpr int TN = BN / (32 * WCO);             // 32-cout MFMA tiles per wave
     __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + PRING * WSTAGE_HALFS];   // the ONLY LDS object
     half_t* const patch0 = lds;
     half_t* const ring0 = lds + 2 * PATCH_HALFS;
@@ -37,7 +40,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wpx = wave >> 1, wco = wave & 1;
+    const int wpx = wave / WCO, wco = wave % WCO;
 
     // XCD-aware bijective block order (see conv_mfma.hip): contiguous logical range per XCD, cout tiles innermost
     const unsigned nblk = gridDim.x, bid = blockIdx.x;
@@ -51,8 +54,9 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
 
     const int PW = PTW + p.kw - 1, PH = PTH + p.kh - 1, P = PW * PH;
     const int taps = p.kh * p.kw;
-    const int nchunks = p.cinp >> 5;
-    const int total = nchunks * taps;
+    const int pairs = (taps + 1) >> 1;                     // steps per chunk (two taps each)
+    const int nchunks = (p.cinp + 31) >> 5;
+    const int total = nchunks * pairs;
 
     // ---- DMA source state ---------------------------------------------------------------------------------
     const int kv = (lane & 3) ^ ((lane >> 4) & 3);        // logical k-vector this lane fetches (source-side swizzle)
@@ -72,13 +76,16 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
 
     auto issue_patch = [&](int cc, int buf) {
         half_t* base = patch0 + buf * PATCH_HALFS;
-        const bool live = cc < nchunks;
+        const bool live = (cc < nchunks) && (cc * 32 + kv * 8 < p.cinp);   // channel tail of the last chunk -> zeros
 #pragma unroll
         for (int j = 0; j < PNPL; ++j)
             glds16((live && pok[j]) ? p.in + poff[j] + cc * 32 : p.zero, base + (wave + 8 * j) * 16 * 32);
     };
-    auto issue_w = [&](int s) {
-        glds16((wok && s < total) ? wsrc + (long)s * p.Np * 32 : p.zero, ring0 + (s & (PRING - 1)) * WSTAGE_HALFS + wave * 16 * 32);
+    auto issue_w = [&](int s) {                            // ring stage = taps 2s, 2s+1 of the packed stream
+        half_t* dst = ring0 + (s & (PRING - 1)) * WSTAGE_HALFS + wave * 16 * 32;
+        const bool live = wok && s < total;
+        glds16(live ? wsrc + (long)(2 * s) * p.Np * 32 : p.zero, dst);
+        glds16(live ? wsrc + (long)(2 * s + 1) * p.Np * 32 : p.zero, dst + 128 * 32);
     };
 
     // ---- fragment addressing ---------------------------------------------------------------------------------
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int r = wco * (BN / 2) + j * 32 + fx;
+            const int r = wco * (BN / WCO) + j * 32 + fx;
             woff[j][ks] = r * 32 + (((ks * 2 + fj) ^ ((r >> 2) & 3)) << 3);
         }
     const int qb0 = (2 * wpx) * PW + fx, qb1 = qb0 + PW;
@@ -109,30 +116,38 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     int s = 0;
     for (int cc = 0; cc < nchunks; ++cc) {
         const half_t* pbuf = patch0 + (cc & 1) * PATCH_HALFS;
-        int tapoff = 0, dx = 0;                            // dy*PW + dx
-        for (int tap = 0; tap < taps; ++tap, ++s) {
-            if (tap == 1 || tap == 2) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        const bool klim1 = (p.cinp - cc * 32) <= 16;
+        int tapoff = 0, dx = 0, tap = 0;                   // tapoff = dy*PW + dx of tap
+        for (int pr = 0; pr < pairs; ++pr, ++s) {
+            if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (tap == 0) issue_patch(cc + 1, (cc + 1) & 1);
+            if (pr == 0) issue_patch(cc + 1, (cc + 1) & 1);
             issue_w(s + 3);
             const half_t* wst = ring0 + (s & (PRING - 1)) * WSTAGE_HALFS;
-            const int q0 = qb0 + tapoff, q1 = qb1 + tapoff;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                half8 wf[TN], xf[2];
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && tap >= taps) break;          // odd tap count: the appended zero-weight tap does no work
+                const int q0 = qb0 + tapoff, q1 = qb1 + tapoff;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(wst + woff[j][ks]);
-                xf[0] = *reinterpret_cast<const half8*>(pbuf + q0 * 32 + (((ks * 2 + fj) ^ ((q0 >> 2) & 3)) << 3));
-                xf[1] = *reinterpret_cast<const half8*>(pbuf + q1 * 32 + (((ks * 2 + fj) ^ ((q1 >> 2) & 3)) << 3));
+                for (int ks = 0; ks < 2; ++ks) {
+                    if (ks == 1 && klim1) break;           // channel tail <= 16: upper half of the chunk is all zeros
+                    half8 wf[TN], xf[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(wst + h * 128 * 32 + woff[j][ks]);
+                    xf[0] = *reinterpret_cast<const half8*>(pbuf + q0 * 32 + (((ks * 2 + fj) ^ ((q0 >> 2) & 3)) << 3));
+                    xf[1] = *reinterpret_cast<const half8*>(pbuf + q1 * 32 + (((ks * 2 + fj) ^ ((q1 >> 2) & 3)) << 3));
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                }
+                if (++tap < taps) {
+                    if (++dx == p.kw) { dx = 0; tapoff += PW - p.kw + 1; } else { ++tapoff; }
+                }
             }
-            if (++dx == p.kw) { dx = 0; tapoff += PW - p.kw + 1; } else { ++tapoff; }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-page dummies before LDS is released
@@ -144,21 +159,38 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
         if (oy >= p.OH || ox >= p.OW) continue;
         const long m = (img * p.OH + oy) * p.OW + ox;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) conv_epilogue_tile(p, acc[i][j], m, img, oy, ox, n0 + wco * (BN / 2) + j * 32, lane);
+        for (int j = 0; j < TN; ++j) conv_epilogue_tile(p, acc[i][j], m, img, oy, ox, n0 + wco * (BN / WCO) + j * 32, lane);
     }
+}
+
+// Tile height: 16 rows when the halo patch fits the 640-pixel LDS buffer and the map tiles at least as well as with 8.
+int conv_patch_th(int kh, int kw, int OH) {
+    if ((16 + kh - 1) * (PTW + kw - 1) > PPIX) return 8;
+    const int pad16 = (OH + 15) / 16 * 16, pad8 = (OH + 7) / 8 * 8;
+    return pad16 <= pad8 ? 16 : 8;
+}
+
+// cout tile: 64 or 128, whichever pads Np less (ties -> 128)
+int conv_patch_bn(int Np) {
+    const int p64 = (Np + 63) / 64 * 64, p128 = (Np + 127) / 128 * 128;
+    return p64 < p128 ? 64 : 128;
 }
 
 int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
     ConvParams p = pin;
-    if (p.sh != 1 || p.sw != 1 || p.kh * p.kw < 3 || (p.cinp & 31) || (p.flags & F_PIXSHUF)) return VSE_E_INVAL;
-    if ((PTH + p.kh - 1) * (PTW + p.kw - 1) > PPIX) return VSE_E_UNSUPPORTED;
-    const int bn = p.Np <= 64 ? 64 : 128;
+    if (p.sh != 1 || p.sw != 1 || p.kh * p.kw < 5 || (p.cinp & 7) || (p.flags & F_PIXSHUF)) return VSE_E_INVAL;
+    if ((8 + p.kh - 1) * (PTW + p.kw - 1) > PPIX) return VSE_E_UNSUPPORTED;
+    const int th = conv_patch_th(p.kh, p.kw, p.OH);
+    const int bn = conv_patch_bn(p.Np);
     p.ntn = (unsigned)((p.Np + bn - 1) / bn);
-    p.tiles_h = (p.OH + PTH - 1) / PTH;
+    p.tiles_h = (p.OH + th - 1) / th;
     p.tiles_w = (p.OW + PTW - 1) / PTW;
     const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w * p.ntn;
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
-    if (bn == 64) hipLaunchKernelGGL((conv_patch_kernel<64>), dim3((unsigned)blocks), dim3(512), 0, st, p);
-    else hipLaunchKernelGGL((conv_patch_kernel<128>), dim3((unsigned)blocks), dim3(512), 0, st, p);
+    const dim3 grid((unsigned)blocks), block(512);
+    if (th == 16 && bn == 64) hipLaunchKernelGGL((conv_patch_kernel<16, 64>), grid, block, 0, st, p);
+    else if (th == 16) hipLaunchKernelGGL((conv_patch_kernel<16, 128>), grid, block, 0, st, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv_patch_kernel<8, 64>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_patch_kernel<8, 128>), grid, block, 0, st, p);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }

@@ -5,7 +5,7 @@
 #include <string>
 #include <vector>
 
-#include "common.h"
+#include "conv_common.h"
 
 static thread_local std::string g_err;
 static void set_err(const char* fmt, ...) {
@@ -196,7 +196,8 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if (!p || i < 0 || i >= (int)p->ops.size()) return VSE_E_INVAL;
     const vse_op& o = p->ops[i];
     if (o.kind != OP_CONV) return 0;
-    if (o.flags & F_PATCH) return o.p[P_COUT] <= 64 ? 1064 : 1128;   // conv_patch_kernel<64|128>
+    if (o.flags & F_PATCH)   // conv_patch_kernel<TH, BN> -> 1000*TH + BN
+        return 1000 * conv_patch_th(o.p[P_KH], o.p[P_KW], o.out.h) + conv_patch_bn(o.p[P_COUT]);
     return conv_tile_bn(o.p[P_COUT]);
 }
 
