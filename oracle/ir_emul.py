@@ -145,6 +145,13 @@ class Emulator:
             res = self._up(self.read(r["in1"]), int(p[ir.P_RESSHIFT]))
             y[..., :res.shape[3]] += res[..., :y.shape[3]]
         y = _act(y, int(p[ir.P_ACT2]))
+        if flags & ir.F_DOT1:
+            dw = torch.from_numpy(self.wread(int(r["aux_off"]), Np, np.float32).copy())
+            z = (y * dw).sum(-1, keepdim=True) + float(f[ir.FS_PRE_B])
+            z = _act(z, int(p[ir.P_DOTACT]))
+            oc2 = int(r["out2"]["c"])
+            self.write(r["out2"], z if oc2 == 1 else F.pad(z, (0, oc2 - 1)))   # pad channels (if any) are written as 0
+            return
         oc = int(r["out"]["c"])
         self.write(r["out"], y[..., :oc] if y.shape[3] >= oc else F.pad(y, (0, oc - y.shape[3])))
 

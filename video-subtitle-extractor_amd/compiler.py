@@ -466,6 +466,43 @@ class Compiler:
         t = mat.reshape(npad, kp // ir.KT, ir.KT).transpose(1, 0, 2)
         return np.ascontiguousarray(t).astype(np.float16)
 
+    def _try_fuse_dot1(self, name, cout, coutp):
+        """`name` (conv output after its epilogue) -> conv2d 1x1 to ONE channel (+bias, +sigmoid): fold it into the
+        producing conv's epilogue as a per-pixel dot product; the wide tensor is then never written to HBM."""
+        cons = self._live_consumers(name)
+        if len(cons) != 1 or name in self.placement:
+            return None
+        j = cons[0]
+        op = self.ops[j]
+        if op["type"] != "conv2d":
+            return None
+        a = op["attrs"]
+        w2 = self.W[op["in"]["Filter"][0]]
+        if tuple(w2.shape) != (1, cout, 1, 1) or list(a["strides"]) != [1, 1] or any(a["paddings"]) or a.get("groups", 1) != 1:
+            return None
+        done_before = set(self.done)
+        ep2 = self.absorb_epilogue(op["out"]["Output"][0], j, 1, allow_res=False)
+        ok = (ep2["act"] in (ir.ACT_NONE, ir.ACT_SIGMOID) and ep2["post_a"] == 1.0 and ep2["post_b"] == 0.0
+              and ep2["act2"] == ir.ACT_NONE)
+        if not ok:
+            self.done = done_before
+            return None
+        self.done.add(j)
+        wv = np.zeros(coutp, np.float32)
+        wv[:cout] = w2[0, :, 0, 0].astype(np.float64) * ep2["scale"][0]
+        out_name = ep2["out_name"]
+        x = self.env_dims_tmp
+        n, h, w = x
+        fcons = self._live_consumers(out_name)
+        if len(fcons) == 1 and self.ops[fcons[0]]["type"] == "fetch":
+            ob = self.new_buf(n, h, w, 1, esize=4, ext=len(self.outputs) + 1)
+            self.outputs.append(dict(name=out_name, kind="map", n=n, h=h, w=w, c=1, ld=1, esize=4))
+        else:
+            ob = self.new_buf(n, h, w, 8, esize=2)
+        view = View(ob, 0, n, h, w, [(0, 1)], 1 if ob.esize == 4 else 8)
+        return dict(w=wv, b=float(ep2["shift"][0]), act=ep2["act"], out_name=out_name, view=view,
+                    wname=op["in"]["Filter"][0])
+
     @staticmethod
     def patch_weights(mat, taps, cinp):
         """[Np][Kp] (K order tap-major, channel-minor) -> [ceil(cinp/32)][taps even][Np][32] fp16 for conv_patch_kernel
@@ -545,6 +582,7 @@ class Compiler:
         # (one block per CU: the fixed prologue/epilogue only amortises over a long enough K loop)
         patch = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 640
                  and tile_eff >= 0.7 and kh * kw * cin >= 580 and self.use_patch)
+        self.env_dims_tmp = (inv.n, oh, ow)
         if patch:
             flags |= ir.F_PATCH
             Kp = (kh * kw + (kh * kw) % 2) * rup(inv.span, 32)      # taps padded to even, channels to 32
@@ -564,6 +602,19 @@ class Compiler:
             w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]),
                                      lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0]))
         b_off = self.add_weights(("convb", wname, ep["out_name"]), bias)
+        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch and th == 16 and coutp <= 128) else None
+        if dot is not None:
+            aux_off = self.add_weights(("dot1", dot["wname"], ep["out_name"]), dot["w"])
+            self.emit(ir.OP_CONV, dot["out_name"], ins, dot["view"], flags=flags | ir.F_DOT1,
+                      p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
+                         ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"], ir.P_COUT: coutp, ir.P_KTOT: Kp,
+                         ir.P_INSHIFT: inv.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span, ir.P_DOTACT: dot["act"]},
+                      f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
+                         ir.FS_POST_B: ep["post_b"], ir.FS_PRE_B: dot["b"]}, w_off=w_off, b_off=b_off,
+                      aux_off=aux_off, out2=dot["view"])
+            self.add_gmacs(inv.n * oh * ow * (cin * cout * kh * kw + cout) / 1e9)
+            self.env[dot["out_name"]] = dot["view"]
+            return
         self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
                      ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"], ir.P_COUT: coutp, ir.P_KTOT: Kp,

@@ -21,6 +21,10 @@ struct ConvParams {
     int flags, coutp;
     unsigned ntn;       // number of cout tiles
     int tiles_h, tiles_w;   // patch kernel: output tile grid per image
+    const float* dotw;      // F_DOT1: per-cout weights of the fused 1-channel projection
+    float dotb;
+    int dotact, dot_f32, dot_ld;
+    void* dot_out;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -78,6 +82,27 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
             *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.out) + opix * p.out_ld + oc) = o;
         }
     }
+}
+
+// F_DOT1 variant: returns this lane's partial  sum_c y[c] * dotw[c]  over the couts it owns in one accumulator tile
+// (y = the full epilogue value); nothing is stored.
+__device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const float16v& acc, int cbase, int lane) {
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c0 = cbase + q * 8 + (lane >> 5) * 4;
+        if (c0 >= p.Np) continue;
+        const float4v b4 = *reinterpret_cast<const float4v*>(p.bias + c0);
+        const float4v w4 = *reinterpret_cast<const float4v*>(p.dotw + c0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = acc[q * 4 + e] + b4[e];
+            x = vse_act(x, p.act, p.act_a, p.act_b) * p.post_a + p.post_b;
+            x = vse_act(x, p.act2, 0.f, 0.f);
+            part += x * w4[e];
+        }
+    }
+    return part;
 }
 
 int launch_conv_patch(const ConvParams& p, int n_img, hipStream_t st);

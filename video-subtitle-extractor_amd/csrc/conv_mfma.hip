@@ -233,11 +233,14 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.coutp = (a.flags & F_PIXSHUF) ? a.Np / 4 : a.Np;
     if (a.in.esize != 2 || (a.in.ld & 7) || (a.cinp & 7) || a.in.c != a.cinp) return VSE_E_INVAL;
     if ((a.flags & F_RES) && (a.res.esize != 2 || (a.res.ld & 3))) return VSE_E_INVAL;
-    if ((a.out.ld & 3) || (a.Np & 7)) return VSE_E_INVAL;
+    if ((!(a.flags & F_DOT1) && (a.out.ld & 3)) || (a.Np & 7)) return VSE_E_INVAL;
     // sanity on the output view: [n, OH(*2), OW(*2)]
     const int mul = (a.flags & F_PIXSHUF) ? 2 : 1;
     if (a.out.h != p.OH * mul || a.out.w != p.OW * mul || a.out.n != a.in.n) return VSE_E_INVAL;
 
+    p.dotw = a.dotw; p.dotb = a.dotb; p.dotact = a.dotact;
+    p.dot_out = a.dot_out.ptr; p.dot_f32 = a.dot_out.esize == 4; p.dot_ld = a.dot_out.ld;
+    if ((a.flags & F_DOT1) && !(a.flags & F_PATCH)) return VSE_E_UNSUPPORTED;
     if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
     if (a.Kp % 64) return VSE_E_INVAL;
     const int bn = conv_tile_bn(a.Np);

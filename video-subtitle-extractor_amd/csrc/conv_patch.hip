@@ -153,6 +153,27 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-page dummies before LDS is released
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
+    if constexpr (WCO == 1) {
+        if (p.flags & F_DOT1) {
+            // fused 1x1 projection to one channel: this wave owns ALL couts of its pixels; lanes l and l+32 hold the
+            // two halves of a pixel's couts -> one cross-half add, then lanes 0..31 store one value per pixel
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) part += conv_epilogue_dot(p, acc[i][j], n0 + j * 32, lane);
+                part += __shfl_xor(part, 32);
+                const int oy = oy0 + 2 * wpx + i, ox = ox0 + fx;
+                if (fj == 0 && oy < p.OH && ox < p.OW) {
+                    const long m = (img * p.OH + oy) * p.OW + ox;
+                    const float z = vse_act(part + p.dotb, p.dotact, 0.f, 0.f);
+                    if (p.dot_f32) reinterpret_cast<float*>(p.dot_out)[m * p.dot_ld] = z;
+                    else reinterpret_cast<half_t*>(p.dot_out)[m * p.dot_ld] = (half_t)z;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int oy = oy0 + 2 * wpx + i, ox = ox0 + fx;
@@ -183,6 +204,7 @@ int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
     const int th = conv_patch_th(p.kh, p.kw, p.OH);
     const int bn = conv_patch_bn(p.Np);
     p.ntn = (unsigned)((p.Np + bn - 1) / bn);
+    if ((p.flags & F_DOT1) && (th != 16 || p.ntn != 1 || (p.flags & F_RES) || !p.dotw || !p.dot_out)) return VSE_E_UNSUPPORTED;
     p.tiles_h = (p.OH + th - 1) / th;
     p.tiles_w = (p.OW + PTW - 1) / PTW;
     const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w * p.ntn;

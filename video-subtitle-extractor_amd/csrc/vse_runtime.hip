@@ -170,6 +170,8 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, hipStream_t st
         a.act = o.p[P_ACT]; a.act2 = o.p[P_ACT2]; a.Np = o.p[P_COUT]; a.Kp = o.p[P_KTOT];
         a.inshift = o.p[P_INSHIFT]; a.resshift = o.p[P_RESSHIFT]; a.cinp = o.p[P_CINP]; a.flags = o.flags;
         a.act_a = o.f[FS_ACT_A]; a.act_b = o.f[FS_ACT_B]; a.post_a = o.f[FS_POST_A]; a.post_b = o.f[FS_POST_B];
+        a.dotw = reinterpret_cast<const float*>(wts + o.aux_off);
+        a.dotb = o.f[FS_PRE_B]; a.dotact = o.p[P_DOTACT]; a.dot_out = out2;
         rc = launch_conv(a, st);
     } else {
         rc = launch_simple_op(o, in0, in1, in2, out, out2, wts, st);
