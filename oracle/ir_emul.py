@@ -119,6 +119,8 @@ class Emulator:
         kh, kw, sh, sw, ph, pw = (int(p[i]) for i in range(6))
         Np, Kp, cinp = int(p[ir.P_COUT]), int(p[ir.P_KTOT]), int(p[ir.P_CINP])
         x = self._up(self.read(r["in0"]), int(p[ir.P_INSHIFT]))
+        if int(r["flags"]) & ir.F_SRC2:
+            x = torch.cat([x, self._up(self.read(r["in2"]), int(p[ir.P_IN2SHIFT]))], dim=3)
         assert x.shape[3] == cinp
         KT = ir.KT
         if int(r["flags"]) & ir.F_PATCH:

@@ -64,6 +64,7 @@ class View:
     span: int                      # physical channel span
     up: int = 0                    # virtual nearest-upsample shift (logical h,w already upsampled)
     tag: str = "nchw"              # logical layout of the Paddle tensor this view stands for
+    parts: Optional[list] = None   # virtual 2-way concat: [View, View] gathered by the consumer conv (no copy)
 
     @property
     def c(self):
@@ -182,15 +183,35 @@ class Compiler:
         """tensor name -> (concat out name, physical channel offset) so producers write in place."""
         self.placement = {}
         self.concat_layout = {}
+        self.virtual_concats = set()
         for i, op in enumerate(self.ops):
             if op["type"] != "concat" or not self.live[i]:
                 continue
             out = op["out"]["Out"][0]
             self.concat_layout[out] = None   # resolved lazily when channel counts are known
+            if self._concat_is_virtual(i):
+                self.virtual_concats.add(out)
+                continue
             for name in op["in"]["X"]:
                 if name not in self.placement and len([c for c in self.consumers.get(name, [])
                                                         if self.ops[c]["type"] == "concat"]) == 1:
                     self.placement[name] = out
+
+    def _concat_is_virtual(self, i):
+        """2-input concat with a nearest-upsampled input whose ONLY consumer is a k x k stride-1 conv: the patch conv
+        kernel gathers both sources itself (second source with its own shift), nothing is copied."""
+        op = self.ops[i]
+        ins = op["in"]["X"]
+        if len(ins) != 2 or not getattr(self, "use_patch", True):
+            return False
+        if not any(self.ops[self.producer[n]]["type"] == "nearest_interp_v2" for n in ins if n in self.producer):
+            return False
+        cons = self._live_consumers(op["out"]["Out"][0])
+        if len(cons) != 1 or self.ops[cons[0]]["type"] != "conv2d":
+            return False
+        c = self.ops[cons[0]]
+        w = self.W[c["in"]["Filter"][0]]
+        return list(c["attrs"]["strides"]) == [1, 1] and w.shape[2] * w.shape[3] >= 5 and c["attrs"].get("groups", 1) == 1
 
     def is_param(self, name):
         return name in self.W
@@ -256,7 +277,7 @@ class Compiler:
         rec = dict(kind=kind, name=name, flags=flags, p=dict(p or {}), f=dict(f or {}), ins=list(ins), out=out,
                    out2=out2, w_off=w_off, b_off=b_off, aux_off=aux_off)
         for v in list(ins) + [out, out2]:
-            if v is not None:
+            if v is not None and v.buf is not None:
                 v.buf.first = min(v.buf.first, idx)
                 v.buf.last = max(v.buf.last, idx)
         rec["gmac"] = 0.0
@@ -274,7 +295,15 @@ class Compiler:
 
     # -------------------------------------------------------------------------------------------- materialize
     def materialize(self, v: View, name="mat"):
-        """Turn a virtual (upsampled) view into a real buffer."""
+        """Turn a virtual (upsampled / 2-source) view into a real buffer."""
+        if v.parts is not None:
+            b = self.new_buf(v.n, v.h, v.w, v.span)
+            off = 0
+            for pv in v.parts:
+                dst = View(b, off, v.n, v.h, v.w, [(0, pv.c)], pv.span)
+                self.emit(ir.OP_RESIZE, name + ":part", [pv], dst, p={0: pv.up})
+                off += pv.span
+            return View(b, 0, v.n, v.h, v.w, list(v.segs), v.span)
         if v.up == 0:
             return v
         out = self.alloc_out("__mat_" + name, v.n, v.h, v.w, v.c)
@@ -586,7 +615,19 @@ class Compiler:
         if patch:
             flags |= ir.F_PATCH
             Kp = (kh * kw + (kh * kw) % 2) * rup(inv.span, 32)      # taps padded to even, channels to 32
-        ins = [inv]
+        in2shift = 0
+        if inv.parts is not None:
+            if patch:
+                flags |= ir.F_SRC2
+                part0, part1 = inv.parts
+                in2shift = part1.up
+                inv_main = part0
+            else:
+                inv = self.materialize(inv, outname)
+                inv_main = inv
+        else:
+            inv_main = inv
+        ins = [inv_main]
         resshift = 0
         if res is not None:
             assert (res.n, res.h, res.w, res.c) == (inv.n, oh, ow, cout), (outname, res, oh, ow, cout)
@@ -594,6 +635,10 @@ class Compiler:
             flags |= ir.F_RES
             ins.append(res)
             resshift = res.up
+        if flags & ir.F_SRC2:
+            while len(ins) < 2:
+                ins.append(None)
+            ins.append(inv.parts[1])
         if patch:
             w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"]),
                                      lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh * kw,
@@ -608,7 +653,8 @@ class Compiler:
             self.emit(ir.OP_CONV, dot["out_name"], ins, dot["view"], flags=flags | ir.F_DOT1,
                       p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
                          ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"], ir.P_COUT: coutp, ir.P_KTOT: Kp,
-                         ir.P_INSHIFT: inv.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span, ir.P_DOTACT: dot["act"]},
+                         ir.P_INSHIFT: inv_main.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span, ir.P_DOTACT: dot["act"],
+                         ir.P_IN2SHIFT: in2shift},
                       f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                          ir.FS_POST_B: ep["post_b"], ir.FS_PRE_B: dot["b"]}, w_off=w_off, b_off=b_off,
                       aux_off=aux_off, out2=dot["view"])
@@ -618,7 +664,7 @@ class Compiler:
         self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
                      ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"], ir.P_COUT: coutp, ir.P_KTOT: Kp,
-                     ir.P_INSHIFT: inv.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span},
+                     ir.P_INSHIFT: inv_main.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span, ir.P_IN2SHIFT: in2shift},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                      ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
         self.add_gmacs(inv.n * oh * ow * cin * cout * kh * kw / 1e9)
@@ -883,6 +929,13 @@ class Compiler:
         ins = [self.resolve(n) for n in op["in"]["X"]]
         assert all(v is not None for v in ins), (i, op["in"]["X"])
         v0 = ins[0]
+        if name in self.virtual_concats and all(v.segs == [(0, v.c)] for v in ins):
+            segs, off = [], 0
+            for v in ins:
+                segs.append((off, v.c))
+                off += v.span
+            self.env[name] = View(None, 0, v0.n, v0.h, v0.w, segs, off, 0, "nchw", parts=list(ins))
+            return
         lay = self._concat_buf(name, v0.n, v0.h, v0.w)
         b = lay["buf"]
         segs = []

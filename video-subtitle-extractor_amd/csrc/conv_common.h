@@ -25,6 +25,8 @@ struct ConvParams {
     float dotb;
     int dotact, dot_f32, dot_ld;
     void* dot_out;
+    const half_t* in2;      // F_SRC2: channels [nv0*8, cinp) come from this tensor (own pixel grid / shift / stride)
+    int in2_ld, in2_shift, in2_hs, in2_ws, nv0;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

@@ -231,7 +231,13 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.act_a = a.act_a; p.act_b = a.act_b; p.post_a = a.post_a; p.post_b = a.post_b;
     p.flags = a.flags;
     p.coutp = (a.flags & F_PIXSHUF) ? a.Np / 4 : a.Np;
-    if (a.in.esize != 2 || (a.in.ld & 7) || (a.cinp & 7) || a.in.c != a.cinp) return VSE_E_INVAL;
+    if (a.flags & F_SRC2) {
+        if (!a.in2.ptr || a.in2.esize != 2 || (a.in2.ld & 7) || a.in.c + a.in2.c != a.cinp) return VSE_E_INVAL;
+        if ((a.in2.h << a.in2shift) != p.H || (a.in2.w << a.in2shift) != p.W) return VSE_E_INVAL;
+    } else if (a.in.c != a.cinp) {
+        return VSE_E_INVAL;
+    }
+    if (a.in.esize != 2 || (a.in.ld & 7) || (a.cinp & 7)) return VSE_E_INVAL;
     if ((a.flags & F_RES) && (a.res.esize != 2 || (a.res.ld & 3))) return VSE_E_INVAL;
     if ((!(a.flags & F_DOT1) && (a.out.ld & 3)) || (a.Np & 7)) return VSE_E_INVAL;
     // sanity on the output view: [n, OH(*2), OW(*2)]
@@ -240,7 +246,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 
     p.dotw = a.dotw; p.dotb = a.dotb; p.dotact = a.dotact;
     p.dot_out = a.dot_out.ptr; p.dot_f32 = a.dot_out.esize == 4; p.dot_ld = a.dot_out.ld;
-    if ((a.flags & F_DOT1) && !(a.flags & F_PATCH)) return VSE_E_UNSUPPORTED;
+    p.in2 = reinterpret_cast<const half_t*>(a.in2.ptr); p.in2_ld = a.in2.ld; p.in2_shift = a.in2shift;
+    p.in2_hs = a.in2.h; p.in2_ws = a.in2.w; p.nv0 = a.in.c >> 3;
+    if ((a.flags & (F_DOT1 | F_SRC2)) && !(a.flags & F_PATCH)) return VSE_E_UNSUPPORTED;
     if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
     if (a.Kp % 64) return VSE_E_INVAL;
     const int bn = conv_tile_bn(a.Np);

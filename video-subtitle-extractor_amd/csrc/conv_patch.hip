@@ -60,7 +60,8 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
 
     // ---- DMA source state ---------------------------------------------------------------------------------
     const int kv = (lane & 3) ^ ((lane >> 4) & 3);        // logical k-vector this lane fetches (source-side swizzle)
-    long poff[PNPL];
+    const bool src2 = p.flags & F_SRC2;                    // virtual concat: vectors >= nv0 come from p.in2
+    long poff[PNPL], poff2[PNPL];
     bool pok[PNPL];
 #pragma unroll
     for (int j = 0; j < PNPL; ++j) {
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
         const int iy = oy0 - p.ph + py, ix = ox0 - p.pw + px;
         pok[j] = (q < P) && (iy >= 0) && (iy < p.H) && (ix >= 0) && (ix < p.W);
         poff[j] = ((img * p.Hs + (iy >> p.inshift)) * p.Ws + (ix >> p.inshift)) * (long)p.in_ld + kv * 8;
+        poff2[j] = src2 ? ((img * p.in2_hs + (iy >> p.in2_shift)) * p.in2_ws + (ix >> p.in2_shift)) * (long)p.in2_ld
+                              + (kv - p.nv0) * 8
+                        : 0;
     }
     const int wr = tid >> 2;                               // weight row (cout within the block tile), 0..127
     const bool wok = (wr < BN) && (n0 + wr < p.Np);
@@ -77,9 +81,13 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     auto issue_patch = [&](int cc, int buf) {
         half_t* base = patch0 + buf * PATCH_HALFS;
         const bool live = (cc < nchunks) && (cc * 32 + kv * 8 < p.cinp);   // channel tail of the last chunk -> zeros
+        const bool second = src2 && (cc * 4 + kv >= p.nv0);
 #pragma unroll
-        for (int j = 0; j < PNPL; ++j)
-            glds16((live && pok[j]) ? p.in + poff[j] + cc * 32 : p.zero, base + (wave + 8 * j) * 16 * 32);
+        for (int j = 0; j < PNPL; ++j) {
+            const half_t* src = p.zero;
+            if (live && pok[j]) src = second ? p.in2 + poff2[j] + cc * 32 : p.in + poff[j] + cc * 32;
+            glds16(src, base + (wave + 8 * j) * 16 * 32);
+        }
     };
     auto issue_w = [&](int s) {                            // ring stage = taps 2s, 2s+1 of the packed stream
         half_t* dst = ring0 + (s & (PRING - 1)) * WSTAGE_HALFS + wave * 16 * 32;

@@ -172,6 +172,7 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, hipStream_t st
         a.act_a = o.f[FS_ACT_A]; a.act_b = o.f[FS_ACT_B]; a.post_a = o.f[FS_POST_A]; a.post_b = o.f[FS_POST_B];
         a.dotw = reinterpret_cast<const float*>(wts + o.aux_off);
         a.dotb = o.f[FS_PRE_B]; a.dotact = o.p[P_DOTACT]; a.dot_out = out2;
+        a.in2 = in2; a.in2shift = o.p[P_IN2SHIFT];
         rc = launch_conv(a, st);
     } else {
         rc = launch_simple_op(o, in0, in1, in2, out, out2, wts, st);

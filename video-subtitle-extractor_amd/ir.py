@@ -62,6 +62,8 @@ F_OUT_F32 = 4       # store fp32
 F_PATCH = 8         # LDS-resident-patch conv kernel; weights packed [chunk][tap][Np][32]
 F_DOT1 = 16         # epilogue ends in a fused 1x1 conv to ONE channel: out2 = act(sum_c y[c]*dotw[c] + f[FS_PRE_B]); y is not stored
 P_DOTACT = 13       # activation of the fused 1-channel projection
+F_SRC2 = 32         # in2 is a second input source: channels [in0.c, in0.c+in2.c) of a virtual concat, own shift p[P_IN2SHIFT]
+P_IN2SHIFT = 14
 # f[] slots (all kinds that carry an activation)
 FS_ACT_A, FS_ACT_B = 0, 1      # hard_sigmoid slope/offset
 FS_POST_A, FS_POST_B = 2, 3    # scalar affine after the activation
