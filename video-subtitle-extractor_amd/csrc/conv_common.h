@@ -108,5 +108,5 @@ __device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const fl
 }
 
 int launch_conv_patch(const ConvParams& p, int n_img, hipStream_t st);
-int conv_patch_th(int kh, int kw, int OH);
+int conv_patch_th(int kh, int kw, int OH, int bn);
 int conv_patch_bn(int Np);

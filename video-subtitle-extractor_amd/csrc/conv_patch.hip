@@ -23,19 +23,23 @@
 #include "conv_common.h"
 
 #define PTW 32
-#define PNPL 5            // patch DMAs per thread per chunk: 5 * 512 threads * 16 B = 640 pixels * 64 B
-#define PPIX 640
 #define PRING 4
-#define PATCH_HALFS (PPIX * 32)
-#define WSTAGE_HALFS (2 * 128 * 32)   // two taps per ring stage
 
-template <int PTH, int BN>
+// BIGP (BN = 64 only): 960-pixel patch (16-row tiles under 9x9 / 7x7 filters) and a 64-row weight ring:
+//   2 x 60 KiB patch + 4 x 8 KiB ring + 4 KiB dummy = 156 KiB;  otherwise 2 x 40 KiB + 4 x 16 KiB = 144 KiB.
+template <int PTH, int BN, bool BIGP>
 __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
+    static_assert(!BIGP || (BN == 64 && PTH == 16), "big patch variant");
     constexpr int WCO = PTH == 16 ? 1 : 2;          // waves along cout
     constexpr int TN = BN / (32 * WCO);             // 32-cout MFMA tiles per wave
-    __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + PRING * WSTAGE_HALFS];   // the ONLY LDS object
+    constexpr int PPIX = BIGP ? 960 : 640;          // patch capacity in pixels
+    constexpr int PNPL = BIGP ? 8 : 5;              // patch DMAs per thread per chunk (512 threads x 16 B each)
+    constexpr int RROWS = BIGP ? 64 : 128;          // weight rows per tap in a ring stage
+    constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = 2 * RROWS * 32;   // two taps per ring stage
+    __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + PRING * WSTAGE_HALFS + (BIGP ? 4 * 512 : 0)];   // the ONLY LDS object
     half_t* const patch0 = lds;
     half_t* const ring0 = lds + 2 * PATCH_HALFS;
+    half_t* const dummy0 = ring0 + PRING * WSTAGE_HALFS;   // BIGP: landing zone of the 4 surplus patch DMAs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -74,7 +78,9 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
                               + (kv - p.nv0) * 8
                         : 0;
     }
-    const int wr = tid >> 2;                               // weight row (cout within the block tile), 0..127
+    // weight DMA: non-BIGP: thread -> row tid>>2 (0..127), both taps of the step (2 DMAs);  BIGP: waves 0-3 fetch
+    // tap 0, waves 4-7 tap 1, rows 0..63 (1 DMA)
+    const int wr = BIGP ? ((tid >> 2) & 63) : (tid >> 2);
     const bool wok = (wr < BN) && (n0 + wr < p.Np);
     const half_t* wsrc = p.w + (long)(n0 + wr) * 32 + kv * 8;
 
@@ -86,14 +92,21 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
         for (int j = 0; j < PNPL; ++j) {
             const half_t* src = p.zero;
             if (live && pok[j]) src = second ? p.in2 + poff2[j] + cc * 32 : p.in + poff[j] + cc * 32;
-            glds16(src, base + (wave + 8 * j) * 16 * 32);
+            half_t* dst = base + (wave + 8 * j) * 16 * 32;
+            if (BIGP && j == PNPL - 1 && wave >= 4) { src = p.zero; dst = dummy0 + (wave - 4) * 512; }   // pixels >= 960
+            glds16(src, dst);
         }
     };
     auto issue_w = [&](int s) {                            // ring stage = taps 2s, 2s+1 of the packed stream
-        half_t* dst = ring0 + (s & (PRING - 1)) * WSTAGE_HALFS + wave * 16 * 32;
+        half_t* st = ring0 + (s & (PRING - 1)) * WSTAGE_HALFS;
         const bool live = wok && s < total;
-        glds16(live ? wsrc + (long)(2 * s) * p.Np * 32 : p.zero, dst);
-        glds16(live ? wsrc + (long)(2 * s + 1) * p.Np * 32 : p.zero, dst + 128 * 32);
+        if constexpr (BIGP) {
+            const int h = wave >> 2;
+            glds16(live ? wsrc + (long)(2 * s + h) * p.Np * 32 : p.zero, st + h * RROWS * 32 + (wave & 3) * 16 * 32);
+        } else {
+            glds16(live ? wsrc + (long)(2 * s) * p.Np * 32 : p.zero, st + wave * 16 * 32);
+            glds16(live ? wsrc + (long)(2 * s + 1) * p.Np * 32 : p.zero, st + RROWS * 32 + wave * 16 * 32);
+        }
     };
 
     // ---- fragment addressing ---------------------------------------------------------------------------------
@@ -127,8 +140,14 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
         const bool klim1 = (p.cinp - cc * 32) <= 16;
         int tapoff = 0, dx = 0, tap = 0;                   // tapoff = dy*PW + dx of tap
         for (int pr = 0; pr < pairs; ++pr, ++s) {
-            if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // stages s+1, s+2 may still fly (+ the next chunk's patch DMAs when they were issued 1-2 steps ago)
+            if constexpr (BIGP) {
+                if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (pr == 0) issue_patch(cc + 1, (cc + 1) & 1);
@@ -143,7 +162,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
                     if (ks == 1 && klim1) break;           // channel tail <= 16: upper half of the chunk is all zeros
                     half8 wf[TN], xf[2];
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(wst + h * 128 * 32 + woff[j][ks]);
+                    for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(wst + h * RROWS * 32 + woff[j][ks]);
                     xf[0] = *reinterpret_cast<const half8*>(pbuf + q0 * 32 + (((ks * 2 + fj) ^ ((q0 >> 2) & 3)) << 3));
                     xf[1] = *reinterpret_cast<const half8*>(pbuf + q1 * 32 + (((ks * 2 + fj) ^ ((q1 >> 2) & 3)) << 3));
 #pragma unroll
@@ -192,25 +211,29 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     }
 }
 
-// Tile height: 16 rows when the halo patch fits the 640-pixel LDS buffer and the map tiles at least as well as with 8.
-int conv_patch_th(int kh, int kw, int OH) {
-    if ((16 + kh - 1) * (PTW + kw - 1) > PPIX) return 8;
-    const int pad16 = (OH + 15) / 16 * 16, pad8 = (OH + 7) / 8 * 8;
-    return pad16 <= pad8 ? 16 : 8;
-}
-
 // cout tile: 64 or 128, whichever pads Np less (ties -> 128)
 int conv_patch_bn(int Np) {
     const int p64 = (Np + 63) / 64 * 64, p128 = (Np + 127) / 128 * 128;
     return p64 < p128 ? 64 : 128;
 }
 
+// Tile height: 16 rows when the halo patch fits the LDS patch buffer (960 pixels for BN = 64, else 640) and the map
+// tiles at least as well as with 8 rows.
+int conv_patch_th(int kh, int kw, int OH, int bn) {
+    if (bn != 64) return 8;      // measured: the 64 px x 128 cout wave tile (204 VGPRs) loses to two 64 x 64 waves
+    const int cap = 960;
+    if ((16 + kh - 1) * (PTW + kw - 1) > cap) return 8;
+    const int pad16 = (OH + 15) / 16 * 16, pad8 = (OH + 7) / 8 * 8;
+    return pad16 * 100 <= pad8 * 120 ? 16 : 8;      // accept <= 20 % extra row padding for the denser wave tile
+}
+
 int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
     ConvParams p = pin;
     if (p.sh != 1 || p.sw != 1 || p.kh * p.kw < 5 || (p.cinp & 7) || (p.flags & F_PIXSHUF)) return VSE_E_INVAL;
-    if ((8 + p.kh - 1) * (PTW + p.kw - 1) > PPIX) return VSE_E_UNSUPPORTED;
-    const int th = conv_patch_th(p.kh, p.kw, p.OH);
+    if ((8 + p.kh - 1) * (PTW + p.kw - 1) > 640) return VSE_E_UNSUPPORTED;
     const int bn = conv_patch_bn(p.Np);
+    const int th = conv_patch_th(p.kh, p.kw, p.OH, bn);
+    const bool big = th == 16 && (16 + p.kh - 1) * (PTW + p.kw - 1) > 640;
     p.ntn = (unsigned)((p.Np + bn - 1) / bn);
     if ((p.flags & F_DOT1) && (th != 16 || p.ntn != 1 || (p.flags & F_RES) || !p.dotw || !p.dot_out)) return VSE_E_UNSUPPORTED;
     p.tiles_h = (p.OH + th - 1) / th;
@@ -218,9 +241,10 @@ int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
     const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w * p.ntn;
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
     const dim3 grid((unsigned)blocks), block(512);
-    if (th == 16 && bn == 64) hipLaunchKernelGGL((conv_patch_kernel<16, 64>), grid, block, 0, st, p);
-    else if (th == 16) hipLaunchKernelGGL((conv_patch_kernel<16, 128>), grid, block, 0, st, p);
-    else if (bn == 64) hipLaunchKernelGGL((conv_patch_kernel<8, 64>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((conv_patch_kernel<8, 128>), grid, block, 0, st, p);
+    if (big) hipLaunchKernelGGL((conv_patch_kernel<16, 64, true>), grid, block, 0, st, p);
+    else if (th == 16 && bn == 64) hipLaunchKernelGGL((conv_patch_kernel<16, 64, false>), grid, block, 0, st, p);
+    else if (th == 16) hipLaunchKernelGGL((conv_patch_kernel<16, 128, false>), grid, block, 0, st, p);
+    else if (bn == 64) hipLaunchKernelGGL((conv_patch_kernel<8, 64, false>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_patch_kernel<8, 128, false>), grid, block, 0, st, p);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }

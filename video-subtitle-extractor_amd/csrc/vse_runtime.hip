@@ -200,7 +200,8 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     const vse_op& o = p->ops[i];
     if (o.kind != OP_CONV) return 0;
     if (o.flags & F_PATCH)   // conv_patch_kernel<TH, BN> -> 1000*TH + BN
-        return 1000 * conv_patch_th(o.p[P_KH], o.p[P_KW], o.out.h) + conv_patch_bn(o.p[P_COUT]);
+        return 1000 * conv_patch_th(o.p[P_KH], o.p[P_KW], (o.flags & F_DOT1) ? o.out2.h : o.out.h, conv_patch_bn(o.p[P_COUT])) +
+               conv_patch_bn(o.p[P_COUT]);
     return conv_tile_bn(o.p[P_COUT]);
 }
 

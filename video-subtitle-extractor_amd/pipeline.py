@@ -69,7 +69,7 @@ class OcrPipeline:
         self.profile_sink = None              # list: when set, every net run is profiled per op and appended here
 
     def _run(self, net, x):
-        if self.profile_sink is not None:
+        if getattr(self, "profile_sink", None) is not None:
             self.profile_sink.append(net.profile(x))
         return net.run(x)
 
