@@ -48,6 +48,9 @@ def load_library(path=None):
     global _lib
     if _lib is not None:
         return _lib
+    # torch must be imported BEFORE libvse_hip.so: the torch wheel bundles its own libamdhip64; if ours (linked against
+    # /opt/rocm) initialises first, two HIP runtimes end up in the process and one of them sees no device
+    import torch  # noqa: F401
     path = path or LIB_PATH
     if not os.path.exists(path):
         raise VseError(f"{path} not found: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950) first; "
