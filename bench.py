@@ -220,8 +220,8 @@ def roofline(pipe, step, repeats=2):
                 a[2] += 1
         pipe.profile_sink = None
     bn, (tms, gmac, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
-    kname = {128: "conv_mfma_kernel<128, 128, 2, 2>", 64: "conv_mfma_kernel<256, 64, 4, 1>",
-             32: "conv_mfma_kernel<256, 32, 4, 1>", 8064: "conv_patch_kernel<8, 64, false>", 8128: "conv_patch_kernel<8, 128, false>",
+    kname = {128: "conv_mfma_kernel<128, 128, 2, 2, false>", 64: "conv_mfma_kernel<256, 64, 4, 1, false>",
+             32: "conv_mfma_kernel<256, 32, 4, 1, false>", 8064: "conv_patch_kernel<8, 64, false>", 8128: "conv_patch_kernel<8, 128, false>",
              16064: "conv_patch_kernel<16, 64, false>", 16128: "conv_patch_kernel<16, 128, false>",
              116064: "conv_patch_kernel<16, 64, true>"}[bn]
     achieved = 2.0 * gmac / tms          # GMAC/ms*2 = TFLOP/s

@@ -22,7 +22,7 @@
 #define STAGES 3       // LDS ring: tile k is consumed while tiles k+1 and k+2 are in flight
 #define ROWB 64        // bytes per LDS row (BK halfs, no padding: LDS-DMA writes are lane-linear)
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool UPS>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -56,11 +56,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     // l&3, i.e. logical k-vector kv = (l&3) ^ ((l>>4)&3)  (row>>2 & 3 == l>>4 & 3 because the 16-row base is 16-aligned)
     const int kv = (lane & 3) ^ ((lane >> 4) & 3);
     const int rsub = lane >> 2;
+    // Gather addressing is incremental: per row one base pointer (tap (0,0), channel 0) and two validity bitmasks
+    // (bit dy / bit dx set when that tap row / column is inside the image); per K step the thread computes ONE tap
+    // offset shared by its rows.  The nearest-upsampled input (UPS) keeps the explicit (y>>s, x>>s) form.
     int ih0[NA], iw0[NA];
     long pbase[NA];
+    const half_t* rowptr[NA];
+    unsigned rmask[NA], cmask[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         const long m = m0 + (j * 4 + wave) * 16 + rsub;
+        ih0[j] = 0; iw0[j] = 0; pbase[j] = 0; rowptr[j] = p.zero; rmask[j] = 0; cmask[j] = 0;
         if (m < p.M) {
             const int ow = (int)(m % p.OW);
             const long t = m / p.OW;
@@ -69,10 +75,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             ih0[j] = oh * p.sh - p.ph;
             iw0[j] = ow * p.sw - p.pw;
             pbase[j] = n * p.Hs * p.Ws;
-        } else {
+            if constexpr (!UPS) {
+                rowptr[j] = p.in + (pbase[j] + (long)ih0[j] * p.Ws + iw0[j]) * p.in_ld;
+                for (int d = 0; d < p.kh; ++d) rmask[j] |= (unsigned)(ih0[j] + d >= 0 && ih0[j] + d < p.H) << d;
+                for (int d = 0; d < p.kw; ++d) cmask[j] |= (unsigned)(iw0[j] + d >= 0 && iw0[j] + d < p.W) << d;
+            }
+        } else if constexpr (UPS) {
             ih0[j] = -(1 << 28);
-            iw0[j] = 0;
-            pbase[j] = 0;
         }
     }
     int kc = kv * 8, dy = 0, dx = 0;
@@ -81,30 +90,37 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         if (++dx == p.kw) { dx = 0; ++dy; }
     }
     const half_t* wrow[NB];
-    bool wok[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int n = n0 + (j * 4 + wave) * 16 + rsub;
-        wok[j] = ((j * 4 + wave) * 16 + rsub < BN) && (n < p.Np);
-        wrow[j] = p.w + (long)n * 64 + kv * 8;        // weights are tiled [Kp/64][Np][64]
+        const bool ok = ((j * 4 + wave) * 16 + rsub < BN) && (n < p.Np);
+        wrow[j] = ok ? p.w + (long)n * 64 + kv * 8 : nullptr;        // weights are tiled [Kp/64][Np][64]
     }
+    const long wstep = (long)p.Np * 64;
 
     // issue the LDS-DMAs of K tile `kt` into ring slot `st` (always exactly LPT VMEM ops per thread)
     auto issue = [&](int kt, int st) {
         half_t* base = lds + st * STAGE_HALFS;
+        if constexpr (UPS) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int ih = ih0[j] + dy, iw = iw0[j] + dx;
-            const bool ok = (dy < p.kh) && (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.W);
-            const half_t* src = p.zero;
-            if (ok) src = p.in + (pbase[j] + (long)(ih >> p.inshift) * p.Ws + (iw >> p.inshift)) * p.in_ld + kc;
-            glds16(src, base + (j * 4 + wave) * 16 * BK);
-        }
+            for (int j = 0; j < NA; ++j) {
+                const int ih = ih0[j] + dy, iw = iw0[j] + dx;
+                const bool ok = (dy < p.kh) && (ih >= 0) && (ih < p.H) && (iw >= 0) && (iw < p.W);
+                const half_t* src = p.zero;
+                if (ok) src = p.in + (pbase[j] + (long)(ih >> p.inshift) * p.Ws + (iw >> p.inshift)) * p.in_ld + kc;
+                glds16(src, base + (j * 4 + wave) * 16 * BK);
+            }
+        } else {
+            const long toff = (long)(dy * p.Ws + dx) * p.in_ld + kc;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const half_t* src = wok[j] ? wrow[j] + (long)(kt >> 1) * p.Np * 64 + (kt & 1) * 32 : p.zero;
-            glds16(src, base + BM * BK + (j * 4 + wave) * 16 * BK);
+            for (int j = 0; j < NA; ++j) {
+                const bool ok = (rmask[j] >> dy) & (cmask[j] >> dx) & 1u;     // bits >= kh / kw are never set
+                glds16(ok ? rowptr[j] + toff : p.zero, base + (j * 4 + wave) * 16 * BK);
+            }
         }
+        const long woff = (long)(kt >> 1) * wstep + (kt & 1) * 32;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) glds16(wrow[j] ? wrow[j] + woff : p.zero, base + BM * BK + (j * 4 + wave) * 16 * BK);
         kc += BK;
         while (kc >= p.cinp) {
             kc -= p.cinp;
@@ -259,8 +275,14 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     const unsigned long long tiles = (unsigned long long)((p.M + bm - 1) / bm) * p.ntn;
     if (tiles == 0 || tiles > 0x7fffffffull) return VSE_E_INVAL;
     dim3 grid((unsigned)tiles);
-    if (bn == 128) hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 2, 2>), grid, block, 0, st, p);
-    else if (bn == 64) hipLaunchKernelGGL((conv_mfma_kernel<256, 64, 4, 1>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((conv_mfma_kernel<256, 32, 4, 1>), grid, block, 0, st, p);
+    if (a.inshift) {
+        if (bn == 128) hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 2, 2, true>), grid, block, 0, st, p);
+        else if (bn == 64) hipLaunchKernelGGL((conv_mfma_kernel<256, 64, 4, 1, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<256, 32, 4, 1, true>), grid, block, 0, st, p);
+    } else {
+        if (bn == 128) hipLaunchKernelGGL((conv_mfma_kernel<128, 128, 2, 2, false>), grid, block, 0, st, p);
+        else if (bn == 64) hipLaunchKernelGGL((conv_mfma_kernel<256, 64, 4, 1, false>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<256, 32, 4, 1, false>), grid, block, 0, st, p);
+    }
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }
