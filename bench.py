@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--boxes", default="gt", choices=["gt", "db"])
     ap.add_argument("--bucket", type=int, default=256, help="rec width bucket (px)")
     ap.add_argument("--batch-round", type=int, default=4)
+    ap.add_argument("--rec-streams", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -137,6 +138,7 @@ def main():
     pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="bucketed", bucket=args.bucket,
                                 batch_round=args.batch_round)
 
+    pipe.rec_streams = args.rec_streams
     frames_np, truth = synth.make_frames(args.batch, args.height, args.width, seed=100 + rank, return_truth=True)
     frames = torch.from_numpy(frames_np).to(ctx.tdev)          # inputs resident in HBM before the timed region
     quads = gt_quads(truth)
@@ -218,6 +220,7 @@ def roofline(pipe, step, repeats=2):
                 a[0] += float(ms[k])
                 a[1] += float(prog.op_gmacs[k])
                 a[2] += 1
+        pipe_last_sink = pipe.profile_sink
         pipe.profile_sink = None
     bn, (tms, gmac, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
     kname = {128: "conv_mfma_kernel<128, 128, 2, 2, false>", 64: "conv_mfma_kernel<256, 64, 4, 1, false>",
@@ -232,6 +235,12 @@ def roofline(pipe, step, repeats=2):
         if kname in tj.get("kernels", {}):
             traffic = tj["kernels"][kname]["hbm_bytes_per_launch"]
     all_ms = sum(v[0] for v in agg.values())
+    # per-net totals of the last profiled step (diagnostics on stderr)
+    per_net = {}
+    for ms, prog, _v in pipe_last_sink:
+        key = "det" if prog.outputs and prog.outputs[0]["kind"] == "map" else f"rec[{prog.in_shape[0]}x{prog.in_shape[2]}]"
+        per_net[key] = per_net.get(key, 0.0) + float(ms.sum())
+    print("[bench] per-net GPU ms (profiled step):", {k: round(v, 2) for k, v in per_net.items()}, file=sys.stderr)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_source": "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,

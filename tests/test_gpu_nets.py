@@ -6,7 +6,8 @@ from oracle import ir_emul, net_ref
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("V4_ch_det", (2, 3, 96, 160)), ("V4_ch_det_fast", (2, 3, 96, 160)), ("V3_ch_det_fast", (1, 3, 96, 160)),
+CASES = [("V4_ch_det", (2, 3, 96, 160)), ("V4_ch_det", (1, 3, 128, 256)),    # 2nd shape: 9x9 convs on 16-row big-patch tiles
+         ("V4_ch_det", (1, 3, 160, 224)),                                        # ragged tile edges in both directions ("V4_ch_det_fast", (2, 3, 96, 160)), ("V3_ch_det_fast", (1, 3, 96, 160)),
          ("V2_ch_det", (1, 3, 64, 96)), ("V4_ch_rec", (3, 3, 48, 200)), ("V4_ch_rec_fast", (2, 3, 48, 320)),
          ("V4_en_rec_fast", (6, 3, 48, 352)), ("V3_ch_rec_fast", (2, 3, 48, 160)), ("V3_latin_rec_fast", (2, 3, 48, 160)),
          ("V2_ch_rec", (2, 3, 32, 128))]
@@ -75,6 +76,14 @@ CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (32, 32, (1, 7), (1, 1), (0, 3), 12, 20, 2), (128, 160, (3, 3), (1, 1), (1, 1), 20, 24, 1),
     (72, 224, (3, 3), (2, 1), (1, 1), 11, 19, 2), (24, 8, (5, 5), (1, 2), (2, 2), 15, 15, 1),
     (256, 1000, (1, 1), (1, 1), (0, 0), 1, 40, 2), (8, 136, (1, 3), (1, 1), (0, 1), 1, 50, 4),
+    # LDS-resident-patch kernel (stride 1, long K, maps that tile into 8x32 / 16x32 patches)
+    (64, 64, (9, 9), (1, 1), (4, 4), 32, 64, 2),       # conv_patch_kernel<16,64,true>  (960-pixel patch)
+    (64, 64, (9, 9), (1, 1), (4, 4), 40, 70, 1),       # <8,64>: 40 rows pad to 48 (> 20 %) and a ragged right edge
+    (128, 160, (3, 3), (1, 1), (1, 1), 16, 64, 2),     # 160 couts -> three 64-cout tiles, one half empty
+    (128, 128, (3, 3), (1, 1), (1, 1), 24, 96, 1),     # <8,128>
+    (72, 64, (3, 3), (1, 1), (1, 1), 32, 64, 1),       # channel tail (72 = 2*32 + 8), <16,64,false>
+    (32, 32, (7, 7), (1, 1), (3, 3), 16, 96, 2),       # 49 taps (odd): last step has a single tap
+    (96, 40, (7, 1), (1, 1), (3, 0), 16, 64, 1), (96, 40, (1, 7), (1, 1), (0, 3), 16, 64, 1),
 ]
 
 

@@ -31,7 +31,7 @@ def main():
     xt = torch.from_numpy(x8.astype(np.float16)).cuda()
     outs = net.run(xt)
     torch.cuda.synchronize()
-    ws = net.ws.cpu().numpy()
+    ws = net.ws[(n, h, w)].cpu().numpy()
     bad = 0
     for k, r in enumerate(prog.ops):
         v = r["out"]

@@ -181,14 +181,13 @@ class Context:
             arr[i].resized_w, arr[i].rotate = c["resized_w"], c["rotate"]
             mw, mh = max(mw, c["crop_w"]), max(mh, c["crop_h"])
         nbytes = self.lib.vse_rec_preprocess_scratch_bytes(n, mw, mh)
-        if getattr(self, "_crop_ws", None) is None or self._crop_ws.numel() < nbytes:
-            self._crop_ws = t.empty(nbytes, dtype=t.uint8, device=self.tdev)
+        crop_ws = t.empty(nbytes, dtype=t.uint8, device=self.tdev)     # per call: groups may run on different streams
         out = t.empty((n, rec_h, rec_w, 8), dtype=t.float16, device=self.tdev)
         nf, h, w, _ = frames_u8.shape
         _check(self.lib.vse_rec_preprocess(self.handle, C.c_void_p(frames_u8.data_ptr()), nf, h, w,
                                            frames_u8.stride(1), frames_u8.stride(0), arr, n,
                                            C.c_void_p(out.data_ptr()), rec_h, rec_w,
-                                           C.c_void_p(self._crop_ws.data_ptr()), nbytes, self.stream()),
+                                           C.c_void_p(crop_ws.data_ptr()), nbytes, self.stream()),
                "vse_rec_preprocess")
         return out
 
@@ -219,7 +218,7 @@ class Net:
         self.plans = {}
         self.wid = None
         self.wbytes = 0
-        self.ws = None
+        self.ws = {}          # one workspace per plan: plans of one net may run concurrently on different streams
 
     def program(self, n, h, w):
         key = (n, h, w)
@@ -253,8 +252,8 @@ class Net:
             self.plans[key][1] = h
             handle = h
         t = self.ctx.torch
-        if self.ws is None or self.ws.numel() < prog.ws_bytes:
-            self.ws = t.zeros(max(prog.ws_bytes, 256), dtype=t.uint8, device=self.ctx.tdev)
+        if key not in self.ws:
+            self.ws[key] = t.zeros(max(prog.ws_bytes, 256), dtype=t.uint8, device=self.ctx.tdev)
         return prog, handle
 
     def _ext(self, prog, x):
@@ -272,8 +271,8 @@ class Net:
         self.program(n, h, w)
         prog, handle = self._ensure((n, h, w))
         outs, ptrs = self._ext(prog, x)
-        _check(self.ctx.lib.vse_plan_run(handle, C.c_void_p(self.ws.data_ptr()), ptrs, len(ptrs), self.ctx.stream()),
-               "vse_plan_run")
+        _check(self.ctx.lib.vse_plan_run(handle, C.c_void_p(self.ws[(n, h, w)].data_ptr()), ptrs, len(ptrs),
+                                         self.ctx.stream()), "vse_plan_run")
         return outs
 
     def profile(self, x):
@@ -283,7 +282,7 @@ class Net:
         prog, handle = self._ensure((n, h, w))
         outs, ptrs = self._ext(prog, x)
         ms = (C.c_float * len(prog.ops))()
-        _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(self.ws.data_ptr()), ptrs, len(ptrs),
+        _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(self.ws[(n, h, w)].data_ptr()), ptrs, len(ptrs),
                                              self.ctx.stream(), ms), "vse_plan_profile")
         variants = [self.ctx.lib.vse_plan_op_variant(handle, i) for i in range(len(prog.ops))]
         return np.array(ms[:], dtype=np.float32), prog, variants

@@ -67,6 +67,7 @@ class OcrPipeline:
         self.batch_round = batch_round        # bucketed mode: pad group sizes to a multiple (bounds the plan cache)
         self.max_rec_batch = max_rec_batch
         self.profile_sink = None              # list: when set, every net run is profiled per op and appended here
+        self.rec_streams = 1                  # >1: width groups of the recogniser run on that many side streams
 
     def _run(self, net, x):
         if getattr(self, "profile_sink", None) is not None:
@@ -138,7 +139,19 @@ class OcrPipeline:
         if not specs:
             return results
         pending = []
-        for idx, img_w in self._groups(specs):
+        groups = self._groups(specs)
+        # width groups are independent: run them on side streams so the latency-bound launches of small groups overlap
+        nstreams = min(len(groups), getattr(self, "rec_streams", 1))
+        main = t.cuda.current_stream(self.ctx.tdev)
+        if nstreams > 1:
+            if len(getattr(self, "_streams", [])) < nstreams:
+                self._streams = [t.cuda.Stream(device=self.ctx.tdev) for _ in range(nstreams)]
+            for st in self._streams[:nstreams]:
+                st.wait_stream(main)
+        for gi, (idx, img_w) in enumerate(groups):
+            side = self._streams[gi % nstreams] if nstreams > 1 else None
+            if side is not None:
+                t.cuda.set_stream(side)
             crops = []
             for i in idx:
                 s = specs[i]
@@ -152,6 +165,10 @@ class OcrPipeline:
             idx_maxp = self._run(self.rec, x)[-1]          # [B,1,T,2]
             oi, ol, oc = self.ctx.ctc_collapse(idx_maxp)
             pending.append((idx, oi, ol, oc))
+        if nstreams > 1:
+            t.cuda.set_stream(main)
+            for st in self._streams[:nstreams]:
+                main.wait_stream(st)
         for idx, oi, ol, oc in pending:                      # one sync per group at the end
             oi, ol, oc = oi.cpu().numpy(), ol.cpu().numpy(), oc.cpu().numpy()
             for k, i in enumerate(idx):
