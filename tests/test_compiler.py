@@ -72,7 +72,7 @@ def test_kernel_selection_and_head_fusion_at_full_size():
     desc, w = net_ref.get_weights("V4_ch_det")
     prog = compiler.compile_model(desc, w, 1, 544, 960)
     flags = [int(o["flags"]) for o in prog.ops if int(o["kind"]) == ir.OP_CONV]
-    assert sum(bool(f & ir.F_PATCH) for f in flags) >= 25
+    assert sum(bool(f & ir.F_PATCH) for f in flags) >= 20
     assert sum(bool(f & ir.F_DOT1) for f in flags) == 1 and sum(bool(f & ir.F_SRC2) for f in flags) == 1
     assert not any(int(o["kind"]) == ir.OP_RESIZE and int(o["out"]["h"]) == 544 for o in prog.ops)
     assert abs(prog.gmacs - 194.703) < 0.05                      # 194.70 GMAC per 544x960 frame
