@@ -93,3 +93,32 @@ def test_drop_in_call_sites(ctx):
     assert len(e_boxes) == 0 and len(e_res) == 0
     e_dt, _ = sd.detect_subtitle(blank)
     assert e_dt.shape == (0, 4, 2) and e_dt.tolist() == []
+
+
+def test_accurate_mode_selector_on_engine(ctx):
+    """a13 end to end: batched detector + on-demand OCR drive the reference's start/end-of-subtitle automaton; the
+    batched selector and the statement-by-statement oracle loop agree when fed by the same engine."""
+    import torch
+    from types import SimpleNamespace
+    from oracle import frame_loop_ref
+    from vse_amd import frame_select, shim, synth
+    shim.config.language, shim.config.mode, shim.config.allow_standin_weights = "en", "fast", True
+    h, w = 360, 640
+    lit = synth.make_frames(3, h, w, seed=4)
+    dark = np.full((h, w, 3), 40, np.uint8)
+    clip = [dark, dark, lit[0], lit[0], lit[0], dark, lit[1], lit[1], lit[2], lit[2], dark]
+    det = shim.TextDetector(SimpleNamespace(det_model_dir="V3_ch_det_fast", det_algorithm="DB"))
+    ocr = shim.OcrRecogniser()
+    ocr.recogniser = shim.PaddleOCR(det_model_dir="V3_ch_det_fast", rec_model_dir="V4_en_rec_fast", drop_score=0, lang="en")
+    area = SimpleNamespace(ymin=int(0.7 * h), ymax=h, xmin=0, xmax=w)
+
+    def detect_batch(frames):
+        dev = torch.from_numpy(np.stack(frames)).cuda()
+        return [np.asarray(b, np.float32).reshape(-1, 4, 2) for b in det.batch(dev)]
+    sel = frame_select.AccurateFrameSelector(detect_batch, ocr.predict, area, len(clip), 80, chunk=4)
+    tasks = sel.run(clip)
+    ref = frame_loop_ref.extract_frame_by_det(clip, len(clip), lambda f: detect_batch([f])[0], ocr.predict,
+                                              dict(ymin=area.ymin, ymax=area.ymax, xmin=area.xmin, xmax=area.xmax), 80)
+    assert [(t[0], t[1], t[2] is None) for t in tasks] == [(t[0], t[1], t[2] is None) for t in ref]
+    nos = [t[1] for t in tasks]
+    assert 3 in nos and 5 in nos and nos == sorted(nos)        # first subtitle spans frames 3..5
