@@ -55,3 +55,44 @@ def test_area_filter_matches_between_oracle_and_shim():
     assert not P.subtitle_area_keep((100, 500, 620, 700), 0.75, area)     # strict > 0.75
     assert not P.subtitle_area_keep((100, 500, 600, 700), 0.9, area)      # sticks out of the area (rate 0)
     assert not P.subtitle_area_keep((100, 500, 10, 50), 0.9, area)        # no intersection
+
+
+def test_model_selection_matrix_golden():
+    """shim.PaddleModelConfig vs the reference's backend/tools/paddle_model_config.py run over all 88 languages x
+    3 modes x accelerator on/off (tests/golden/make_model_config_golden.py), incl. its FileNotFoundError for 'kn'."""
+    from vse_amd import shim
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "model_config.json")))
+
+    class HA:
+        def __init__(self, acc):
+            self.acc = acc
+            self.onnx_providers = []
+
+        def has_accelerator(self):
+            return self.acc
+    old = (shim.config.language, shim.config.mode)
+    try:
+        for lang, mode, acc, det, rec, ver, shape, err in g["rows"]:
+            shim.config.language, shim.config.mode = lang, mode
+            if err is not None:
+                with pytest.raises(FileNotFoundError):
+                    shim.PaddleModelConfig(HA(acc))
+                continue
+            c = shim.PaddleModelConfig(HA(acc))
+            assert (c.DET_MODEL_PATH, c.REC_MODEL_PATH, c.MODEL_VERSION, c.REC_IMAGE_SHAPE) == (det, rec, ver, shape), (lang, mode, acc)
+    finally:
+        shim.config.language, shim.config.mode = old
+    assert len(g["rows"]) == 528
+
+
+def test_raw_subtitle_line_format():
+    from types import SimpleNamespace
+    from vse_amd import shim
+    boxes = [[(100, 850), (500, 850), (500, 900), (100, 900)], [(100, 10), (300, 10), (300, 40), (100, 40)]]
+    res = [("hello\u4e16\u754c", 0.9), ("logo", 0.99)]
+    area = SimpleNamespace(ymin=800, ymax=1000, xmin=50, xmax=1800)
+    out = shim.extract_subtitles(42, (boxes, res), area, rec_char_type="en")
+    assert out == ["00000042\t(100, 500, 850, 900)\thello\n"]          # CJK stripped for 'en', watermark outside
+    out = shim.extract_subtitles(7, (boxes, res), None, rec_char_type="ch")
+    assert out == ["00000007\t(100, 500, 850, 900)\thello\u4e16\u754c\n", "00000007\t(100, 300, 10, 40)\tlogo\n"]
+    assert shim.extract_subtitles(1, ([], []), area) == []

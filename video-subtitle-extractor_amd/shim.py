@@ -111,6 +111,11 @@ class PaddleModelConfig:
                 rec = 'devanagari_rec_fast'
             self.MODEL_VERSION = ver
             self.REC_IMAGE_SHAPE = '3,32,320' if ver == 'V2' else '3,48,320'
+            # the reference lists the chosen model directories here (paddle_model_config.py:100-106) and therefore
+            # raises FileNotFoundError for a language without any model (e.g. 'kn'); keep that error behaviour
+            for v, name in ((ver, rec), ('V4', det)):
+                if not self._exists(v, name):
+                    raise FileNotFoundError(f"no model {v}/{name} for language {lang!r}")
         self.DET_MODEL_PATH = f'V4_{det}'        # det path is computed while MODEL_VERSION == 'V4' (App. D)
         self.REC_MODEL_PATH = f'{ver}_{rec}'
 
@@ -319,3 +324,19 @@ def subtitle_area_keep(coordinate, prob, sub_area, deviation_rate=None, drop_sco
     a_area = (sub_area.xmax - sub_area.xmin) * (sub_area.ymax - sub_area.ymin)
     b_area = (xmax - xmin) * (ymax - ymin)
     return (a_area + b_area - inter) / a_area - 1 <= deviation_rate and prob > drop_score
+
+
+def extract_subtitles(frame_no, predict_result, sub_area=None, rec_char_type=None, deviation_rate=None, drop_score=None):
+    """Raw subtitle lines of one frame as extract_subtitles writes them (backend/tools/subtitle_ocr.py:20-85):
+    '%08d\t(xmin, xmax, ymin, ymax)\ttext\n' for every recognised line that passes the area / confidence filter
+    (all lines when no area is given); CJK ideographs are stripped first when the language is 'en' (:35-37)."""
+    import re
+    dt_box, rec_res = predict_result
+    lang = config.language if rec_char_type is None else rec_char_type
+    lines = []
+    for (text, prob), coordinate in zip(rec_res, get_coordinates(dt_box)):
+        if lang == 'en':
+            text = re.sub('[\u4e00-\u9fa5]', '', text)
+        if sub_area is None or subtitle_area_keep(coordinate, prob, sub_area, deviation_rate, drop_score):
+            lines.append(f'{str(frame_no).zfill(8)}\t{coordinate}\t{text}\n')
+    return lines
