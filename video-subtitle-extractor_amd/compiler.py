@@ -541,8 +541,10 @@ class Compiler:
         tp = taps + taps % 2
         full = np.zeros((npad, tp, c32), mat.dtype)
         full[:, :taps, :cinp] = mat[:, :taps * cinp].reshape(npad, taps, cinp)
-        m = full.reshape(npad, tp, c32 // 32, 32).transpose(2, 1, 0, 3)
-        return np.ascontiguousarray(m).astype(np.float16)
+        m = np.ascontiguousarray(full.reshape(npad, tp, c32 // 32, 32).transpose(2, 1, 0, 3)).astype(np.float16)
+        # PATCH_WPAD_STEPS = 4 zero steps (8 taps) after the stream: the kernel's DMA look-ahead runs past the last
+        # real step without a bounds test and must land on readable zeros
+        return np.concatenate([m.reshape(-1), np.zeros(8 * npad * 32, np.float16)])
 
     def lower_conv(self, i):
         op = self.ops[i]

@@ -22,6 +22,10 @@
 //   weights are packed [chunk][tap][Np][32] by the compiler for this kernel (F_PATCH) so the stream is sequential.
 #include "conv_common.h"
 
+#ifndef VSE_ABLATE
+#define VSE_ABLATE 0      // 1: no s_barrier  2: no fragment ds_reads  3: no weight/patch DMA  4: no MFMA   (timing experiments only)
+#endif
+
 #define PTW 32
 #define PRING 4
 
@@ -82,7 +86,11 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     // tap 0, waves 4-7 tap 1, rows 0..63 (1 DMA)
     const int wr = BIGP ? ((tid >> 2) & 63) : (tid >> 2);
     const bool wok = (wr < BN) && (n0 + wr < p.Np);
-    const half_t* wsrc = p.w + (long)(n0 + wr) * 32 + kv * 8;
+    // running DMA source of this thread: advanced by one step (two taps) per issue_w; the compiler appends
+    // PATCH_WPAD_STEPS zero steps to the packed stream, so the look-ahead past the last real step reads real zeros
+    // (no select in the loop); rows beyond the cout range park on the zero page and never move
+    const half_t* wptr = wok ? p.w + (long)(n0 + wr) * 32 + kv * 8 + (BIGP ? (long)(wave >> 2) * p.Np * 32 : 0) : p.zero;
+    const long winc = wok ? (long)p.Np * 64 : 0;
 
     auto issue_patch = [&](int cc, int buf) {
         half_t* base = patch0 + buf * PATCH_HALFS;
@@ -99,27 +107,26 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     };
     auto issue_w = [&](int s) {                            // ring stage = taps 2s, 2s+1 of the packed stream
         half_t* st = ring0 + (s & (PRING - 1)) * WSTAGE_HALFS;
-        const bool live = wok && s < total;
         if constexpr (BIGP) {
-            const int h = wave >> 2;
-            glds16(live ? wsrc + (long)(2 * s + h) * p.Np * 32 : p.zero, st + h * RROWS * 32 + (wave & 3) * 16 * 32);
+            glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
         } else {
-            glds16(live ? wsrc + (long)(2 * s) * p.Np * 32 : p.zero, st + wave * 16 * 32);
-            glds16(live ? wsrc + (long)(2 * s + 1) * p.Np * 32 : p.zero, st + RROWS * 32 + wave * 16 * 32);
+            glds16(wptr, st + wave * 16 * 32);
+            glds16(wptr + (wok ? (long)p.Np * 32 : 0), st + RROWS * 32 + wave * 16 * 32);
         }
+        wptr += winc;
     };
 
     // ---- fragment addressing ---------------------------------------------------------------------------------
     const int fx = lane & 31, fj = lane >> 5;
-    int woff[TN][2];
+    // byte offsets; the second k half of a chunk (k-vectors 2,3) sits at (offset ^ 32): slot' = (2*ks + fj) ^ swz
+    unsigned woffb[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int r = wco * (BN / WCO) + j * 32 + fx;
-            woff[j][ks] = r * 32 + (((ks * 2 + fj) ^ ((r >> 2) & 3)) << 3);
-        }
+    for (int j = 0; j < TN; ++j) {
+        const int r = wco * (BN / WCO) + j * 32 + fx;
+        woffb[j] = (unsigned)(r * 64 + ((fj ^ ((r >> 2) & 3)) << 4));
+    }
     const int qb0 = (2 * wpx) * PW + fx, qb1 = qb0 + PW;
+    const char* const ring_b = reinterpret_cast<const char*>(ring0);
 
     float16v acc[2][TN];
 #pragma unroll
@@ -148,28 +155,44 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
                 if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             }
+#if VSE_ABLATE != 1
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
+#if VSE_ABLATE != 3
             if (pr == 0) issue_patch(cc + 1, (cc + 1) & 1);
             issue_w(s + 3);
-            const half_t* wst = ring0 + (s & (PRING - 1)) * WSTAGE_HALFS;
+#endif
+            const unsigned wsb = (unsigned)(s & (PRING - 1)) * (WSTAGE_HALFS * 2);
+            const char* const pb = reinterpret_cast<const char*>(pbuf);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (h == 1 && tap >= taps) break;          // odd tap count: the appended zero-weight tap does no work
-                const int q0 = qb0 + tapoff, q1 = qb1 + tapoff;
+                const unsigned q0 = (unsigned)(qb0 + tapoff), q1 = (unsigned)(qb1 + tapoff);
+                const unsigned a0 = (q0 << 6) + ((fj ^ ((q0 >> 2) & 3)) << 4), a1 = (q1 << 6) + ((fj ^ ((q1 >> 2) & 3)) << 4);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     if (ks == 1 && klim1) break;           // channel tail <= 16: upper half of the chunk is all zeros
                     half8 wf[TN], xf[2];
+#if VSE_ABLATE == 2
+                    for (int j = 0; j < TN; ++j) for (int e = 0; e < 8; ++e) wf[j][e] = (half_t)(float)(q0 + e + j);
+                    for (int e = 0; e < 8; ++e) { xf[0][e] = (half_t)(float)(q1 + e); xf[1][e] = (half_t)(float)(q0 - e); }
+#else
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const half8*>(wst + h * RROWS * 32 + woff[j][ks]);
-                    xf[0] = *reinterpret_cast<const half8*>(pbuf + q0 * 32 + (((ks * 2 + fj) ^ ((q0 >> 2) & 3)) << 3));
-                    xf[1] = *reinterpret_cast<const half8*>(pbuf + q1 * 32 + (((ks * 2 + fj) ^ ((q1 >> 2) & 3)) << 3));
+                    for (int j = 0; j < TN; ++j)
+                        wf[j] = *reinterpret_cast<const half8*>(ring_b + wsb + h * (RROWS * 64) + (woffb[j] ^ (ks << 5)));
+                    xf[0] = *reinterpret_cast<const half8*>(pb + (a0 ^ (ks << 5)));
+                    xf[1] = *reinterpret_cast<const half8*>(pb + (a1 ^ (ks << 5)));
+#endif
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
+#if VSE_ABLATE == 4
+                            { acc[i][j][0] += (float)wf[j][0] * (float)xf[i][0]; asm volatile("" : "+v"(acc[i][j][0])); }
+#else
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+#endif
                 }
                 if (++tap < taps) {
                     if (++dx == p.kw) { dx = 0; tapoff += PW - p.kw + 1; } else { ++tapoff; }
