@@ -130,8 +130,10 @@ class Compiler:
     def __init__(self, desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True,
                  store=None, reuse=True):
         self.desc = desc
-        self.W = weights
-        self.ops = desc["ops"]
+        self.W = dict(weights)
+        self.ops = list(desc["ops"])
+        self.merged_gmac_credit = {}          # merged conv weight name -> algorithmic MAC factor of the original branches
+        self._merge_parallel_convs()
         self.N, self.H, self.Wd = batch, height, width
         self.fetch_cols = tuple(fetch_cols)
         self.want_probs = want_probs
@@ -156,6 +158,96 @@ class Compiler:
                     self.consumers.setdefault(n, []).append(i)
         self._mark_live()
         self._plan_concats()
+
+    # -------------------------------------------------------------------------------------------- graph rewrite
+    def _merge_parallel_convs(self):
+        """Re-parameterisation: conv_a(T) + conv_b(T) (both stride 1, 'same' padding, own bias, no activation in
+        between) == ONE conv with the two kernels embedded, centred, in a common (max kh) x (max kw) window and the
+        biases added.  PP-OCRv4's IntraCL blocks sum a k x k, a k x 1 and a 1 x k conv of the same tensor: three
+        launches + two adds become one k x k conv (the k x 1 / 1 x k taps ride along for free on the matrix cores).
+        Exact in real arithmetic; applied repeatedly until nothing matches."""
+        changed = True
+        while changed:
+            changed = False
+            prod, cons = {}, {}
+            for i, op in enumerate(self.ops):
+                for outs in op["out"].values():
+                    for o in outs:
+                        prod.setdefault(o, i)
+                for ins in op["in"].values():
+                    for n in ins:
+                        cons.setdefault(n, []).append(i)
+
+            def branch(name):
+                """name = output of [conv2d -> elementwise_add(bias)] with single consumers -> (i_conv, i_bias) or None."""
+                ib = prod.get(name)
+                if ib is None or self.ops[ib]["type"] != "elementwise_add" or len(cons.get(name, [])) != 1:
+                    return None
+                b = self.ops[ib]
+                y = b["in"]["Y"][0]
+                if y not in self.W or b["attrs"].get("axis", -1) != 1:
+                    return None
+                ic = prod.get(b["in"]["X"][0])
+                if ic is None or self.ops[ic]["type"] != "conv2d" or len(cons.get(b["in"]["X"][0], [])) != 1:
+                    return None
+                c = self.ops[ic]
+                a = c["attrs"]
+                w = self.W[c["in"]["Filter"][0]]
+                pads = a["paddings"]
+                if list(a["strides"]) != [1, 1] or a.get("groups", 1) != 1 or len(pads) != 2:
+                    return None
+                if w.shape[2] % 2 == 0 or w.shape[3] % 2 == 0 or pads[0] != w.shape[2] // 2 or pads[1] != w.shape[3] // 2:
+                    return None
+                return ic, ib
+
+            for i, op in enumerate(self.ops):
+                if op["type"] != "elementwise_add" or op["attrs"].get("axis", -1) not in (-1,):
+                    continue
+                xa, xb = op["in"]["X"][0], op["in"]["Y"][0]
+                if xa in self.W or xb in self.W:
+                    continue
+                ba, bb = branch(xa), branch(xb)
+                if ba is None or bb is None:
+                    continue
+                ca, cb = self.ops[ba[0]], self.ops[bb[0]]
+                if ca["in"]["Input"][0] != cb["in"]["Input"][0]:
+                    continue
+                wa, wb = self.W[ca["in"]["Filter"][0]], self.W[cb["in"]["Filter"][0]]
+                if wa.shape[:2] != wb.shape[:2]:
+                    continue
+                kh, kw = max(wa.shape[2], wb.shape[2]), max(wa.shape[3], wb.shape[3])
+                wm = np.zeros(wa.shape[:2] + (kh, kw), np.float64)
+                for w_ in (wa, wb):
+                    oy, ox = (kh - w_.shape[2]) // 2, (kw - w_.shape[3]) // 2
+                    wm[:, :, oy:oy + w_.shape[2], ox:ox + w_.shape[3]] += w_
+                wname = ca["in"]["Filter"][0] + "+" + cb["in"]["Filter"][0]
+                bname = self.ops[ba[1]]["in"]["Y"][0] + "+" + self.ops[bb[1]]["in"]["Y"][0]
+                self.W[wname] = wm.astype(np.float32)
+                self.W[bname] = (self.W[self.ops[ba[1]]["in"]["Y"][0]].astype(np.float64) +
+                                 self.W[self.ops[bb[1]]["in"]["Y"][0]].astype(np.float64)).astype(np.float32)
+                # algorithmic MACs stay those of the ORIGINAL branches (the roofline counts the reference's work)
+                taps = lambda n, w_: self.merged_gmac_credit.get(n, w_.shape[2] * w_.shape[3])
+                self.merged_gmac_credit[wname] = taps(ca["in"]["Filter"][0], wa) + taps(cb["in"]["Filter"][0], wb)
+                out = op["out"]["Out"][0]
+                mid = out + ":merged_conv"
+                conv = {"type": "conv2d", "in": {"Input": [ca["in"]["Input"][0]], "Filter": [wname]},
+                        "out": {"Output": [mid]},
+                        "attrs": {"strides": [1, 1], "paddings": [kh // 2, kw // 2], "dilations": [1, 1], "groups": 1}}
+                bias = {"type": "elementwise_add", "in": {"X": [mid], "Y": [bname]}, "out": {"Out": [out]},
+                        "attrs": {"axis": 1}}
+                drop = {ba[0], ba[1], bb[0], bb[1], i}
+                first = min(drop)
+                new_ops = []
+                for k, o in enumerate(self.ops):
+                    if k == first:
+                        new_ops += [conv, bias]
+                    if k not in drop:
+                        new_ops.append(o)
+                # the merged conv must come after its input is produced: `first` is the earlier branch conv, whose
+                # input precedes it already
+                self.ops = new_ops
+                changed = True
+                break
 
     # -------------------------------------------------------------------------------------------- helpers
     def _mark_live(self):
@@ -671,7 +763,7 @@ class Compiler:
                      ir.P_INSHIFT: inv_main.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span, ir.P_IN2SHIFT: in2shift},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                      ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
-        self.add_gmacs(inv.n * oh * ow * cin * cout * kh * kw / 1e9)
+        self.add_gmacs(inv.n * oh * ow * cin * cout * self.merged_gmac_credit.get(wname, kh * kw) / 1e9)
         self.env[ep["out_name"]] = out
 
     def lower_dwconv(self, i, inv, w, sh, sw, ph, pw):
