@@ -178,7 +178,7 @@ def main():
         n_lines = sum(len(q) for q in quads)
         total_frames = world * args.batch * args.steps
         result = {
-            "metric": "OCR frames/sec (det+rec) @1080p", "value": round(total_frames / dt, 2), "unit": "frames/s",
+            "metric": f"OCR frames/sec (det+rec) @{args.height}p", "value": round(total_frames / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
