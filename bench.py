@@ -202,6 +202,17 @@ def main():
     return result
 
 
+def variant_kernel_name(code):
+    """vse_plan_op_variant() code -> the kernel instantiation rocprofv3 reports (see csrc/vse_runtime.hip)."""
+    code = int(code)
+    tiles = {128: "128, 128, 2, 2", 64: "256, 64, 4, 1", 32: "256, 32, 4, 1"}
+    if code >= 200000:
+        return f"conv_gemm_kernel<{tiles[code % 1000]}, {(code // 1000) % 10}>"
+    if code >= 1000 and code % 1000 in (64, 128) and (code // 1000) % 100 in (8, 16):
+        return f"conv_patch_kernel<{(code // 1000) % 100}, {code % 1000}, {'true' if code >= 100000 else 'false'}>"
+    return f"conv_mfma_kernel<{tiles[code % 1000]}, {'true' if code >= 10000 else 'false'}>"
+
+
 def roofline(pipe, step, repeats=2):
     """Dominant kernel = the conv_mfma_kernel instantiation with the largest total time over one whole step
     (detector + every recogniser launch).  Every op of every plan is bracketed by HIP events recorded on the stream
@@ -223,10 +234,7 @@ def roofline(pipe, step, repeats=2):
         pipe_last_sink = pipe.profile_sink
         pipe.profile_sink = None
     bn, (tms, gmac, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
-    kname = {128: "conv_mfma_kernel<128, 128, 2, 2, false>", 64: "conv_mfma_kernel<256, 64, 4, 1, false>",
-             32: "conv_mfma_kernel<256, 32, 4, 1, false>", 8064: "conv_patch_kernel<8, 64, false>", 8128: "conv_patch_kernel<8, 128, false>",
-             16064: "conv_patch_kernel<16, 64, false>", 16128: "conv_patch_kernel<16, 128, false>",
-             116064: "conv_patch_kernel<16, 64, true>"}[bn]
+    kname = variant_kernel_name(bn)
     achieved = 2.0 * gmac / tms          # GMAC/ms*2 = TFLOP/s
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")

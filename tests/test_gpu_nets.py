@@ -84,6 +84,15 @@ CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (72, 64, (3, 3), (1, 1), (1, 1), 32, 64, 1),       # channel tail (72 = 2*32 + 8), <16,64,false>
     (32, 32, (7, 7), (1, 1), (3, 3), 16, 96, 2),       # 49 taps (odd): last step has a single tap
     (96, 40, (7, 1), (1, 1), (3, 0), 16, 64, 1), (96, 40, (1, 7), (1, 1), (0, 3), 16, 64, 1),
+    # scalar-addressed implicit GEMM (conv_gemm_kernel: cin % 32 == 0, <= 31 taps); VSE_CONV_GEMM=0 sends the same
+    # cases through conv_mfma_kernel
+    (64, 128, (3, 3), (1, 1), (1, 1), 20, 36, 2),      # masked, BN=128, image seam inside a tile
+    (64, 64, (3, 3), (2, 2), (1, 1), 21, 37, 2),       # stride 2, BN=64, M tail
+    (96, 32, (1, 1), (1, 1), (0, 0), 13, 17, 3),       # 1x1 with a zero-padded last K tile (K=96 -> 128): masked, BN=32
+    (128, 256, (1, 1), (1, 1), (0, 0), 15, 23, 2),     # unmasked 1x1, two cout tiles
+    (160, 72, (5, 5), (1, 1), (2, 2), 10, 12, 1),      # 25 taps, map too small for the patch kernel
+    (32, 48, (2, 2), (2, 2), (0, 0), 18, 22, 2),       # even kernel, no padding
+    (64, 200, (1, 1), (2, 2), (0, 0), 19, 27, 1),      # strided 1x1, cout tail inside the second tile
 ]
 
 

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Single-layer timing of the conv kernels on the GPU, per conv_gemm_kernel tile configuration.
+
+usage: python tools/bench_conv.py [--cfgs 0,3,4,5,6,8] [--layers name,name...]
+Each layer is a two-op graph (1x1 stem lifting the 3-channel feed to `cin`, then the conv under test); the conv under
+test is timed with HIP events (vse_plan_profile), min of 3.  VSE_GEMM_CFG is read by the launcher at every launch."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from vse_amd import engine
+
+LAYERS = {  # name: cin, cout, k, stride, pad, h, w, n
+    "det_1x1_896_256": (896, 256, (1, 1), (1, 1), (0, 0), 136, 240, 64),
+    "det_1x1_1216_512": (1216, 512, (1, 1), (1, 1), (0, 0), 68, 120, 64),
+    "det_1x1_256_256": (256, 256, (1, 1), (1, 1), (0, 0), 136, 240, 64),
+    "det_1x1_1920_768": (1920, 768, (1, 1), (1, 1), (0, 0), 34, 60, 64),
+    "det_3x3_64_128": (64, 128, (3, 3), (1, 1), (1, 1), 272, 480, 64),
+    "det_3x3_64_64": (64, 64, (3, 3), (1, 1), (1, 1), 272, 480, 64),
+    "det_1x1_64_256": (64, 256, (1, 1), (1, 1), (0, 0), 272, 480, 64),
+    "rec_1x1_1216_512": (1216, 512, (1, 1), (1, 1), (0, 0), 12, 256, 32),
+    "rec_1x1_1920_768": (1920, 768, (1, 1), (1, 1), (0, 0), 6, 256, 32),
+    "rec_1x1_896_256": (896, 256, (1, 1), (1, 1), (0, 0), 12, 512, 32),
+    "rec_3x3_224_224": (224, 224, (3, 3), (1, 1), (1, 1), 3, 256, 32),
+    "rec_3x3_64_128": (64, 128, (3, 3), (1, 1), (1, 1), 24, 512, 32),
+}
+
+
+def graph(cin, cout, k, s, p):
+    desc = {"model": "unit", "ops": [
+        {"type": "feed", "in": {"X": ["feed"]}, "out": {"Out": ["x"]}, "attrs": {"col": 0}},
+        {"type": "conv2d", "in": {"Input": ["x"], "Filter": ["w0"]}, "out": {"Output": ["t0"]},
+         "attrs": {"strides": [1, 1], "paddings": [0, 0], "groups": 1}},
+        {"type": "conv2d", "in": {"Input": ["t0"], "Filter": ["w1"]}, "out": {"Output": ["t1"]},
+         "attrs": {"strides": list(s), "paddings": list(p), "groups": 1}},
+        {"type": "elementwise_add", "in": {"X": ["t1"], "Y": ["b1"]}, "out": {"Out": ["t2"]}, "attrs": {"axis": 1}},
+        {"type": "relu", "in": {"X": ["t2"]}, "out": {"Out": ["t3"]}, "attrs": {}},
+        {"type": "fetch", "in": {"X": ["t3"]}, "out": {"Out": ["fetch"]}, "attrs": {"col": 0}}],
+        "params": {"w0": {"dims": [cin, 3, 1, 1], "dtype": 5}, "w1": {"dims": [cout, cin, k[0], k[1]], "dtype": 5},
+                   "b1": {"dims": [cout], "dtype": 5}},
+        "var_shapes": {"t0": [-1, cin, -1, -1], "t1": [-1, cout, -1, -1]}}
+    rng = np.random.default_rng(1)
+    wts = {"w0": rng.standard_normal((cin, 3, 1, 1)).astype(np.float32),
+           "w1": (rng.standard_normal((cout, cin, k[0], k[1])) / np.sqrt(cin * k[0] * k[1])).astype(np.float32),
+           "b1": rng.standard_normal(cout).astype(np.float32) * 0.1}
+    return desc, wts
+
+
+def main():
+    cfgs = [c for c in (sys.argv[sys.argv.index("--cfgs") + 1].split(",") if "--cfgs" in sys.argv else ["0"])]
+    names = sys.argv[sys.argv.index("--layers") + 1].split(",") if "--layers" in sys.argv else list(LAYERS)
+    ctx = engine.Context(0)
+    for name in names:
+        cin, cout, k, s, p, h, w, n = LAYERS[name]
+        desc, wts = graph(cin, cout, k, s, p)
+        net = engine.Net(ctx, desc, wts, want_probs=False)
+        x = (torch.rand((n, h, w, 8), device="cuda") * 2 - 1).half()
+        x[..., 3:] = 0
+        oh = (h + 2 * p[0] - k[0]) // s[0] + 1
+        ow = (w + 2 * p[1] - k[1]) // s[1] + 1
+        flops = 2.0 * n * oh * ow * cout * cin * k[0] * k[1]
+        row = []
+        ref = None
+        for c in cfgs:
+            os.environ["VSE_GEMM_CFG"] = c
+            out = net.run(x)
+            torch.cuda.synchronize()
+            o = out[0].float()
+            if ref is None:
+                ref = o.clone()
+            same = bool(torch.equal(o, ref))
+            best = 1e9
+            for _ in range(3):
+                ms, prog, var = net.profile(x)
+                best = min(best, float(ms[1]))
+            row.append(f"cfg{c}: {best:7.3f} ms {flops / best / 1e9:6.0f} TF/s{'' if same else ' MISMATCH'}")
+        print(f"{name:20s} " + " | ".join(row), flush=True)
+        del net, x
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

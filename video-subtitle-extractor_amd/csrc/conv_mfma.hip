@@ -16,6 +16,7 @@
 //     -> activation2 -> fp16 (or fp32) store; 2x2/stride-2 transposed conv = same GEMM with a
 //     pixel-shuffle store.
 
+#include <stdlib.h>
 #include "conv_common.h"
 
 #define BK 32          // K elements per pipeline stage
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const int r = wn * WTN + j * 32 + frow;
+            const int r = wn * WTN + j * 32 + conv_wrow(frow);
             woff[j][ks] = BM * BK + r * BK + (((ks * 2 + fj) ^ ((r >> 2) & 3)) << 3);
         }
 
@@ -260,6 +261,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int mul = (a.flags & F_PIXSHUF) ? 2 : 1;
     if (a.out.h != p.OH * mul || a.out.w != p.OW * mul || a.out.n != a.in.n) return VSE_E_INVAL;
 
+    p.vec16 = ((reinterpret_cast<uintptr_t>(a.out.ptr) & 15) == 0 && ((long)a.out.ld * a.out.esize) % 16 == 0 &&
+               (!(a.flags & F_RES) || ((reinterpret_cast<uintptr_t>(a.res.ptr) & 15) == 0 && (a.res.ld & 7) == 0))) ? 1 : 0;
     p.dotw = a.dotw; p.dotb = a.dotb; p.dotact = a.dotact;
     p.dot_out = a.dot_out.ptr; p.dot_f32 = a.dot_out.esize == 4; p.dot_ld = a.dot_out.ld;
     p.in2 = reinterpret_cast<const half_t*>(a.in2.ptr); p.in2_ld = a.in2.ld; p.in2_shift = a.in2shift;
@@ -267,6 +270,12 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     if ((a.flags & (F_DOT1 | F_SRC2)) && !(a.flags & F_PATCH)) return VSE_E_UNSUPPORTED;
     if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
     if (a.Kp % 64) return VSE_E_INVAL;
+    if (!a.zero) return VSE_E_INVAL;
+    static const bool use_gemm = [] { const char* e = getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
+    if (use_gemm) {
+        const int rc = launch_conv_gemm(p, a.Kp, st);
+        if (rc != VSE_E_UNSUPPORTED) return rc;
+    }
     const int bn = conv_tile_bn(a.Np);
     dim3 block(256);
     const int bm = bn == 128 ? 128 : 256;

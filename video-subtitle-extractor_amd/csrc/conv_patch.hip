@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     unsigned woffb[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int r = wco * (BN / WCO) + j * 32 + fx;
+        const int r = wco * (BN / WCO) + j * 32 + conv_wrow(fx);
         woffb[j] = (unsigned)(r * 64 + ((fj ^ ((r >> 2) & 3)) << 4));
     }
     const int qb0 = (2 * wpx) * PW + fx, qb1 = qb0 + PW;

@@ -1,4 +1,5 @@
 // C-ABI runtime: context, weight arenas, plan creation and the op dispatch loop (see include/vse_hip.h).
+#include <stdlib.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -205,7 +206,12 @@ int vse_plan_op_variant(vse_plan* p, int i) {
         const bool big = th == 16 && (16 + o.p[P_KH] - 1) * (32 + o.p[P_KW] - 1) > 640;
         return (big ? 100000 : 0) + 1000 * th + bn;
     }
-    return conv_tile_bn(o.p[P_COUT]);
+    // conv_gemm_kernel<.., MASK> -> 200000 + 1000*MASK + BN; conv_mfma_kernel<.., UPS> -> 10000*UPS + BN
+    static const bool use_gemm = [] { const char* e = getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
+    const int mode = use_gemm ? conv_gemm_mode(o.p[P_KH], o.p[P_KW], o.p[P_SH], o.p[P_SW], o.p[P_PH], o.p[P_PW], o.p[P_CINP],
+                                               o.p[P_KTOT], o.p[P_INSHIFT], o.flags) : 0;
+    if (mode) return 200000 + (mode == 1 ? 1000 : 0) + conv_tile_bn(o.p[P_COUT]);
+    return (o.p[P_INSHIFT] ? 10000 : 0) + conv_tile_bn(o.p[P_COUT]);
 }
 
 int vse_plan_profile(vse_plan* p, void* ws, void* const* ext, int n_ext, void* stream, float* ms) {
