@@ -66,13 +66,14 @@ def test_weight_store_is_shape_independent():
 
 
 def test_kernel_selection_and_head_fusion_at_full_size():
-    """At the reference's det size the k x k stride-1 convs go to the LDS-resident-patch kernel, the DB head's
+    """At the reference's det size the k x k stride-1 convs with <= 64 couts go to the LDS-resident-patch kernel (wider
+    ones are faster on the 256-pixel implicit-GEMM tiles), the DB head's
     1x1->1-channel conv + sigmoid is folded into its producer (F_DOT1) and the upsample+concat in front of it is a
     virtual 2-source gather (F_SRC2): no 64-channel 544x960 tensor is written or copied."""
     desc, w = net_ref.get_weights("V4_ch_det")
     prog = compiler.compile_model(desc, w, 1, 544, 960)
     flags = [int(o["flags"]) for o in prog.ops if int(o["kind"]) == ir.OP_CONV]
-    assert sum(bool(f & ir.F_PATCH) for f in flags) >= 20
+    assert sum(bool(f & ir.F_PATCH) for f in flags) >= 10
     assert sum(bool(f & ir.F_DOT1) for f in flags) == 1 and sum(bool(f & ir.F_SRC2) for f in flags) == 1
     assert not any(int(o["kind"]) == ir.OP_RESIZE and int(o["out"]["h"]) == 544 for o in prog.ops)
     assert abs(prog.gmacs - 194.703) < 0.05                      # SURVEY §8(d): 194.70 GMAC per 544x960 frame
@@ -82,4 +83,4 @@ def test_kernel_selection_and_head_fusion_at_full_size():
         if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_PATCH:
             p = o["p"]
             assert (p[ir.P_SH], p[ir.P_SW]) == (1, 1) and p[ir.P_KH] * p[ir.P_KW] >= 5
-            assert (8 + p[ir.P_KH] - 1) * (32 + p[ir.P_KW] - 1) <= 640
+            assert (8 + p[ir.P_KH] - 1) * (32 + p[ir.P_KW] - 1) <= 640 and p[ir.P_COUT] <= 64

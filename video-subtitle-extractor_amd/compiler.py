@@ -25,6 +25,7 @@ import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
+import os
 import numpy as np
 
 from . import ir
@@ -124,6 +125,13 @@ _VIRTUAL = {"nearest_interp_v2", "flatten_contiguous_range", "transpose2", "resh
             "assign", "shape", "fill_constant", "fill_constant_batch_size_like", "scale_noop"}
 _ACTS = {"relu": ir.ACT_RELU, "hard_swish": ir.ACT_HSWISH, "swish": ir.ACT_SWISH, "sigmoid": ir.ACT_SIGMOID,
          "hard_sigmoid": ir.ACT_HSIGMOID}
+
+
+# shortest K (taps x channels) worth a conv_patch_kernel launch; VSE_PATCH_MINK overrides it for kernel experiments
+PATCH_MIN_K = int(os.environ.get("VSE_PATCH_MINK", "580"))
+# most couts sent to the patch kernel: with more than 64 couts the 256-pixel implicit-GEMM tiles (conv_gemm.hip,
+# activation tile fetched once for 128-256 couts) measure 15-50 % faster than the patch kernel on MI355X
+PATCH_MAX_COUT = int(os.environ.get("VSE_PATCH_MAXCOUT", "64"))
 
 
 class Compiler:
@@ -706,7 +714,7 @@ class Compiler:
         tile_eff = (oh * ow) / float(-(-oh // th) * th * -(-ow // 32) * 32)
         # (one block per CU: the fixed prologue/epilogue only amortises over a long enough K loop)
         patch = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 640
-                 and tile_eff >= 0.7 and kh * kw * cin >= 580 and self.use_patch)
+                 and tile_eff >= 0.7 and kh * kw * cin >= PATCH_MIN_K and coutp <= PATCH_MAX_COUT and self.use_patch)
         self.env_dims_tmp = (inv.n, oh, ow)
         if patch:
             flags |= ir.F_PATCH

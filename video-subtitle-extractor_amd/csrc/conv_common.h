@@ -20,6 +20,7 @@ struct ConvParams {
     float act_a, act_b, post_a, post_b;
     int flags, coutp;
     unsigned ntn;       // number of cout tiles
+    unsigned ntiles;    // persistent kernels: total output tiles
     int tiles_h, tiles_w;   // patch kernel: output tile grid per image
     const float* dotw;      // F_DOT1: per-cout weights of the fused 1-channel projection
     float dotb;
@@ -137,6 +138,7 @@ __device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const fl
 int launch_conv_patch(const ConvParams& p, int n_img, hipStream_t st);
 // scalar-addressed implicit GEMM (conv_gemm.hip): VSE_E_UNSUPPORTED when the layer is not eligible
 int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st);
+int conv_gemm_config(int Np, int cinp, long M);   // index into the tile-configuration table of conv_gemm.hip
 int conv_gemm_mode(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int Kp, int inshift, int flags);
 int conv_patch_th(int kh, int kw, int OH, int bn);
 int conv_patch_bn(int Np);

@@ -206,11 +206,15 @@ int vse_plan_op_variant(vse_plan* p, int i) {
         const bool big = th == 16 && (16 + o.p[P_KH] - 1) * (32 + o.p[P_KW] - 1) > 640;
         return (big ? 100000 : 0) + 1000 * th + bn;
     }
-    // conv_gemm_kernel<.., MASK> -> 200000 + 1000*MASK + BN; conv_mfma_kernel<.., UPS> -> 10000*UPS + BN
+    // conv_gemm_kernel configuration c, MASK m -> 200000 + 10*c + m; conv_mfma_kernel<.., UPS> -> 10000*UPS + BN
     static const bool use_gemm = [] { const char* e = getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
     const int mode = use_gemm ? conv_gemm_mode(o.p[P_KH], o.p[P_KW], o.p[P_SH], o.p[P_SW], o.p[P_PH], o.p[P_PW], o.p[P_CINP],
                                                o.p[P_KTOT], o.p[P_INSHIFT], o.flags) : 0;
-    if (mode) return 200000 + (mode == 1 ? 1000 : 0) + conv_tile_bn(o.p[P_COUT]);
+    if (mode) {
+        long m = (long)o.out.n * o.out.h * o.out.w;
+        if (o.flags & F_PIXSHUF) m /= 4;
+        return 200000 + 10 * conv_gemm_config(o.p[P_COUT], o.p[P_CINP], m) + (mode == 1 ? 1 : 0);
+    }
     return (o.p[P_INSHIFT] ? 10000 : 0) + conv_tile_bn(o.p[P_COUT]);
 }
 
