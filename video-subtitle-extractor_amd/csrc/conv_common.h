@@ -20,7 +20,6 @@ struct ConvParams {
     float act_a, act_b, post_a, post_b;
     int flags, coutp;
     unsigned ntn;       // number of cout tiles
-    unsigned ntiles;    // persistent kernels: total output tiles
     int tiles_h, tiles_w;   // patch kernel: output tile grid per image
     const float* dotw;      // F_DOT1: per-cout weights of the fused 1-channel projection
     float dotb;
@@ -28,6 +27,7 @@ struct ConvParams {
     void* dot_out;
     const half_t* in2;      // F_SRC2: channels [nv0*8, cinp) come from this tensor (own pixel grid / shift / stride)
     int in2_ld, in2_shift, in2_hs, in2_ws, nv0;
+    unsigned long long* trace;   // -DVSE_TRACE builds only: per-block phase stamps
     int vec16;              // output (and residual) rows allow 16-byte accesses at every 8-channel group
 };
 
@@ -40,6 +40,32 @@ __device__ __forceinline__ void glds16(const void* g, half_t* l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
+// Buffer-addressed LDS-DMA helpers (conv_gemm.hip): an offset with bit 31 set is out of range for the
+// 2 GiB descriptors these kernels build, so the DMA writes zeros.
+#define OOB 0x80000000u
+typedef __attribute__((address_space(3))) void* ldsv_t;
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N <= 16, "vmcnt literal");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
 // Accumulator tile layout.  v_mfma_f32_32x32x16_f16 leaves lane l with rows 8q + 4(l>>5) + e (q, e in 0..3; register
 // 4q + e) of column l & 31.  Columns are pixels; rows are couts THROUGH THE PERMUTATION "swap bits 2 and 3": the lane
 // that supplies weight row f of a 32-cout tile reads cout conv_wrow(f), so lane l ends up with the 16 couts
@@ -49,89 +75,143 @@ __device__ __forceinline__ void glds16(const void* g, half_t* l) {
 // ds_read_b128 bank-conflict free under both LDS swizzles (64-byte and 128-byte rows).
 __device__ __forceinline__ int conv_wrow(int f) { return (f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1); }
 
+// One activation code applied to N values: ONE uniform switch per call (per-element switches blow the epilogue up to
+// thousands of scalar branches).
+template <int N> __device__ __forceinline__ void vse_act_n(float (&v)[N], int code, float a, float b) {
+    switch (code) {
+        case ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.f);
+            break;
+        case ACT_HSWISH:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+            break;
+        case ACT_SWISH:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+            break;
+        case ACT_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+            break;
+        case ACT_HSIGMOID:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = fminf(fmaxf(v[e] * a + b, 0.f), 1.f);
+            break;
+        default: break;
+    }
+}
+
+// Per-cout epilogue constants (bias, F_DOT1 projection weights) are staged ONCE per block in LDS (conv_stage_consts;
+// visible after the K loop's first wait + barrier) and read back per accumulator
+// tile in the lane's register order.  Reading them from global memory inside the epilogue costs one dependent memory
+// round trip per 8 couts (s_memtime trace: 7 us of a 20 us tile on the detector's last layer); holding them in
+// registers across the K loop costs the occupancy the ring was sized for.
+// The staging itself is a 4-byte-per-lane LDS-DMA issued BEFORE the prologue DMAs: it is then the oldest entry of the
+// issuing wave's vmcnt queue, so every counted wait of the K loop covers it without changing a literal, no VGPR is
+// involved and the compiler adds no wait of its own.  Wave w stages couts 64w .. 64w+63 of the block's cout tile.
+__device__ __forceinline__ void conv_stage_consts(float* dst, const float* src, const half_t* zero, int n0, int bn, int Np,
+                                                  int wave, int lane) {
+    if (wave >= 0 && wave * 64 < bn) {
+        const int c = wave * 64 + lane;
+        const void* g = (c < bn && n0 + c < Np) ? (const void*)(src + n0 + c) : (const void*)zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + wave * 64), 4, 0, 0);
+    }
+}
+// `tab` = the staged table of this block's cout tile, `c` = first cout of the 32-cout accumulator tile inside it
+__device__ __forceinline__ void conv_epilogue_consts(const float* tab, int c, int lane, float (&out)[16]) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float* q = tab + c + g * 16 + (lane >> 5) * 8;
+        const float4v a = *reinterpret_cast<const float4v*>(q), b = *reinterpret_cast<const float4v*>(q + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { out[g * 8 + e] = a[e]; out[g * 8 + 4 + e] = b[e]; }
+    }
+}
+
 // Epilogue of one 32(cout) x 32(pixel) accumulator tile: lane l owns pixel (l & 31) — passed in as (m, n, oh, ow).
 //   + bias (BN folded) -> activation -> scalar affine -> (+ residual, optionally nearest-upsampled) -> activation2
 //   -> fp16 / fp32 store; F_PIXSHUF scatters a 2x2-stride-2 transposed conv.
-__device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const float16v& acc, long m, long n, int oh,
-                                                   int ow, int cbase, int lane) {
+__device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const float16v& acc, const float (&bias)[16], long m,
+                                                   long n, int oh, int ow, int cbase, int lane) {
     const bool pixshuf = p.flags & F_PIXSHUF;
     const bool has_res = p.flags & F_RES;
     long res_pix = m;
     if (has_res && p.resshift) res_pix = (n * p.res_hs + (oh >> p.resshift)) * p.res_ws + (ow >> p.resshift);
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = acc[e] + bias[e];
+    vse_act_n(v, p.act, p.act_a, p.act_b);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = v[e] * p.post_a + p.post_b;
+    long opix[2];
+    int oc[2];
+    bool live[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int c0 = cbase + g * 16 + (lane >> 5) * 8;
-        if (c0 >= p.Np) continue;
-        const float4v b0 = *reinterpret_cast<const float4v*>(p.bias + c0);
-        const float4v b1 = *reinterpret_cast<const float4v*>(p.bias + c0 + 4);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float x = acc[g * 8 + e] + (e < 4 ? b0[e & 3] : b1[e & 3]);
-            x = vse_act(x, p.act, p.act_a, p.act_b);
-            v[e] = x * p.post_a + p.post_b;
-        }
-        long opix = m;
-        int oc = c0;
+        live[g] = c0 < p.Np;
+        opix[g] = m;
+        oc[g] = c0;
         if (pixshuf) {                                   // coutp % 8 == 0: a run of 8 never straddles two quads
             const int quad = c0 / p.coutp;
-            oc = c0 - quad * p.coutp;
-            opix = (n * (2 * p.OH) + 2 * oh + (quad >> 1)) * (2L * p.OW) + 2 * ow + (quad & 1);
+            oc[g] = c0 - quad * p.coutp;
+            opix[g] = (n * (2 * p.OH) + 2 * oh + (quad >> 1)) * (2L * p.OW) + 2 * ow + (quad & 1);
         }
-        if (has_res) {
-            const half_t* rp = p.res + res_pix * p.res_ld + oc;
+    }
+    if (has_res) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (!live[g]) continue;
+            const half_t* rp = p.res + res_pix * p.res_ld + oc[g];
             if (p.vec16) {
                 const half8 r8 = *reinterpret_cast<const half8*>(rp);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)r8[e];
+                for (int e = 0; e < 8; ++e) v[g * 8 + e] += (float)r8[e];
             } else {
                 const half4 r0 = *reinterpret_cast<const half4*>(rp), r1 = *reinterpret_cast<const half4*>(rp + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += (float)r0[e]; v[e + 4] += (float)r1[e]; }
+                for (int e = 0; e < 4; ++e) { v[g * 8 + e] += (float)r0[e]; v[g * 8 + 4 + e] += (float)r1[e]; }
             }
         }
-        if (p.act2 != ACT_NONE) {
+    }
+    vse_act_n(v, p.act2, 0.f, 0.f);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = vse_act(v[e], p.act2, 0.f, 0.f);
-        }
+    for (int g = 0; g < 2; ++g) {
+        if (!live[g]) continue;
+        const float* w = v + g * 8;
         if (p.out_f32) {
-            float* op = reinterpret_cast<float*>(p.out) + opix * p.out_ld + oc;
-            *reinterpret_cast<float4v*>(op) = float4v{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<float4v*>(op + 4) = float4v{v[4], v[5], v[6], v[7]};
+            float* op = reinterpret_cast<float*>(p.out) + opix[g] * p.out_ld + oc[g];
+            *reinterpret_cast<float4v*>(op) = float4v{w[0], w[1], w[2], w[3]};
+            *reinterpret_cast<float4v*>(op + 4) = float4v{w[4], w[5], w[6], w[7]};
         } else {
-            half_t* op = reinterpret_cast<half_t*>(p.out) + opix * p.out_ld + oc;
+            half_t* op = reinterpret_cast<half_t*>(p.out) + opix[g] * p.out_ld + oc[g];
             if (p.vec16) {
-                *reinterpret_cast<half8*>(op) = half8{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3],
-                                                      (half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+                *reinterpret_cast<half8*>(op) = half8{(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3],
+                                                      (half_t)w[4], (half_t)w[5], (half_t)w[6], (half_t)w[7]};
             } else {
-                *reinterpret_cast<half4*>(op) = half4{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *reinterpret_cast<half4*>(op + 4) = half4{(half_t)v[4], (half_t)v[5], (half_t)v[6], (half_t)v[7]};
+                *reinterpret_cast<half4*>(op) = half4{(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3]};
+                *reinterpret_cast<half4*>(op + 4) = half4{(half_t)w[4], (half_t)w[5], (half_t)w[6], (half_t)w[7]};
             }
         }
     }
 }
 
 // F_DOT1 variant: returns this lane's partial  sum_c y[c] * dotw[c]  over the couts it owns in one accumulator tile
-// (y = the full epilogue value); nothing is stored.
-__device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const float16v& acc, int cbase, int lane) {
+// (y = the full epilogue value); nothing is stored.  Padded couts carry zero weights.
+__device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const float16v& acc, const float (&bias)[16],
+                                                   const float (&dotw)[16]) {
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = acc[e] + bias[e];
+    vse_act_n(v, p.act, p.act_a, p.act_b);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = v[e] * p.post_a + p.post_b;
+    vse_act_n(v, p.act2, 0.f, 0.f);
     float part = 0.f;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int c0 = cbase + g * 16 + (lane >> 5) * 8;
-        if (c0 >= p.Np) continue;
-#pragma unroll
-        for (int h4 = 0; h4 < 2; ++h4) {
-            const float4v b4 = *reinterpret_cast<const float4v*>(p.bias + c0 + 4 * h4);
-            const float4v w4 = *reinterpret_cast<const float4v*>(p.dotw + c0 + 4 * h4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = acc[g * 8 + h4 * 4 + e] + b4[e];
-                x = vse_act(x, p.act, p.act_a, p.act_b) * p.post_a + p.post_b;
-                x = vse_act(x, p.act2, 0.f, 0.f);
-                part += x * w4[e];
-            }
-        }
-    }
+    for (int e = 0; e < 16; ++e) part += v[e] * dotw[e];
     return part;
 }
 

@@ -20,39 +20,25 @@
 #include <type_traits>
 #include "conv_common.h"
 
-#define OOB 0x80000000u
 #ifndef VSE_ABLATE
 #define VSE_ABLATE 0      // 1: no s_barrier  2: no fragment ds_reads  3: no DMA in the loop  4: no MFMA  5: no epilogue   (timing experiments only)
 #endif
 
-typedef __attribute__((address_space(3))) void* ldsv_t;
-
-template <int N> __device__ __forceinline__ void wait_vm() {
-    static_assert(N >= 0 && N <= 16, "vmcnt literal");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if constexpr (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-}
-
 // BM x BN block tile (pixels x couts), WM x WN waves, BKT-deep K tiles in an ST-stage LDS ring.
 // MASK = 0: 1x1, no padding, K % 64 == 0 -> every (row, k) of a valid row is a real element, no tap mask.
 // MASK = 1: up to 31 taps, one validity bit per tap and row.
+// blocks per CU the LDS ring allows -> waves per SIMD the register allocation has to leave room for
+constexpr int gemm_waves_per_simd(int bm, int bn, int bkt, int st, int nw) {
+    const int rpi = 64 / (bkt / 8);
+    const int bnr = (bn + rpi * nw - 1) / (rpi * nw) * (rpi * nw);
+    const int blocks = (160 * 1024) / (st * (bm + bnr) * bkt * 2 + bn * 4);
+    const int w = blocks * nw / 4;
+    return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
+
 template <int BM, int BN, int WM, int WN, int BKT, int ST, int MASK>
-__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WM * WN, gemm_waves_per_simd(BM, BN, BKT, ST, WM * WN))
+void conv_gemm_kernel(const ConvParams p) {
     constexpr int NW = WM * WN;                 // waves per block
     constexpr int KV = BKT / 8;                 // 16-byte k-vectors per LDS row (4 or 8)
     constexpr int RPI = 64 / KV;                // tile rows one wave instruction (1 KiB) covers
@@ -68,9 +54,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvParam
     static_assert(BKT == 32 || BKT == 64, "BK");
     static_assert(ST >= 2 && ST <= 4 && (ST - 2) * LPT <= 16, "ring depth");
     static_assert(TM >= 1 && TN >= 1 && NA >= 1 && NB >= 1 && BM % (RPI * NW) == 0 && BNR % (RPI * NW) == 0, "tile shape");
-    static_assert(ST * STAGE_HALFS * 2 <= 160 * 1024, "LDS");
+    static_assert(ST * STAGE_HALFS * 2 + BN * 4 <= 160 * 1024, "LDS");
 
-    __shared__ __attribute__((aligned(16))) half_t lds[ST * STAGE_HALFS];
+    __shared__ __attribute__((aligned(16))) half_t lds[ST * STAGE_HALFS + BN * 2];   // ring + BN floats of bias
+    float* const sbias = reinterpret_cast<float*>(lds + ST * STAGE_HALFS);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -173,6 +160,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    conv_stage_consts(sbias, p.bias, p.zero, n0, BN, p.Np, wave, lane);
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
         if (s < p.nk) issue(s, s);
@@ -275,228 +263,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(const ConvParam
 #if VSE_ABLATE == 5
             if (acc[i][j][0] == 12345.678f)
 #endif
-            conv_epilogue_tile(p, acc[i][j], m, n, oh, ow, n0 + wn * WTN + j * 32, lane);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Persistent variant: one block per (CU x occupancy) slot walks a strided list of tiles inside its XCD's contiguous
-// tile range.  The LDS ring runs on across tile boundaries, so the first K tiles of the next output tile are already
-// in flight while the current tile's epilogue stores drain, and the per-block costs of the one-tile kernel (launch,
-// first-fetch latency with nothing to overlap, store tail before the slot is reused) are paid once per block.
-// The ring stage is a run-time value here (one loop body, one copy of the epilogue); per-tile addressing state is
-// recomputed by tile_setup() on the ISSUE side, ST-1 steps ahead of the compute side.
-// blocks per CU the LDS ring allows -> waves per SIMD the register allocation has to leave room for
-constexpr int pers_waves_per_simd(int bm, int bn, int bkt, int st, int nw) {
-    const int rpi = 64 / (bkt / 8);
-    const int bnr = (bn + rpi * nw - 1) / (rpi * nw) * (rpi * nw);
-    const int blocks = (160 * 1024) / (st * (bm + bnr) * bkt * 2);
-    const int w = blocks * nw / 4;
-    return w < 1 ? 1 : (w > 4 ? 4 : w);
-}
-
-template <int BM, int BN, int WM, int WN, int BKT, int ST, int MASK>
-__global__ __launch_bounds__(64 * WM * WN, pers_waves_per_simd(BM, BN, BKT, ST, WM * WN))
-void conv_gemm_pers_kernel(const ConvParams p) {
-    constexpr int NW = WM * WN;
-    constexpr int KV = BKT / 8;
-    constexpr int RPI = 64 / KV;
-    constexpr int ROWB = BKT * 2;
-    constexpr int WTM = BM / WM, WTN = BN / WN;
-    constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int KS = BKT / 16;
-    constexpr int BNR = (BN + RPI * NW - 1) / (RPI * NW) * (RPI * NW);   // weight rows staged (whole wave instructions)
-    constexpr int NA = BM / (RPI * NW);
-    constexpr int NB = BNR / (RPI * NW);
-    constexpr int LPT = NA + NB;
-    constexpr int STAGE_HALFS = (BM + BNR) * BKT;
-    static_assert(ST == 3 || ST == 4, "ring depth");
-    static_assert((ST - 2) * LPT <= 16 && ST * STAGE_HALFS * 2 <= 160 * 1024, "ring size");
-
-    __shared__ __attribute__((aligned(16))) half_t lds[ST * STAGE_HALFS];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    auto swz = [](int r) { return BKT == 32 ? (r >> 2) & 3 : (r >> 1) & 7; };
-
-    // this block's tile list: XCD x = bid % 8 owns the contiguous logical range [lo, hi); its blocks take every nbx-th
-    const unsigned T = p.ntiles, nb = gridDim.x, bid = blockIdx.x;
-    const unsigned xcd = bid & 7, slot = bid >> 3;
-    const unsigned q8 = T >> 3, r8 = T & 7;
-    const unsigned lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const unsigned hi = lo + q8 + (xcd < r8 ? 1 : 0);
-    const unsigned nbx = (nb >> 3) + (xcd < (nb & 7) ? 1 : 0);
-    if (lo + slot >= hi) return;
-
-    const int rsub = lane / KV;
-    const unsigned wstep = (unsigned)p.Np * 128u;
-
-    // ---- issue-side state (tile being fetched) -------------------------------------------------------------
-    unsigned iss_t = lo + slot;
-    bool iss_valid = true;
-    int kt_i = 0, stage_i = 0, kc = 0, dx = 0, dy = 0, tap = 0;
-    unsigned voffA[NA], ntap[NA], voffW[NB];
-    __amdgpu_buffer_rsrc_t rsA, rsW;
-    auto tile_setup = [&](unsigned logical) {
-        const unsigned mtile = logical / p.ntn, ntile = logical - mtile * p.ntn;
-        const long m0 = (long)mtile * BM;
-        const int n0 = ntile * BN;
-        long pix0;
-        {
-            const int ow = (int)(m0 % p.OW);
-            const long t = m0 / p.OW;
-            const int oh = (int)(t % p.OH);
-            const long n = t / p.OH;
-            pix0 = (n * p.Hs + (long)oh * p.sh - p.ph) * p.Ws + (long)ow * p.sw - p.pw;
-        }
-        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + pix0 * p.in_ld), 0, 0x7fffffff, 0x00020000);
-        rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * 64), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int r = (j * NW + wave) * RPI + rsub;
-            const int kv = (lane % KV) ^ swz(r);
-            const long m = m0 + r;
-            voffA[j] = OOB;
-            ntap[j] = 0xffffffffu;
-            if (m < p.M) {
-                const int ow = (int)(m % p.OW);
-                const long t = m / p.OW;
-                const int oh = (int)(t % p.OH);
-                const long n = t / p.OH;
-                const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
-                const long pix = (n * p.Hs + ih0) * p.Ws + iw0;
-                voffA[j] = (unsigned)((pix - pix0) * p.in_ld * 2 + kv * 16);
-                if constexpr (MASK) {
-                    unsigned okm = 0;
-                    for (int ty = 0; ty < p.kh; ++ty)
-                        for (int tx = 0; tx < p.kw; ++tx)
-                            okm |= (unsigned)(ih0 + ty >= 0 && ih0 + ty < p.H && iw0 + tx >= 0 && iw0 + tx < p.W) << (ty * p.kw + tx);
-                    ntap[j] = ~okm;
-                }
+            {
+                float bias[16];
+                conv_epilogue_consts(sbias, wn * WTN + j * 32, lane, bias);
+                conv_epilogue_tile(p, acc[i][j], bias, m, n, oh, ow, n0 + wn * WTN + j * 32, lane);
             }
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int r = (j * NW + wave) * RPI + rsub;
-            const int kv = (lane % KV) ^ swz(r);
-            voffW[j] = (r < BN && n0 + r < p.Np) ? (unsigned)(r * 128 + kv * 16) : OOB;
-        }
-    };
-    auto issue_next = [&]() {
-        half_t* base = lds + stage_i * STAGE_HALFS;
-        const int soffA = ((dy * p.Ws + dx) * p.in_ld + kc) * 2;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            unsigned off = voffA[j];
-            if constexpr (MASK) off |= __builtin_amdgcn_ubfe(ntap[j], (unsigned)tap, 1u) << 31;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsv_t)(base + (j * NW + wave) * RPI * BKT), 16, (int)off, soffA, 0, 0);
-        }
-        const int soffW = BKT == 64 ? (int)((unsigned)kt_i * wstep) : (int)((unsigned)(kt_i >> 1) * wstep + (unsigned)(kt_i & 1) * 64u);
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (ldsv_t)(base + BM * BKT + (j * NW + wave) * RPI * BKT), 16,
-                                                     (int)voffW[j], soffW, 0, 0);
-        if (++stage_i == ST) stage_i = 0;
-        kc += BKT;
-        if (kc >= p.cinp) {
-            kc = 0;
-            ++tap;
-            if (++dx == p.kw) { dx = 0; ++dy; }
-        }
-        if (++kt_i == p.nk) {                          // next fetch belongs to this block's next tile
-            kt_i = 0; kc = 0; dx = 0; dy = 0; tap = 0;
-            iss_t += nbx;
-            iss_valid = iss_t < hi;
-            if (iss_valid) tile_setup(iss_t);
-        }
-    };
-
-    float16v acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    tile_setup(iss_t);
-    int inflight = 0;                                   // K tiles issued and not yet consumed
-#pragma unroll 1
-    for (int s = 0; s < ST - 1; ++s)
-        if (iss_valid) { issue_next(); ++inflight; }
-
-    const int frow = lane & 31, fj = lane >> 5;
-    unsigned xoff[KS], woff[KS];                        // byte offsets inside a stage
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int rx = wm * WTM + frow, rw = wn * WTN + conv_wrow(frow);
-        xoff[ks] = rx * ROWB + (((ks * 2 + fj) ^ swz(rx)) << 4);
-        woff[ks] = BM * ROWB + rw * ROWB + (((ks * 2 + fj) ^ swz(rw)) << 4);
-    }
-
-    int stage_c = 0;
-#pragma unroll 1
-    for (unsigned cur = lo + slot; cur < hi; cur += nbx) {
-#pragma unroll 1
-        for (int kt = 0; kt < p.nk; ++kt) {
-            __builtin_amdgcn_sched_barrier(0);
-            // the tile to consume has landed once only the `inflight - 1` younger K tiles can be outstanding; epilogue
-            // stores of the previous output tile are younger than it as well, so this wait also drains them (stores
-            // and loads share vmcnt and complete out of order with respect to each other: count younger LOADS only)
-            if (inflight >= ST - 1) wait_vm<(ST - 2) * LPT>();
-            else if (ST == 4 && inflight == 2) wait_vm<LPT>();
-            else wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (iss_valid) issue_next(); else --inflight;
-            const char* sb = reinterpret_cast<const char*>(lds) + stage_c * (STAGE_HALFS * 2);
-            constexpr int KG = (KS * (TM + TN) <= 16) ? KS : (KS / 2 * (TM + TN) <= 16 ? KS / 2 : 1);
-#pragma unroll
-            for (int k0 = 0; k0 < KS; k0 += KG) {
-                half8 wf[KG][TN], xf[KG][TM];
-#pragma unroll
-                for (int ks = 0; ks < KG; ++ks) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        wf[ks][j] = *reinterpret_cast<const half8*>(sb + woff[k0 + ks] + j * 32 * ROWB);
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        xf[ks][i] = *reinterpret_cast<const half8*>(sb + xoff[k0 + ks] + i * 32 * ROWB);
-                }
-#pragma unroll
-                for (int ks = 0; ks < KG; ++ks)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, KG * (TM + TN), 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, KG * TM * TN, 0);
-            }
-            if (++stage_c == ST) stage_c = 0;
-        }
-        // ---- epilogue of tile `cur`; the next tile's first K tiles are in flight meanwhile -----------------------
-        const unsigned mtile = cur / p.ntn, ntile = cur - mtile * p.ntn;
-        const long m0 = (long)mtile * BM;
-        const int n0 = ntile * BN;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const long m = m0 + wm * WTM + i * 32 + (lane & 31);
-            if (m < p.M) {
-                const int ow = (int)(m % p.OW);
-                const long t = m / p.OW;
-                const int oh = (int)(t % p.OH);
-                const long n = t / p.OH;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) conv_epilogue_tile(p, acc[i][j], m, n, oh, ow, n0 + wn * WTN + j * 32, lane);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
     }
 }
 
@@ -511,31 +282,21 @@ int conv_gemm_mode(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int
     return 1;
 }
 
-// Tile configurations.  Index = the `cfg` digit of vse_plan_op_variant() (bench.py mirrors the names).
-//   0: 128 x 128, 4 waves, BK 32, 3 stages  (48 KiB LDS, 3 blocks/CU)  — the conv_mfma_kernel shape
-//   1: 256 x  64, 4 waves, BK 32, 3 stages
-//   2: 256 x  32, 4 waves, BK 32, 3 stages
-//   3: 256 x 128, 8 waves, BK 64, 3 stages  (144 KiB, 1 block/CU)
-//   4: 256 x 256, 8 waves, BK 64, 2 stages  (128 KiB, 1 block/CU)
-//   5: 128 x 128, 4 waves, BK 64, 2 stages  ( 64 KiB, 2 blocks/CU)
-//   6: 256 x 128, 8 waves, BK 32, 3 stages  ( 72 KiB, 2 blocks/CU)
-//   7: 256 x  64, 4 waves, BK 64, 2 stages  ( 80 KiB, 2 blocks/CU)
-//   8: 256 x 128, 8 waves, BK 64, 2 stages  ( 96 KiB, 1 block/CU)
-//   9: persistent 128 x 128, 4 waves, BK 32, 3 stages (3 blocks/CU)
-//  10: persistent 256 x 128, 8 waves, BK 32, 3 stages (2 blocks/CU)
-//  11: persistent 256 x  64, 4 waves, BK 32, 3 stages (2 blocks/CU)
-//  12: persistent 256 x  32, 4 waves, BK 32, 3 stages (2 blocks/CU)
-//  13: persistent 128 x 128, 4 waves, BK 32, 4 stages (2 blocks/CU)
-//  14: 256 x 256, 16 waves, BK 32, 4 stages (128 KiB, 1 block/CU)
-//  15: 256 x 256,  8 waves, BK 32, 4 stages (128 KiB, 1 block/CU)
-//  16: 256 x 256, 16 waves, BK 32, 3 stages ( 96 KiB, 1 block/CU)
-//  17: 256 x 192, 16 waves (8 x 2), BK 32, 3 stages (96 KiB, 1 block/CU)
-//  18: 512 x 128, 16 waves (8 x 2), BK 32, 3 stages (144 KiB, 1 block/CU)
-struct GemmCfg { int bm, bn, bk, pers_occ; };
-static const GemmCfg kCfg[] = {{128, 128, 32, 0}, {256, 64, 32, 0}, {256, 32, 32, 0}, {256, 128, 64, 0}, {256, 256, 64, 0},
-                               {128, 128, 64, 0}, {256, 128, 32, 0}, {256, 64, 64, 0}, {256, 128, 64, 0},
-                               {128, 128, 32, 3}, {256, 128, 32, 2}, {256, 64, 32, 2}, {256, 32, 32, 2}, {128, 128, 32, 2},
-                               {256, 256, 32, 0}, {256, 256, 32, 0}, {256, 256, 32, 0}, {256, 192, 32, 0}, {512, 128, 32, 0}};
+// Tile configurations (BM x BN, waves, BK, stages).  Index = the `cfg` field of vse_plan_op_variant() (bench.py mirrors
+// the names).  Measured and dropped on MI355X (tools/bench_conv.py): BK = 64 rings with 2-3 stages (fewer
+// bytes in flight per CU, -5..-25 %), 4-stage 128 x 128 (2 blocks/CU, -10 %), 512 x 128, 8-wave 256 x 256 (VGPR
+// spills), and a persistent one-block-per-slot variant of every shape (-5..-15 %: the hardware already overlaps
+// one block's store tail with its neighbours' K loops, and stores share vmcnt with the LDS-DMAs).
+//   0: 128 x 128,  4 waves (2 x 2), BK 32, 3 stages  (48 KiB LDS, 3 blocks/CU)  — the conv_mfma_kernel shape
+//   1: 256 x  64,  4 waves (4 x 1), BK 32, 3 stages  (60 KiB, 2 blocks/CU)
+//   2: 256 x  32,  4 waves (4 x 1), BK 32, 3 stages
+//   6: 256 x 128,  8 waves (4 x 2), BK 32, 3 stages  (72 KiB, 2 blocks/CU)
+//  16: 256 x 256, 16 waves (4 x 4), BK 32, 3 stages  (96 KiB, 1 block/CU)
+//  17: 256 x 192, 16 waves (8 x 2), BK 32, 3 stages  (96 KiB, 1 block/CU; weight rows staged as 256)
+struct GemmCfg { int bm, bn, bk; };
+static const GemmCfg kCfg[] = {{128, 128, 32}, {256, 64, 32}, {256, 32, 32}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {256, 128, 32},
+                               {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0},
+                               {256, 256, 32}, {256, 192, 32}};
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 // Which configuration serves a layer.  The kernel is bound by the L2 -> LDS fill (ablation: MFMAs and fragment reads
@@ -546,7 +307,7 @@ int conv_gemm_config(int Np, int cinp, long M) {
     const char* e = getenv("VSE_GEMM_CFG");          // experiments: force a configuration where it is legal
     if (e && e[0]) {
         const int c = atoi(e);
-        if (c >= 0 && c < kNumCfg && cinp % kCfg[c].bk == 0) return c;
+        if (c >= 0 && c < kNumCfg && kCfg[c].bm && cinp % kCfg[c].bk == 0) return c;
     }
     auto ntn = [&](int bn) { return (long)((Np + bn - 1) / bn); };
     if (Np <= 32) return 2;
@@ -560,13 +321,6 @@ int conv_gemm_config(int Np, int cinp, long M) {
     if (mt * ntn(192) >= 192 && w192 <= 1.34) return 17;
     if (mt * ntn(256) >= 192 && w256 <= 1.34) return 16;
     return mt * ntn(128) >= 512 ? 6 : 0;
-}
-
-template <int BM, int BN, int WM, int WN, int BKT, int ST>
-static void launch_pers(const ConvParams& p, int mode, dim3 grid, hipStream_t st) {
-    dim3 block(64 * WM * WN);
-    if (mode == 1) hipLaunchKernelGGL((conv_gemm_pers_kernel<BM, BN, WM, WN, BKT, ST, 1>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((conv_gemm_pers_kernel<BM, BN, WM, WN, BKT, ST, 0>), grid, block, 0, st, p);
 }
 
 template <int BM, int BN, int WM, int WN, int BKT, int ST>
@@ -588,34 +342,14 @@ int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st) {
     p.nk = Kp / g.bk;
     const unsigned long long tiles = (unsigned long long)((p.M + g.bm - 1) / g.bm) * p.ntn;
     if (tiles == 0 || tiles > 0x7fffffffull) return VSE_E_INVAL;
-    p.ntiles = (unsigned)tiles;
     dim3 grid((unsigned)tiles);
-    if (g.pers_occ) {
-        static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); (void)hipGetDeviceProperties(&pr, d); return pr.multiProcessorCount; }();
-        unsigned nb = (unsigned)(ncu * g.pers_occ);
-        if (nb > tiles) nb = (unsigned)tiles;
-        grid = dim3(nb);
-    }
     switch (c) {
-        case 0: launch_cfg<128, 128, 2, 2, 32, 3>(p, mode, grid, st); break;
         case 1: launch_cfg<256, 64, 4, 1, 32, 3>(p, mode, grid, st); break;
         case 2: launch_cfg<256, 32, 4, 1, 32, 3>(p, mode, grid, st); break;
-        case 3: launch_cfg<256, 128, 4, 2, 64, 3>(p, mode, grid, st); break;
-        case 4: launch_cfg<256, 256, 2, 4, 64, 2>(p, mode, grid, st); break;
-        case 5: launch_cfg<128, 128, 2, 2, 64, 2>(p, mode, grid, st); break;
         case 6: launch_cfg<256, 128, 4, 2, 32, 3>(p, mode, grid, st); break;
-        case 7: launch_cfg<256, 64, 4, 1, 64, 2>(p, mode, grid, st); break;
-        case 8: launch_cfg<256, 128, 4, 2, 64, 2>(p, mode, grid, st); break;
-        case 9: launch_pers<128, 128, 2, 2, 32, 3>(p, mode, grid, st); break;
-        case 10: launch_pers<256, 128, 4, 2, 32, 3>(p, mode, grid, st); break;
-        case 11: launch_pers<256, 64, 4, 1, 32, 3>(p, mode, grid, st); break;
-        case 12: launch_pers<256, 32, 4, 1, 32, 3>(p, mode, grid, st); break;
-        case 13: launch_pers<128, 128, 2, 2, 32, 4>(p, mode, grid, st); break;
-        case 14: launch_cfg<256, 256, 4, 4, 32, 4>(p, mode, grid, st); break;
-        case 15: launch_cfg<256, 256, 2, 4, 32, 4>(p, mode, grid, st); break;
         case 16: launch_cfg<256, 256, 4, 4, 32, 3>(p, mode, grid, st); break;
         case 17: launch_cfg<256, 192, 8, 2, 32, 3>(p, mode, grid, st); break;
-        default: launch_cfg<512, 128, 8, 2, 32, 3>(p, mode, grid, st); break;
+        default: launch_cfg<128, 128, 2, 2, 32, 3>(p, mode, grid, st); break;
     }
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }

@@ -24,7 +24,7 @@
 #define ROWB 64        // bytes per LDS row (BK halfs, no padding: LDS-DMA writes are lane-linear)
 
 template <int BM, int BN, int WM, int WN, bool UPS>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (BM + (BN < 64 ? 64 : BN)) <= 256 ? 3 : 2) void conv_mfma_kernel(const ConvParams p) {   // 3 / 2 blocks per CU by LDS
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int BNR = BN < 64 ? 64 : BN;      // weight rows staged per tile (>= one wave instruction per wave)
@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     constexpr int STAGE_HALFS = (BM + BNR) * BK;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "tile shape");
 
-    __shared__ __attribute__((aligned(16))) half_t lds[STAGES * STAGE_HALFS];   // the ONLY LDS object
+    __shared__ __attribute__((aligned(16))) half_t lds[STAGES * STAGE_HALFS + BN * 2];   // the ONLY LDS object: ring + bias
+    float* const sbias = reinterpret_cast<float*>(lds + STAGES * STAGE_HALFS);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -137,6 +138,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    conv_stage_consts(sbias, p.bias, p.zero, n0, BN, p.Np, wave, lane);
     issue(0, 0);
     if (p.nk > 1) issue(1, 1);
 
@@ -205,7 +207,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         const int oh = (int)(t % p.OH);
         const long n = t / p.OH;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) conv_epilogue_tile(p, acc[i][j], m, n, oh, ow, n0 + wn * WTN + j * 32, lane);
+        for (int j = 0; j < TN; ++j) {
+            float bias[16];
+            conv_epilogue_consts(sbias, wn * WTN + j * 32, lane, bias);
+            conv_epilogue_tile(p, acc[i][j], bias, m, n, oh, ow, n0 + wn * WTN + j * 32, lane);
+        }
     }
 }
 
@@ -219,6 +225,7 @@ int conv_tile_bn(int Np) {
 
 int launch_conv(const ConvArgs& a, hipStream_t st) {
     ConvParams p;
+    p.trace = nullptr;
     p.in = reinterpret_cast<const half_t*>(a.in.ptr);
     p.w = a.w;
     p.bias = a.bias;
@@ -268,9 +275,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.in2 = reinterpret_cast<const half_t*>(a.in2.ptr); p.in2_ld = a.in2.ld; p.in2_shift = a.in2shift;
     p.in2_hs = a.in2.h; p.in2_ws = a.in2.w; p.nv0 = a.in.c >> 3;
     if ((a.flags & (F_DOT1 | F_SRC2)) && !(a.flags & F_PATCH)) return VSE_E_UNSUPPORTED;
+    if (!a.zero) return VSE_E_INVAL;
     if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
     if (a.Kp % 64) return VSE_E_INVAL;
-    if (!a.zero) return VSE_E_INVAL;
     static const bool use_gemm = [] { const char* e = getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
     if (use_gemm) {
         const int rc = launch_conv_gemm(p, a.Kp, st);
@@ -279,7 +286,6 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     const int bn = conv_tile_bn(a.Np);
     dim3 block(256);
     const int bm = bn == 128 ? 128 : 256;
-    if (!a.zero) return VSE_E_INVAL;
     p.ntn = (unsigned)((a.Np + bn - 1) / bn);
     const unsigned long long tiles = (unsigned long long)((p.M + bm - 1) / bm) * p.ntn;
     if (tiles == 0 || tiles > 0x7fffffffull) return VSE_E_INVAL;

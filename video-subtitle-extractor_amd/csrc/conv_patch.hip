@@ -21,6 +21,10 @@
 //            stay conflict-free)
 //   weights are packed [chunk][tap][Np][32] by the compiler for this kernel (F_PATCH) so the stream is sequential.
 #include "conv_common.h"
+#ifdef VSE_TRACE
+#include <stdio.h>
+#include <vector>
+#endif
 
 #ifndef VSE_ABLATE
 #define VSE_ABLATE 0      // 1: no s_barrier  2: no fragment ds_reads  3: no weight/patch DMA  4: no MFMA   (timing experiments only)
@@ -28,6 +32,15 @@
 
 #define PTW 32
 #define PRING 4
+
+// -DVSE_TRACE: wave 0 of every block stamps s_memtime at phase boundaries into p.trace[block][8] (timing experiments
+// only; tools/trace_patch.sh): 0 start, 1 setup done, 2 first barrier passed, 3 K loop done, 4 epilogue done,
+// 5 = cycles spent in (wait + barrier) summed over the loop
+#ifdef VSE_TRACE
+#define TR_STAMP(i) do { if (tid == 0) tr[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TR_STAMP(i) do { } while (0)
+#endif
 
 // BIGP (BN = 64 only): 960-pixel patch (16-row tiles under 9x9 / 7x7 filters) and a 64-row weight ring:
 //   2 x 60 KiB patch + 4 x 8 KiB ring + 4 KiB dummy = 156 KiB;  otherwise 2 x 40 KiB + 4 x 16 KiB = 144 KiB.
@@ -40,7 +53,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     constexpr int PNPL = BIGP ? 8 : 5;              // patch DMAs per thread per chunk (512 threads x 16 B each)
     constexpr int RROWS = BIGP ? 64 : 128;          // weight rows per tap in a ring stage
     constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = 2 * RROWS * 32;   // two taps per ring stage
-    __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + PRING * WSTAGE_HALFS + (BIGP ? 4 * 512 : 0)];   // the ONLY LDS object
+    __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + PRING * WSTAGE_HALFS + (BIGP ? 4 * 512 : 0) + 4 * BN];   // the ONLY LDS object
+    // ... + BN floats of bias + BN floats of F_DOT1 projection weights
+    float* const sbias = reinterpret_cast<float*>(lds + 2 * PATCH_HALFS + PRING * WSTAGE_HALFS + (BIGP ? 4 * 512 : 0));
+    float* const sdotw = sbias + BN;
     half_t* const patch0 = lds;
     half_t* const ring0 = lds + 2 * PATCH_HALFS;
     half_t* const dummy0 = ring0 + PRING * WSTAGE_HALFS;   // BIGP: landing zone of the 4 surplus patch DMAs
@@ -49,6 +65,11 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wpx = wave / WCO, wco = wave % WCO;
+#ifdef VSE_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_sync = 0;
+#endif
+    TR_STAMP(0);
 
     // XCD-aware bijective block order (see conv_mfma.hip): contiguous logical range per XCD, cout tiles innermost
     const unsigned nblk = gridDim.x, bid = blockIdx.x;
@@ -136,6 +157,9 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    TR_STAMP(1);
+    conv_stage_consts(sbias, p.bias, p.zero, n0, BN, p.Np, wave, lane);                      // waves 0 .. BN/64-1
+    if (p.flags & F_DOT1) conv_stage_consts(sdotw, p.dotw, p.zero, n0, BN, p.Np, wave - 4, lane);   // waves 4 ..
     issue_patch(0, 0);
     issue_w(0);
     issue_w(1);
@@ -148,6 +172,9 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
         int tapoff = 0, dx = 0, tap = 0;                   // tapoff = dy*PW + dx of tap
         for (int pr = 0; pr < pairs; ++pr, ++s) {
             // stages s+1, s+2 may still fly (+ the next chunk's patch DMAs when they were issued 1-2 steps ago)
+#ifdef VSE_TRACE
+            const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
             if constexpr (BIGP) {
                 if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -159,6 +186,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
             __builtin_amdgcn_s_barrier();
 #endif
             asm volatile("" ::: "memory");
+#ifdef VSE_TRACE
+            t_sync += __builtin_amdgcn_s_memtime() - tw0;
+            if (s == 0) TR_STAMP(2);
+#endif
 #if VSE_ABLATE != 3
             if (pr == 0) issue_patch(cc + 1, (cc + 1) & 1);
             issue_w(s + 3);
@@ -201,6 +232,16 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the zero-page dummies before LDS is released
+    TR_STAMP(3);
+#ifdef VSE_TRACE
+    auto tr_flush = [&]() {
+        if (tid == 0 && p.trace) {
+            tr[4] = __builtin_amdgcn_s_memtime();
+            tr[5] = t_sync;
+            for (int i = 0; i < 8; ++i) p.trace[(unsigned long long)blockIdx.x * 8 + i] = tr[i];
+        }
+    };
+#endif
 
     // ---- epilogue ---------------------------------------------------------------------------------------------
     if constexpr (WCO == 1) {
@@ -211,7 +252,12 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
             for (int i = 0; i < 2; ++i) {
                 float part = 0.f;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) part += conv_epilogue_dot(p, acc[i][j], n0 + j * 32, lane);
+                for (int j = 0; j < TN; ++j) {
+                    float dbias[16], dw[16];
+                    conv_epilogue_consts(sbias, j * 32, lane, dbias);
+                    conv_epilogue_consts(sdotw, j * 32, lane, dw);
+                    part += conv_epilogue_dot(p, acc[i][j], dbias, dw);
+                }
                 part += __shfl_xor(part, 32);
                 const int oy = oy0 + 2 * wpx + i, ox = ox0 + fx;
                 if (fj == 0 && oy < p.OH && ox < p.OW) {
@@ -221,6 +267,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
                     else reinterpret_cast<half_t*>(p.dot_out)[m * p.dot_ld] = (half_t)z;
                 }
             }
+#ifdef VSE_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tr_flush();
+#endif
             return;
         }
     }
@@ -230,8 +280,16 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
         if (oy >= p.OH || ox >= p.OW) continue;
         const long m = (img * p.OH + oy) * p.OW + ox;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) conv_epilogue_tile(p, acc[i][j], m, img, oy, ox, n0 + wco * (BN / WCO) + j * 32, lane);
+        for (int j = 0; j < TN; ++j) {
+            float bias[16];
+            conv_epilogue_consts(sbias, wco * (BN / WCO) + j * 32, lane, bias);
+            conv_epilogue_tile(p, acc[i][j], bias, m, img, oy, ox, n0 + wco * (BN / WCO) + j * 32, lane);
+        }
     }
+#ifdef VSE_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tr_flush();
+#endif
 }
 
 // cout tile: 64 or 128, whichever pads Np less (ties -> 128)
@@ -264,10 +322,40 @@ int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
     const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w * p.ntn;
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
     const dim3 grid((unsigned)blocks), block(512);
+#ifdef VSE_TRACE
+    static unsigned long long* trace_dev = nullptr;
+    static size_t trace_cap = 0;
+    if (trace_cap < blocks * 8) {
+        if (trace_dev) (void)hipFree(trace_dev);
+        (void)hipMalloc(&trace_dev, blocks * 8 * sizeof(unsigned long long));
+        trace_cap = blocks * 8;
+    }
+    p.trace = trace_dev;
+#endif
     if (big) hipLaunchKernelGGL((conv_patch_kernel<16, 64, true>), grid, block, 0, st, p);
     else if (th == 16 && bn == 64) hipLaunchKernelGGL((conv_patch_kernel<16, 64, false>), grid, block, 0, st, p);
     else if (th == 16) hipLaunchKernelGGL((conv_patch_kernel<16, 128, false>), grid, block, 0, st, p);
     else if (bn == 64) hipLaunchKernelGGL((conv_patch_kernel<8, 64, false>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv_patch_kernel<8, 128, false>), grid, block, 0, st, p);
+#ifdef VSE_TRACE
+    {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(blocks * 8);
+        (void)hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost);
+        double d[5] = {0, 0, 0, 0, 0};
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (size_t b = 0; b < blocks; ++b) {
+            const unsigned long long* t = &h[b * 8];
+            d[0] += (double)(t[1] - t[0]); d[1] += (double)(t[2] - t[1]); d[2] += (double)(t[3] - t[2]);
+            d[3] += (double)(t[4] - t[3]); d[4] += (double)t[5];
+            if (t[0] < tmin) tmin = t[0];
+            if (t[4] > tmax) tmax = t[4];
+        }
+        fprintf(stderr, "[patch trace] k%dx%d cin%d N%d %dx%d th%d big%d blocks %llu: per block (s_memtime ticks) setup %.0f, first wait %.0f, "
+                "loop %.0f (of which wait+barrier %.0f), epilogue %.0f; kernel span %llu ticks = %.1f block-lifetimes/slot\n",
+                p.kh, p.kw, p.cinp, p.Np, p.OH, p.OW, th, (int)big, blocks, d[0] / blocks, d[1] / blocks, d[2] / blocks, d[4] / blocks,
+                d[3] / blocks, tmax - tmin, (double)(tmax - tmin) / ((d[0] + d[1] + d[2] + d[3]) / blocks));
+    }
+#endif
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }
