@@ -68,7 +68,7 @@ def main():
         desc, wts = graph(cin, cout, k, s, p)
         from vse_amd import compiler
         nets = {}
-        for key, mink in (("g", 1 << 30), ("p", 580)):     # "p": conv_patch_kernel allowed; numeric cfgs: implicit GEMM only
+        for key, mink in (("g", 1 << 30), ("p", 500)):     # "p": conv_patch_kernel allowed; numeric cfgs: implicit GEMM only
             compiler.PATCH_MIN_K = mink
             nets[key] = engine.Net(ctx, desc, wts, want_probs=False)
         x = (torch.rand((n, h, w, 8), device="cuda") * 2 - 1).half()
@@ -80,7 +80,7 @@ def main():
         ref = None
         for c in cfgs:
             net = nets["p" if c == "p" else "g"]
-            compiler.PATCH_MIN_K = 580 if c == "p" else 1 << 30      # plans are compiled lazily on the first run
+            compiler.PATCH_MIN_K = 500 if c == "p" else 1 << 30      # plans are compiled lazily on the first run
             os.environ["VSE_GEMM_CFG"] = "" if c == "p" else c
             out = net.run(x)
             torch.cuda.synchronize()

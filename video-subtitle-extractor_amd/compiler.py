@@ -128,7 +128,7 @@ _ACTS = {"relu": ir.ACT_RELU, "hard_swish": ir.ACT_HSWISH, "swish": ir.ACT_SWISH
 
 
 # shortest K (taps x channels) worth a conv_patch_kernel launch; VSE_PATCH_MINK overrides it for kernel experiments
-PATCH_MIN_K = int(os.environ.get("VSE_PATCH_MINK", "580"))
+PATCH_MIN_K = int(os.environ.get("VSE_PATCH_MINK", "500"))
 # most couts sent to the patch kernel: with more than 64 couts the 256-pixel implicit-GEMM tiles (conv_gemm.hip,
 # activation tile fetched once for 128-256 couts) measure 15-50 % faster than the patch kernel on MI355X
 PATCH_MAX_COUT = int(os.environ.get("VSE_PATCH_MAXCOUT", "64"))
