@@ -251,10 +251,15 @@ class Net:
                                        prog.ws_bytes, C.byref(h)), "vse_plan_create")
             self.plans[key][1] = h
             handle = h
-        t = self.ctx.torch
-        if key not in self.ws:
-            self.ws[key] = t.zeros(max(prog.ws_bytes, 256), dtype=t.uint8, device=self.ctx.tdev)
         return prog, handle
+
+    def _workspace(self, key, prog, slot):
+        """One workspace per (plan, slot): a plan is stateless between runs, so the same plan may run concurrently on
+        several streams as long as every in-flight run has its own slot."""
+        t = self.ctx.torch
+        if (key, slot) not in self.ws:
+            self.ws[(key, slot)] = t.zeros(max(prog.ws_bytes, 256), dtype=t.uint8, device=self.ctx.tdev)
+        return self.ws[(key, slot)]
 
     def _ext(self, prog, x):
         t = self.ctx.torch
@@ -263,7 +268,7 @@ class Net:
         ptrs = (C.c_void_p * (1 + len(outs)))(x.data_ptr(), *[o.data_ptr() for o in outs])
         return outs, ptrs
 
-    def run(self, x):
+    def run(self, x, slot=0):
         """x: cuda fp16 [N,H,W,8] NHWC (3 real channels).  Returns list of fp32 cuda tensors (prog.outputs order)."""
         t = self.ctx.torch
         assert x.dtype == t.float16 and x.is_contiguous() and x.shape[3] == 8, (x.dtype, x.shape)
@@ -271,18 +276,20 @@ class Net:
         self.program(n, h, w)
         prog, handle = self._ensure((n, h, w))
         outs, ptrs = self._ext(prog, x)
-        _check(self.ctx.lib.vse_plan_run(handle, C.c_void_p(self.ws[(n, h, w)].data_ptr()), ptrs, len(ptrs),
-                                         self.ctx.stream()), "vse_plan_run")
+        ws = self._workspace((n, h, w), prog, slot)
+        _check(self.ctx.lib.vse_plan_run(handle, C.c_void_p(ws.data_ptr()), ptrs, len(ptrs), self.ctx.stream()),
+               "vse_plan_run")
         return outs
 
-    def profile(self, x):
+    def profile(self, x, slot=0):
         """Per-op milliseconds (HIP events) for one run; returns (ms ndarray, program)."""
         n, h, w, _ = x.shape
         self.program(n, h, w)
         prog, handle = self._ensure((n, h, w))
         outs, ptrs = self._ext(prog, x)
         ms = (C.c_float * len(prog.ops))()
-        _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(self.ws[(n, h, w)].data_ptr()), ptrs, len(ptrs),
-                                             self.ctx.stream(), ms), "vse_plan_profile")
+        ws = self._workspace((n, h, w), prog, slot)
+        _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(ws.data_ptr()), ptrs, len(ptrs), self.ctx.stream(), ms),
+               "vse_plan_profile")
         variants = [self.ctx.lib.vse_plan_op_variant(handle, i) for i in range(len(prog.ops))]
         return np.array(ms[:], dtype=np.float32), prog, variants

@@ -69,10 +69,10 @@ class OcrPipeline:
         self.profile_sink = None              # list: when set, every net run is profiled per op and appended here
         self.rec_streams = 1                  # >1: width groups of the recogniser run on that many side streams
 
-    def _run(self, net, x):
+    def _run(self, net, x, slot=0):
         if getattr(self, "profile_sink", None) is not None:
-            self.profile_sink.append(net.profile(x))
-        return net.run(x)
+            self.profile_sink.append(net.profile(x, slot))
+        return net.run(x, slot)
 
     # ---- detection ---------------------------------------------------------------------------------------
     def det_maps(self, frames):
