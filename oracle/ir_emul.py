@@ -125,7 +125,8 @@ class Emulator:
         KT = ir.KT
         if int(r["flags"]) & ir.F_PATCH:
             taps = kh * kw
-            tp, c32 = taps + taps % 2, (cinp + 31) // 32 * 32
+            c32 = (cinp + 31) // 32 * 32
+            tp = Kp // c32                                  # taps padded to whole kernel steps by the compiler
             wt = self.wread(int(r["w_off"]), tp * c32 * Np, np.float16).astype(np.float32)
             wfull = wt.reshape(c32 // 32, tp, Np, 32).transpose(2, 1, 0, 3).reshape(Np, tp, c32)
             assert not wfull[:, taps:].any() and not wfull[:, :, cinp:].any()

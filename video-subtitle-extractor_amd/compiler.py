@@ -131,7 +131,7 @@ _ACTS = {"relu": ir.ACT_RELU, "hard_swish": ir.ACT_HSWISH, "swish": ir.ACT_SWISH
 PATCH_MIN_K = int(os.environ.get("VSE_PATCH_MINK", "500"))
 # most couts sent to the patch kernel: with more than 64 couts the 256-pixel implicit-GEMM tiles (conv_gemm.hip,
 # activation tile fetched once for 128-256 couts) measure 15-50 % faster than the patch kernel on MI355X
-PATCH_MAX_COUT = int(os.environ.get("VSE_PATCH_MAXCOUT", "64"))
+PATCH_MAX_COUT = 64
 
 
 class Compiler:
@@ -633,18 +633,17 @@ class Compiler:
                     wname=op["in"]["Filter"][0])
 
     @staticmethod
-    def patch_weights(mat, taps, cinp):
-        """[Np][Kp] (K order tap-major, channel-minor) -> [ceil(cinp/32)][taps even][Np][32] fp16 for conv_patch_kernel
-        (zero weights for the channel tail and for the tap appended to an odd tap count)."""
+    def patch_weights(mat, taps, cinp, tp):
+        """[Np][Kp] (K order tap-major, channel-minor) -> [ceil(cinp/32)][tp taps][Np][32] fp16 for conv_patch_kernel
+        (zero weights for the channel tail and for the taps appended up to `tp` = whole kernel steps)."""
         npad = mat.shape[0]
         c32 = rup(cinp, 32)
-        tp = taps + taps % 2
         full = np.zeros((npad, tp, c32), mat.dtype)
         full[:, :taps, :cinp] = mat[:, :taps * cinp].reshape(npad, taps, cinp)
         m = np.ascontiguousarray(full.reshape(npad, tp, c32 // 32, 32).transpose(2, 1, 0, 3)).astype(np.float16)
-        # PATCH_WPAD_STEPS = 4 zero steps (8 taps) after the stream: the kernel's DMA look-ahead runs past the last
-        # real step without a bounds test and must land on readable zeros
-        return np.concatenate([m.reshape(-1), np.zeros(8 * npad * 32, np.float16)])
+        # PATCH_WPAD_STEPS = 4 zero steps (of up to 4 taps) after the stream: the kernel's DMA look-ahead runs past the
+        # last real step without a bounds test and must land on readable zeros
+        return np.concatenate([m.reshape(-1), np.zeros(16 * npad * 32, np.float16)])
 
     def lower_conv(self, i):
         op = self.ops[i]
@@ -718,7 +717,10 @@ class Compiler:
         self.env_dims_tmp = (inv.n, oh, ow)
         if patch:
             flags |= ir.F_PATCH
-            Kp = (kh * kw + (kh * kw) % 2) * rup(inv.span, 32)      # taps padded to even, channels to 32
+            # taps padded to whole kernel steps (2 taps with the 960-pixel patch, else 4), channels to 32
+            big = th == 16 and (16 + kh - 1) * (32 + kw - 1) > 640
+            ptaps = rup(kh * kw, 2 if big else 4)
+            Kp = ptaps * rup(inv.span, 32)
         in2shift = 0
         if inv.parts is not None:
             if patch:
@@ -744,9 +746,10 @@ class Compiler:
                 ins.append(None)
             ins.append(inv.parts[1])
         if patch:
-            w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"]),
+            # (the tap padding depends on the kernel variant the map size selects: part of the cache key)
+            w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"], ptaps),
                                      lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh * kw,
-                                                                inv.span))
+                                                                inv.span, ptaps))
         else:
             w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]),
                                      lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0]))

@@ -11,7 +11,8 @@
 //   block  = 512 threads = 8 waves; TH=8: 4 (pixel rows 2w,2w+1) x 2 (cout halves); TH=16: 8 x 1 (all couts):
 //            wave tile = 64 px x {BN/2 | BN} couts, up to 32 MFMAs per wave between barriers
 //   LDS    = 2 x 40 KiB patch (double-buffered across channel chunks) + 4 x 8 KiB weight ring = 112 KiB, one object
-//   step   = TWO filter taps (16 MFMAs per wave between barriers; odd tap counts get one zero-weight tap appended)
+//   step   = FOUR filter taps (32 MFMAs per wave between barriers; 9x9 / 7x7 / 5x5 with the 960-pixel patch: TWO, the
+//            weight ring then has 8 KiB stages); tap counts are padded with zero-weight taps to a whole step
 //   sync   = ONE raw s_barrier per step; LDS-DMA completion by counted s_waitcnt vmcnt(N): per step every thread
 //            issues exactly 2 weight DMAs (+5 patch DMAs at step 0 of a chunk, zero-page dummies included), so N is
 //            a literal: 9 at steps 1,2 of a chunk (the patch DMAs of the NEXT chunk are younger than the stage
@@ -51,8 +52,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     constexpr int TN = BN / (32 * WCO);             // 32-cout MFMA tiles per wave
     constexpr int PPIX = BIGP ? 960 : 640;          // patch capacity in pixels
     constexpr int PNPL = BIGP ? 8 : 5;              // patch DMAs per thread per chunk (512 threads x 16 B each)
-    constexpr int RROWS = BIGP ? 64 : 128;          // weight rows per tap in a ring stage
-    constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = 2 * RROWS * 32;   // two taps per ring stage
+    constexpr int RROWS = 64;                       // weight rows per tap in a ring stage (BN = 64 only)
+    constexpr int TPS = BIGP ? 2 : 4;               // filter taps per step: 16 / 32 MFMAs per wave between barriers
+    constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = TPS * RROWS * 32;
+    static_assert(BN == 64, "the patch kernel serves <= 64 couts per tile");
     __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + PRING * WSTAGE_HALFS + (BIGP ? 4 * 512 : 0) + 4 * BN];   // the ONLY LDS object
     // ... + BN floats of bias + BN floats of F_DOT1 projection weights
     float* const sbias = reinterpret_cast<float*>(lds + 2 * PATCH_HALFS + PRING * WSTAGE_HALFS + (BIGP ? 4 * 512 : 0));
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
 
     const int PW = PTW + p.kw - 1, PH = PTH + p.kh - 1, P = PW * PH;
     const int taps = p.kh * p.kw;
-    const int pairs = (taps + 1) >> 1;                     // steps per chunk (two taps each)
+    const int pairs = (taps + TPS - 1) / TPS;              // steps per chunk (TPS taps each; the stream is padded to that)
     const int nchunks = (p.cinp + 31) >> 5;
     const int total = nchunks * pairs;
 
@@ -103,15 +106,15 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
                               + (kv - p.nv0) * 8
                         : 0;
     }
-    // weight DMA: non-BIGP: thread -> row tid>>2 (0..127), both taps of the step (2 DMAs);  BIGP: waves 0-3 fetch
-    // tap 0, waves 4-7 tap 1, rows 0..63 (1 DMA)
-    const int wr = BIGP ? ((tid >> 2) & 63) : (tid >> 2);
+    // weight DMA: thread -> cout row (tid>>2)&63; waves 0-3 fetch the even taps of a step, waves 4-7 the odd ones
+    // (BIGP: 2 taps per step = 1 DMA per thread; otherwise 4 taps per step = 2 DMAs per thread)
+    const int wr = (tid >> 2) & 63;
     const bool wok = (wr < BN) && (n0 + wr < p.Np);
-    // running DMA source of this thread: advanced by one step (two taps) per issue_w; the compiler appends
+    // running DMA source of this thread: advanced by one step (TPS taps) per issue_w; the compiler appends
     // PATCH_WPAD_STEPS zero steps to the packed stream, so the look-ahead past the last real step reads real zeros
     // (no select in the loop); rows beyond the cout range park on the zero page and never move
-    const half_t* wptr = wok ? p.w + (long)(n0 + wr) * 32 + kv * 8 + (BIGP ? (long)(wave >> 2) * p.Np * 32 : 0) : p.zero;
-    const long winc = wok ? (long)p.Np * 64 : 0;
+    const half_t* wptr = wok ? p.w + (long)(n0 + wr) * 32 + kv * 8 + (long)(wave >> 2) * p.Np * 32 : p.zero;
+    const long winc = wok ? (long)p.Np * 32 * TPS : 0;
 
     auto issue_patch = [&](int cc, int buf) {
         half_t* base = patch0 + buf * PATCH_HALFS;
@@ -131,8 +134,9 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
         if constexpr (BIGP) {
             glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
         } else {
-            glds16(wptr, st + wave * 16 * 32);
-            glds16(wptr + (wok ? (long)p.Np * 32 : 0), st + RROWS * 32 + wave * 16 * 32);
+            // waves 0-3: taps 0 and 2 of the step, waves 4-7: taps 1 and 3
+            glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
+            glds16(wptr + (wok ? (long)p.Np * 64 : 0), st + (2 + (wave >> 2)) * RROWS * 32 + (wave & 3) * 16 * 32);
         }
         wptr += winc;
     };
@@ -197,8 +201,8 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
             const unsigned wsb = (unsigned)(s & (PRING - 1)) * (WSTAGE_HALFS * 2);
             const char* const pb = reinterpret_cast<const char*>(pbuf);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 1 && tap >= taps) break;          // odd tap count: the appended zero-weight tap does no work
+            for (int h = 0; h < TPS; ++h) {
+                if (h >= 1 && tap >= taps) break;          // tap count not a multiple of TPS: the appended zero-weight taps do no work
                 const unsigned q0 = (unsigned)(qb0 + tapoff), q1 = (unsigned)(qb1 + tapoff);
                 const unsigned a0 = (q0 << 6) + ((fj ^ ((q0 >> 2) & 3)) << 4), a1 = (q1 << 6) + ((fj ^ ((q1 >> 2) & 3)) << 4);
 #pragma unroll
@@ -313,6 +317,7 @@ int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
     if (p.sh != 1 || p.sw != 1 || p.kh * p.kw < 5 || (p.cinp & 7) || (p.flags & F_PIXSHUF)) return VSE_E_INVAL;
     if ((8 + p.kh - 1) * (PTW + p.kw - 1) > 640) return VSE_E_UNSUPPORTED;
     const int bn = conv_patch_bn(p.Np);
+    if (bn != 64) return VSE_E_UNSUPPORTED;           // wider layers run on conv_gemm_kernel (compiler.py)
     const int th = conv_patch_th(p.kh, p.kw, p.OH, bn);
     const bool big = th == 16 && (16 + p.kh - 1) * (PTW + p.kw - 1) > 640;
     p.ntn = (unsigned)((p.Np + bn - 1) / bn);
@@ -334,9 +339,7 @@ int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
 #endif
     if (big) hipLaunchKernelGGL((conv_patch_kernel<16, 64, true>), grid, block, 0, st, p);
     else if (th == 16 && bn == 64) hipLaunchKernelGGL((conv_patch_kernel<16, 64, false>), grid, block, 0, st, p);
-    else if (th == 16) hipLaunchKernelGGL((conv_patch_kernel<16, 128, false>), grid, block, 0, st, p);
-    else if (bn == 64) hipLaunchKernelGGL((conv_patch_kernel<8, 64, false>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((conv_patch_kernel<8, 128, false>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_patch_kernel<8, 64, false>), grid, block, 0, st, p);
 #ifdef VSE_TRACE
     {
         (void)hipStreamSynchronize(st);
