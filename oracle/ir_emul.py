@@ -130,7 +130,8 @@ class Emulator:
             wt = self.wread(int(r["w_off"]), tp * c32 * Np, np.float16).astype(np.float32)
             wfull = wt.reshape(c32 // 32, tp, Np, 32).transpose(2, 1, 0, 3).reshape(Np, tp, c32)
             assert not wfull[:, taps:].any() and not wfull[:, :, cinp:].any()
-            wmat = np.ascontiguousarray(wfull[:, :taps, :cinp]).reshape(Np, taps * cinp)
+            row_major = [(t % kw) * kh + t // kw for t in range(taps)]     # stream is column-major: t' = dx*kh + dy
+            wmat = np.ascontiguousarray(wfull[:, :taps, :cinp][:, row_major, :]).reshape(Np, taps * cinp)
         else:
             wt = self.wread(int(r["w_off"]), (Kp // KT) * Np * KT, np.float16).astype(np.float32)
             wmat = wt.reshape(Kp // KT, Np, KT).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]

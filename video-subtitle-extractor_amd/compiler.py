@@ -633,13 +633,17 @@ class Compiler:
                     wname=op["in"]["Filter"][0])
 
     @staticmethod
-    def patch_weights(mat, taps, cinp, tp):
-        """[Np][Kp] (K order tap-major, channel-minor) -> [ceil(cinp/32)][tp taps][Np][32] fp16 for conv_patch_kernel
-        (zero weights for the channel tail and for the taps appended up to `tp` = whole kernel steps)."""
+    def patch_weights(mat, kh, kw, cinp, tp):
+        """[Np][Kp] (K order tap-major (dy, dx), channel-minor) -> [ceil(cinp/32)][tp taps][Np][32] fp16 for
+        conv_patch_kernel, taps in COLUMN-major order (t' = dx*kh + dy: the kernel walks filter columns so that
+        consecutive taps share an activation fragment); zero weights for the channel tail and for the taps appended
+        up to `tp` = whole kernel steps."""
         npad = mat.shape[0]
         c32 = rup(cinp, 32)
+        taps = kh * kw
+        col_major = [(t % kh) * kw + t // kh for t in range(taps)]        # stream position t' -> row-major tap
         full = np.zeros((npad, tp, c32), mat.dtype)
-        full[:, :taps, :cinp] = mat[:, :taps * cinp].reshape(npad, taps, cinp)
+        full[:, :taps, :cinp] = mat[:, :taps * cinp].reshape(npad, taps, cinp)[:, col_major, :]
         m = np.ascontiguousarray(full.reshape(npad, tp, c32 // 32, 32).transpose(2, 1, 0, 3)).astype(np.float16)
         # PATCH_WPAD_STEPS = 4 zero steps (of up to 4 taps) after the stream: the kernel's DMA look-ahead runs past the
         # last real step without a bounds test and must land on readable zeros
@@ -748,7 +752,7 @@ class Compiler:
         if patch:
             # (the tap padding depends on the kernel variant the map size selects: part of the cache key)
             w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"], ptaps),
-                                     lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh * kw,
+                                     lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh, kw,
                                                                 inv.span, ptaps))
         else:
             w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]),

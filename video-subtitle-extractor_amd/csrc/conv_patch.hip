@@ -20,7 +20,9 @@
 //   banks  = 64-byte rows; 16-byte slot s of row/pixel q holds logical k-vector s ^ ((q >> 2) & 3), applied on the
 //            DMA source side; 16 consecutive pixels at ANY alignment then hit 16 distinct bank groups (shifted taps
 //            stay conflict-free)
-//   weights are packed [chunk][tap][Np][32] by the compiler for this kernel (F_PATCH) so the stream is sequential.
+//   weights are packed [chunk][tap][Np][32] by the compiler for this kernel (F_PATCH) so the stream is sequential;
+//   taps in COLUMN-major order (dx outer, dy inner): consecutive taps of a column share one of their two activation
+//   fragments, which is carried in registers (LDS fragment reads per MFMA 1.0 -> 0.78 for 9x9).
 #include "conv_common.h"
 #ifdef VSE_TRACE
 #include <stdio.h>
@@ -173,7 +175,12 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     for (int cc = 0; cc < nchunks; ++cc) {
         const half_t* pbuf = patch0 + (cc & 1) * PATCH_HALFS;
         const bool klim1 = (p.cinp - cc * 32) <= 16;
-        int tapoff = 0, dx = 0, tap = 0;                   // tapoff = dy*PW + dx of tap
+        // taps are walked COLUMN by column (dx outer, dy inner; the compiler packs the weight stream in that order): the
+        // wave's second output row under tap (dy, dx) reads the patch row its first output row reads under (dy+1, dx),
+        // so inside a column every tap needs ONE new activation fragment per k half instead of two
+        int tapoff = 0, dx = 0, dy = 0, tap = 0;           // tapoff = dy*PW + dx of tap
+        half8 xc[2];                                       // row-1 fragments of the previous tap (k halves)
+        xc[0] = xc[1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         for (int pr = 0; pr < pairs; ++pr, ++s) {
             // stages s+1, s+2 may still fly (+ the next chunk's patch DMAs when they were issued 1-2 steps ago)
 #ifdef VSE_TRACE
@@ -216,8 +223,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         wf[j] = *reinterpret_cast<const half8*>(ring_b + wsb + h * (RROWS * 64) + (woffb[j] ^ (ks << 5)));
-                    xf[0] = *reinterpret_cast<const half8*>(pb + (a0 ^ (ks << 5)));
+                    if (dy == 0) xf[0] = *reinterpret_cast<const half8*>(pb + (a0 ^ (ks << 5)));
+                    else xf[0] = xc[ks];
                     xf[1] = *reinterpret_cast<const half8*>(pb + (a1 ^ (ks << 5)));
+                    xc[ks] = xf[1];
 #endif
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
 #endif
                 }
                 if (++tap < taps) {
-                    if (++dx == p.kw) { dx = 0; tapoff += PW - p.kw + 1; } else { ++tapoff; }
+                    if (++dy == p.kh) { dy = 0; tapoff = ++dx; } else { tapoff += PW; }
                 }
             }
         }
