@@ -206,6 +206,8 @@ def variant_kernel_name(code):
     """vse_plan_op_variant() code -> the kernel instantiation rocprofv3 reports (see csrc/vse_runtime.hip)."""
     code = int(code)
     tiles = {128: "128, 128, 2, 2", 64: "256, 64, 4, 1", 32: "256, 32, 4, 1"}
+    if code >= 400000:
+        return "conv_head_up2_kernel"
     if code >= 200000:
         cfg = {0: "128, 128, 2, 2, 32, 3", 1: "256, 64, 4, 1, 32, 3", 2: "256, 32, 4, 1, 32, 3", 6: "256, 128, 4, 2, 32, 3",
                16: "256, 256, 4, 4, 32, 3", 17: "256, 192, 8, 2, 32, 3"}.get((code - 200000) // 10)

@@ -123,6 +123,34 @@ class Emulator:
             x = torch.cat([x, self._up(self.read(r["in2"]), int(p[ir.P_IN2SHIFT]))], dim=3)
         assert x.shape[3] == cinp
         KT = ir.KT
+        if int(r["flags"]) & ir.F_UP2HEAD:
+            # folded weights: [2 chunks][4 parities][4 taps][64][32] + u block [64][32]; evaluate per output parity on
+            # the low-res grid exactly as conv_head_up2_kernel does, then fall through to the common epilogue
+            wt = self.wread(int(r["w_off"]), 2 * 4 * 4 * 64 * 32 + 64 * 32, np.float16).astype(np.float32)
+            wx = wt[:2 * 4 * 4 * 64 * 32].reshape(2, 4, 4, 64, 32)
+            wu = torch.from_numpy(wt[2 * 4 * 4 * 64 * 32:].reshape(64, 32)[:Np, :9].reshape(Np, 1, 3, 3).copy())
+            xl = self.read(r["in2"]).permute(0, 3, 1, 2)                      # [n,64,Hl,Wl]
+            u = self.read(r["in0"])[..., 0:1].permute(0, 3, 1, 2)            # [n,1,2Hl,2Wl]
+            n, _, Hl, Wl = xl.shape
+            y = F.conv2d(u, wu, None, 1, 1)                                   # [n,Np,2Hl,2Wl]
+            xp = F.pad(xl, (1, 1, 1, 1))
+            for a_ in range(2):
+                for b_ in range(2):
+                    wk = np.concatenate([wx[0, a_ * 2 + b_], wx[1, a_ * 2 + b_]], axis=2)       # [4 taps][64][64 ch]
+                    w4 = torch.from_numpy(np.ascontiguousarray(wk.reshape(2, 2, 64, 64).transpose(2, 3, 0, 1))[:Np])
+                    z = F.conv2d(xp[:, :, a_:a_ + Hl + 1, b_:b_ + Wl + 1], w4)                     # [n,Np,Hl,Wl]
+                    y[:, :, a_::2, b_::2] += z
+            bias = torch.from_numpy(self.wread(int(r["b_off"]), Np, np.float32).copy())
+            y = (y + bias.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+            y = _act(y, int(p[ir.P_ACT]), float(f[ir.FS_ACT_A]), float(f[ir.FS_ACT_B]))
+            y = y * float(f[ir.FS_POST_A]) + float(f[ir.FS_POST_B])
+            y = _act(y, int(p[ir.P_ACT2]))
+            dw = torch.from_numpy(self.wread(int(r["aux_off"]), Np, np.float32).copy())
+            z = (y * dw).sum(-1, keepdim=True) + float(f[ir.FS_PRE_B])
+            z = _act(z, int(p[ir.P_DOTACT]))
+            oc2 = int(r["out2"]["c"])
+            self.write(r["out2"], z if oc2 == 1 else F.pad(z, (0, oc2 - 1)))
+            return
         if int(r["flags"]) & ir.F_PATCH:
             taps = kh * kw
             c32 = (cinp + 31) // 32 * 32

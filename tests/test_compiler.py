@@ -75,6 +75,8 @@ def test_kernel_selection_and_head_fusion_at_full_size():
     flags = [int(o["flags"]) for o in prog.ops if int(o["kind"]) == ir.OP_CONV]
     assert sum(bool(f & ir.F_PATCH) for f in flags) >= 10
     assert sum(bool(f & ir.F_DOT1) for f in flags) == 1 and sum(bool(f & ir.F_SRC2) for f in flags) == 1
+    # ... and that last conv runs on the LOW-RES grid with folded 2x2 taps (conv_head.hip): same algorithmic MACs reported
+    assert sum(bool(f & ir.F_UP2HEAD) for f in flags) == 1
     assert not any(int(o["kind"]) == ir.OP_RESIZE and int(o["out"]["h"]) == 544 for o in prog.ops)
     assert abs(prog.gmacs - 194.703) < 0.05                      # 194.70 GMAC per 544x960 frame
     assert prog.outputs[0]["kind"] == "map" and prog.outputs[0]["esize"] == 4 and prog.outputs[0]["c"] == 1

@@ -132,6 +132,9 @@ PATCH_MIN_K = int(os.environ.get("VSE_PATCH_MINK", "500"))
 # most couts sent to the patch kernel: with more than 64 couts the 256-pixel implicit-GEMM tiles (conv_gemm.hip,
 # activation tile fetched once for 128-256 couts) measure 15-50 % faster than the patch kernel on MI355X
 PATCH_MAX_COUT = 64
+# evaluate the PP-OCRv4 server detector's last 3x3 conv on the low-res grid (conv_head.hip); VSE_HEAD_UP2=0 keeps it on
+# the patch kernel (experiments / A-B)
+HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
 
 
 class Compiler:
@@ -649,6 +652,36 @@ class Compiler:
         # last real step without a bounds test and must land on readable zeros
         return np.concatenate([m.reshape(-1), np.zeros(16 * npad * 32, np.float16)])
 
+    @staticmethod
+    def head_up2_weights(mat, cinp):
+        """3x3 conv over concat[u (8 physical channels, 1 real), up2(x) (64 channels)], matrix [Np][9*cinp] in
+        (tap, channel) order -> the stream of conv_head_up2_kernel:
+            [chunk 0..1][parity a*2+b][tap r*2+s][64][32] fp16   (x part, folded onto the low-res grid)
+            [64][32] fp16                                        (u part: k = 3*dy + dx < 9, rest zero)
+        Under nearest x2 upsampling output parity a sees low-res row offsets a-1 (r=0) and a (r=1); the original taps
+        that land on the same low-res pixel are summed (fp64): a=0: r0 <- dy 0, r1 <- dy 1,2;  a=1: r0 <- dy 0,1,
+        r1 <- dy 2 (same for columns)."""
+        npad = mat.shape[0]
+        assert npad <= 64 and cinp == 72
+        w = np.zeros((64, 3, 3, cinp), np.float64)
+        w[:npad] = mat[:, :9 * cinp].reshape(npad, 3, 3, cinp)
+        wx, wu = w[..., 8:72], w[..., 0]                       # [64,3,3,64], [64,3,3]
+        taps_of = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+        out = np.zeros((2, 4, 4, 64, 32), np.float64)
+        for a in range(2):
+            for b in range(2):
+                for r in range(2):
+                    for s_ in range(2):
+                        acc = np.zeros((64, 64), np.float64)
+                        for dy in taps_of[(a, r)]:
+                            for dx in taps_of[(b, s_)]:
+                                acc += wx[:, dy, dx, :]
+                        for c in range(2):
+                            out[c, a * 2 + b, r * 2 + s_] = acc[:, c * 32:(c + 1) * 32]
+        ublock = np.zeros((64, 32), np.float64)
+        ublock[:, :9] = wu.reshape(64, 9)
+        return np.concatenate([out.reshape(-1), ublock.reshape(-1)]).astype(np.float16)
+
     def lower_conv(self, i):
         op = self.ops[i]
         a = op["attrs"]
@@ -749,7 +782,19 @@ class Compiler:
             while len(ins) < 2:
                 ins.append(None)
             ins.append(inv.parts[1])
-        if patch:
+        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch and th == 16 and coutp <= 128) else None
+        # DB head of the PP-OCRv4 server detector: 3x3 over [1-channel full-res map, x2-upsampled 64-channel map] with
+        # the fused 1-channel projection -> evaluated on the low-res grid with folded 2x2 taps (conv_head.hip)
+        head = (dot is not None and (flags & ir.F_SRC2) and res is None and (kh, kw, ph, pw) == (3, 3, 1, 1)
+                and in2shift == 1 and inv_main.up == 0 and inv_main.span == 8 and inv_main.c == 1
+                and inv.parts[1].span == 64 and inv.span == 72 and coutp <= 64
+                and (oh, ow) == (inv.parts[1].h, inv.parts[1].w) and oh % 2 == 0 and ow % 2 == 0 and HEAD_UP2)
+        if head:
+            flags |= ir.F_UP2HEAD
+            Kp = 2 * 4 * 4 * 32 + 32
+            w_off = self.add_weights(("convh", wname, tuple(inv.segs), ep["out_name"]),
+                                     lambda: self.head_up2_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], inv.span))
+        elif patch:
             # (the tap padding depends on the kernel variant the map size selects: part of the cache key)
             w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"], ptaps),
                                      lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh, kw,
@@ -758,7 +803,6 @@ class Compiler:
             w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]),
                                      lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0]))
         b_off = self.add_weights(("convb", wname, ep["out_name"]), bias)
-        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch and th == 16 and coutp <= 128) else None
         if dot is not None:
             aux_off = self.add_weights(("dot1", dot["wname"], ep["out_name"]), dot["w"])
             self.emit(ir.OP_CONV, dot["out_name"], ins, dot["view"], flags=flags | ir.F_DOT1,

@@ -1,0 +1,246 @@
+// DB head on the LOW-RESOLUTION grid ("conv_head_up2_kernel", F_UP2HEAD).
+//
+// PP-OCRv4's server detector ends in   y = dot(relu(bn(conv3x3(concat[u, up2(x)]))), w) -> sigmoid   at full resolution,
+// where x is a 64-channel map at HALF resolution (nearest x2 upsampled on the fly) and u a 1-channel full-resolution
+// map.  Under nearest x2 upsampling the 3x3 window of an output pixel of parity (a, b) = (row & 1, col & 1) touches
+// only 2 x 2 distinct pixels of x: low-res offsets {a-1, a} x {b-1, b}.  The compiler therefore folds the 3x3 taps into
+// four 2x2-tap weight sets W_ab[r][s] (sums of the original taps, in fp64), and this kernel computes, for a tile of
+// 8 x 32 LOW-RES pixels, the 4 parities x 64 couts from ONE staging of the low-res halo patch: 2.25x fewer MACs than
+// the full-resolution 3x3 conv (exact in real arithmetic), no upsampled tensor, no 64-channel output tensor.
+//
+//   block   = 512 threads = 8 waves: wave -> 2 low-res rows (wave >> 1) x 32 couts (wave & 1), 4 parities:
+//             acc[4][2] accumulator tiles (128 VGPRs)
+//   LDS     = x halo patch, both 32-channel chunks (10 x 34 pixels, staged once) 48 KiB + 4-stage weight ring
+//             (stage = 4 taps x 64 couts x 32 channels = 16 KiB) 64 KiB + u weights 4 KiB + u tile 2.4 KiB
+//             + cross-wave partial dots 8 KiB + epilogue constants
+//   K loop  = 8 steps (2 chunks x 4 parities, fully unrolled: the parity selects the accumulator set), 16 MFMAs per
+//             wave between barriers; the 6 activation fragments a step needs serve its 8 (row, tap) pairs
+//   u       = one extra K = 16 MFMA slice per parity: the 9 full-resolution taps of the 1-channel map are gathered
+//             from the LDS u tile (ds_read_u16) into an activation fragment
+//   epilogue= bias -> activation -> dot with the 1x1 projection over this wave's 32 couts -> cross-half shuffle ->
+//             LDS exchange between the two cout halves -> activation (sigmoid) -> one 8-byte store per lane and row
+//             parity (columns 2j, 2j+1)
+// weights stream (compiler.py head_up2_weights): [chunk][parity a*2+b][tap r*2+s][64][32] fp16, then [64][32] for u
+// (k = 3*dy + dx < 9, rest zero).
+#include <type_traits>
+#include "conv_common.h"
+
+#define HT_ROWS 8
+#define HT_COLS 32
+#define HPW (HT_COLS + 2)
+#define HPH (HT_ROWS + 2)
+#define HP (HPW * HPH)               // 340 patch pixels
+#define HPPIX 384                    // staged (whole wave instructions: 8 waves x 3 x 16 pixels)
+#define UTW 68                       // u tile row pitch (66 used)
+#define UTH 18
+
+__global__ __launch_bounds__(512) void conv_head_up2_kernel(const ConvParams p) {
+    constexpr int PATCHC_HALFS = HPPIX * 32;                 // one 32-channel chunk of the patch
+    constexpr int WSTAGE_HALFS = 4 * 64 * 32;
+    constexpr int NSTEP = 8;
+    __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCHC_HALFS + 4 * WSTAGE_HALFS + 64 * 32 + UTH * UTW + 2 * 4096 + 2 * 128];
+    half_t* const patch0 = lds;
+    half_t* const ring0 = lds + 2 * PATCHC_HALFS;
+    half_t* const uw0 = ring0 + 4 * WSTAGE_HALFS;
+    half_t* const ut0 = uw0 + 64 * 32;
+    float* const part0 = reinterpret_cast<float*>(ut0 + UTH * UTW);      // [8 waves][4 parities][2 rows][32 px]
+    float* const sbias = part0 + 2048;
+    float* const sdotw = sbias + 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = wave >> 1, wco = wave & 1;
+
+    // XCD-aware bijective block order (see conv_mfma.hip)
+    const unsigned nblk = gridDim.x, bid = blockIdx.x;
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+    unsigned t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int tx = t % p.tiles_w;  t /= p.tiles_w;
+    const int ty = t % p.tiles_h;
+    const long img = t / p.tiles_h;
+    const int oy0 = ty * HT_ROWS, ox0 = tx * HT_COLS;        // low-res origin of the tile
+    const int Hl = p.in2_hs, Wl = p.in2_ws;                  // low-res map; the output is 2Hl x 2Wl
+
+    // ---- prologue: everything but the weight stream is staged once --------------------------------------------------
+    const int kv = (lane & 3) ^ ((lane >> 4) & 3);           // logical k-vector this lane fetches (source-side swizzle)
+    conv_stage_consts(sbias, p.bias, p.zero, 0, 64, p.Np, wave, lane);            // wave 0
+    conv_stage_consts(sdotw, p.dotw, p.zero, 0, 64, p.Np, wave - 4, lane);        // wave 4
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = 16 * (wave + 8 * j) + (lane >> 2);
+            const int py = q / HPW, px = q - py * HPW;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            const bool ok = (q < HP) && (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
+            const half_t* src = ok ? p.in2 + ((img * Hl + iy) * Wl + ix) * (long)p.in2_ld + c * 32 + kv * 8 : p.zero;
+            glds16(src, patch0 + c * PATCHC_HALFS + (wave + 8 * j) * 16 * 32);
+        }
+    const half_t* const wu = p.w + (long)NSTEP * WSTAGE_HALFS;
+    if (wave < 4) glds16(wu + (wave * 16 + (lane >> 2)) * 32 + kv * 8, uw0 + wave * 16 * 32);
+    // weight ring: thread -> cout row (tid>>2)&63; waves 0-3 fetch taps 0 and 2 of a stage, waves 4-7 taps 1 and 3
+    const half_t* wptr = p.w + ((long)(wave >> 2) * 64 + ((tid >> 2) & 63)) * 32 + kv * 8;
+    auto issue_w = [&](int s) __attribute__((always_inline)) {
+        half_t* st = ring0 + (s & 3) * WSTAGE_HALFS;
+        glds16(wptr, st + (wave >> 2) * 64 * 32 + (wave & 3) * 16 * 32);
+        glds16(wptr + 2 * 64 * 32, st + (2 + (wave >> 2)) * 64 * 32 + (wave & 3) * 16 * 32);
+        wptr += WSTAGE_HALFS;
+    };
+    issue_w(0);
+    issue_w(1);
+    issue_w(2);
+    // u tile: full-res rows 2*oy0-1 .. 2*oy0+16, cols 2*ox0-1 .. 2*ox0+64 of channel 0, zero outside the map
+    {
+        const half_t* ub = p.in + img * (long)(2 * Hl) * (2 * Wl) * p.in_ld;
+        for (int idx = tid; idx < UTH * 66; idx += 512) {
+            const int uy = idx / 66, ux = idx - uy * 66;
+            const int fy = 2 * oy0 - 1 + uy, fx2 = 2 * ox0 - 1 + ux;
+            half_t v = (half_t)0.f;
+            if (fy >= 0 && fy < 2 * Hl && fx2 >= 0 && fx2 < 2 * Wl) v = ub[((long)fy * (2 * Wl) + fx2) * p.in_ld];
+            ut0[uy * UTW + ux] = v;
+        }
+    }
+
+    float16v acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][i][r] = 0.f;
+
+    const int fx = lane & 31, fj = lane >> 5;
+    const int wr = wco * 32 + conv_wrow(fx);                 // weight row (cout) this lane supplies
+    const unsigned woffb = (unsigned)(wr * 64 + ((fj ^ ((wr >> 2) & 3)) << 4));
+    const char* const ring_b = reinterpret_cast<const char*>(ring0);
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- K loop -----------------------------------------------------------------------------------------------------
+    auto step = [&](auto c_c, auto par_c) __attribute__((always_inline)) {
+        constexpr int C = decltype(c_c)::value, PAR = decltype(par_c)::value;
+        constexpr int S = C * 4 + PAR, A = PAR >> 1, B = PAR & 1;
+        if constexpr (S > 0) {
+            __builtin_amdgcn_sched_barrier(0);     // keep the barrier behind the previous step's fragment reads
+            // stage S has landed: only the stages issued after it (S+1, S+2 when they exist) may be outstanding
+            if constexpr (S + 2 < NSTEP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (S + 1 < NSTEP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        if constexpr (S + 3 < NSTEP) issue_w(S + 3);
+        const char* const pb = reinterpret_cast<const char*>(patch0 + C * PATCHC_HALFS);
+        const unsigned wsb = (unsigned)(S & 3) * (WSTAGE_HALFS * 2);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // activation fragments: patch rows 2*wrow + A + {0,1,2}, cols fx + B + {0,1}
+            half8 xf[3][2];
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const unsigned q = (unsigned)((2 * wrow + A + rr) * HPW + fx + B + s2);
+                    xf[rr][s2] = *reinterpret_cast<const half8*>(pb + ((q << 6) + (((2 * ks + fj) ^ ((q >> 2) & 3)) << 4)));
+                }
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const half8 wf = *reinterpret_cast<const half8*>(ring_b + wsb + (r * 2 + s2) * (64 * 64) + (woffb ^ (ks << 5)));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[PAR][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf[i + r][s2], acc[PAR][i], 0, 0, 0);
+                }
+        }
+    };
+    step(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
+
+    // ---- the 1-channel full-resolution source: one K = 16 slice per parity ---------------------------------------------
+    {
+        const half8 wfu = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(uw0) + woffb);   // k 0..15 of row wr
+#pragma unroll
+        for (int par = 0; par < 4; ++par) {
+            const int a = par >> 1, b = par & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // lane (fx, fj) supplies k = 8*fj + e: tap (dy, dx) = (k / 3, k % 3) of output pixel (2*row + a, 2*fx + b)
+                const int uy0 = 2 * (2 * wrow + i) + a, ux0 = 2 * fx + b;      // tile coords of tap (0, 0)
+                half8 xu = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (fj == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xu[e] = ut0[(uy0 + e / 3) * UTW + ux0 + e % 3];
+                } else {
+                    xu[0] = ut0[(uy0 + 2) * UTW + ux0 + 2];                        // k = 8: tap (2, 2)
+                }
+                acc[par][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfu, xu, acc[par][i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    {
+        float dbias[16], dw[16];
+        conv_epilogue_consts(sbias, wco * 32, lane, dbias);
+        conv_epilogue_consts(sdotw, wco * 32, lane, dw);
+#pragma unroll
+        for (int par = 0; par < 4; ++par)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float part = conv_epilogue_dot(p, acc[par][i], dbias, dw);
+                part += __shfl_xor(part, 32);
+                if (fj == 0) part0[((wave * 4 + par) * 2 + i) * 32 + fx] = part;
+            }
+    }
+    __syncthreads();
+    if (wco == 0) {
+        // lanes 0-31: row parity a = 0, lanes 32-63: a = 1; both column parities of a pixel -> one 8-byte store
+        const int a = fj;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int oy = oy0 + 2 * wrow + i, ox = ox0 + fx;
+            if (oy >= Hl || ox >= Wl) continue;
+            float z[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int par = a * 2 + b;
+                const float s0 = part0[((wave * 4 + par) * 2 + i) * 32 + fx] + part0[(((wave + 1) * 4 + par) * 2 + i) * 32 + fx];
+                z[b] = vse_act(s0 + p.dotb, p.dotact, 0.f, 0.f);
+            }
+            const long m = ((img * (2 * Hl) + 2 * oy + a) * (long)(2 * Wl) + 2 * ox) * p.dot_ld;
+            if (p.dot_f32) {
+                float* o = reinterpret_cast<float*>(p.dot_out) + m;
+                if (p.dot_ld == 1) *reinterpret_cast<float2*>(o) = make_float2(z[0], z[1]);
+                else { o[0] = z[0]; o[p.dot_ld] = z[1]; }
+            } else {
+                half_t* o = reinterpret_cast<half_t*>(p.dot_out) + m;
+                o[0] = (half_t)z[0]; o[p.dot_ld] = (half_t)z[1];
+            }
+        }
+    }
+}
+
+int launch_conv_head_up2(const ConvParams& pin, int n_img, hipStream_t st) {
+    ConvParams p = pin;
+    // u = in0: [n, 2Hl, 2Wl, 8-channel padded, 1 real]; x = in2: [n, Hl, Wl, 64], upsampled by 2
+    if (!(p.flags & F_DOT1) || !(p.flags & F_SRC2) || p.in2_shift != 1 || p.inshift != 0) return VSE_E_INVAL;
+    if (p.kh != 3 || p.kw != 3 || p.ph != 1 || p.pw != 1 || p.sh != 1 || p.sw != 1) return VSE_E_INVAL;
+    if (p.cinp != 72 || p.nv0 != 1 || p.Np > 64 || (p.flags & (F_RES | F_PIXSHUF))) return VSE_E_INVAL;
+    if (p.H != 2 * p.in2_hs || p.W != 2 * p.in2_ws || !p.dotw || !p.dot_out || !p.zero) return VSE_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(p.dot_out) & 7) || ((2 * p.in2_ws * p.dot_ld) & 1)) return VSE_E_INVAL;
+    p.tiles_h = (p.in2_hs + HT_ROWS - 1) / HT_ROWS;
+    p.tiles_w = (p.in2_ws + HT_COLS - 1) / HT_COLS;
+    const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w;
+    if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
+    hipLaunchKernelGGL(conv_head_up2_kernel, dim3((unsigned)blocks), dim3(512), 0, st, p);
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}

@@ -200,6 +200,7 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if (!p || i < 0 || i >= (int)p->ops.size()) return VSE_E_INVAL;
     const vse_op& o = p->ops[i];
     if (o.kind != OP_CONV) return 0;
+    if (o.flags & F_UP2HEAD) return 400000;   // conv_head_up2_kernel
     if (o.flags & F_PATCH) {   // conv_patch_kernel<TH, BN, BIGP> -> 100000*BIGP + 1000*TH + BN
         const int bn = conv_patch_bn(o.p[P_COUT]);
         const int th = conv_patch_th(o.p[P_KH], o.p[P_KW], (o.flags & F_DOT1) ? o.out2.h : o.out.h, bn);
