@@ -81,6 +81,7 @@ def main():
         for c in cfgs:
             net = nets["p" if c == "p" else "g"]
             compiler.PATCH_MIN_K = 500 if c == "p" else 1 << 30      # plans are compiled lazily on the first run
+            compiler.PATCH_MAX_COUT = 256 if c == "p" else 64       # "p": also try the patch kernel on wide layers (two+ cout tiles)
             os.environ["VSE_GEMM_CFG"] = "" if c == "p" else c
             out = net.run(x)
             torch.cuda.synchronize()
