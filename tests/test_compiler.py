@@ -85,4 +85,4 @@ def test_kernel_selection_and_head_fusion_at_full_size():
         if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_PATCH:
             p = o["p"]
             assert (p[ir.P_SH], p[ir.P_SW]) == (1, 1) and p[ir.P_KH] * p[ir.P_KW] >= 5
-            assert (8 + p[ir.P_KH] - 1) * (32 + p[ir.P_KW] - 1) <= 640 and p[ir.P_COUT] <= 64
+            assert (8 + p[ir.P_KH] - 1) * (32 + p[ir.P_KW] - 1) <= 640 and p[ir.P_COUT] <= 128

@@ -132,6 +132,8 @@ PATCH_MIN_K = int(os.environ.get("VSE_PATCH_MINK", "500"))
 # most couts sent to the patch kernel: with more than 64 couts the 256-pixel implicit-GEMM tiles (conv_gemm.hip,
 # activation tile fetched once for 128-256 couts) measure 15-50 % faster than the patch kernel on MI355X
 PATCH_MAX_COUT = 64
+# LIGHT patch variant policy, mirrors VSE_PATCH_LIGHT in csrc/conv_patch.hip: 0 never, 1 layers with 65-128 couts, 2 all eligible
+PATCH_LIGHT = int(os.environ.get("VSE_PATCH_LIGHT", "2"))
 # evaluate the PP-OCRv4 server detector's last 3x3 conv on the low-res grid (conv_head.hip); VSE_HEAD_UP2=0 keeps it on
 # the patch kernel (experiments / A-B)
 HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
@@ -749,15 +751,18 @@ class Compiler:
         th = 16 if (pbn == 64 and (16 + kh - 1) * (32 + kw - 1) <= pcap and -(-oh // 16) * 16 * 100 <= -(-oh // 8) * 8 * 120) else 8
         tile_eff = (oh * ow) / float(-(-oh // th) * th * -(-ow // 32) * 32)
         # (one block per CU: the fixed prologue/epilogue only amortises over a long enough K loop)
-        patch = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 640
-                 and tile_eff >= 0.7 and kh * kw * cin >= PATCH_MIN_K and coutp <= PATCH_MAX_COUT and self.use_patch)
+        patch_std = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 640
+                     and tile_eff >= 0.7 and kh * kw * cin >= PATCH_MIN_K and coutp <= PATCH_MAX_COUT and self.use_patch)
+        # LIGHT variant (conv_patch_plan in csrc/conv_patch.hip): 8-row tiles whose halo patch fits 352 pixels (3x3, 1xk),
+        # 64 or 128 couts per tile, two blocks per CU; not combined with the fused 1-channel projection
+        tile_eff8 = (oh * ow) / float(-(-oh // 8) * 8 * -(-ow // 32) * 32)
+        light_ok = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 352 and tile_eff8 >= 0.7
+                    and kh * kw * cin >= PATCH_MIN_K and self.use_patch
+                    and (PATCH_LIGHT >= 2 if coutp <= 64 else (coutp <= 128 and PATCH_LIGHT >= 1)))
+        patch = patch_std or light_ok
         self.env_dims_tmp = (inv.n, oh, ow)
         if patch:
             flags |= ir.F_PATCH
-            # taps padded to whole kernel steps (2 taps with the 960-pixel patch, else 4), channels to 32
-            big = th == 16 and (16 + kh - 1) * (32 + kw - 1) > 640
-            ptaps = rup(kh * kw, 2 if big else 4)
-            Kp = ptaps * rup(inv.span, 32)
         in2shift = 0
         if inv.parts is not None:
             if patch:
@@ -782,7 +787,14 @@ class Compiler:
             while len(ins) < 2:
                 ins.append(None)
             ins.append(inv.parts[1])
-        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch and th == 16 and coutp <= 128) else None
+        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch_std and th == 16 and coutp <= 128) else None
+        if patch:
+            # taps padded to whole kernel steps (1 tap in the LIGHT variant, 2 with the 960-pixel patch, else 4), channels to 32
+            light = light_ok and dot is None
+            assert light or patch_std
+            big = (not light) and th == 16 and (16 + kh - 1) * (32 + kw - 1) > 640
+            ptaps = kh * kw if light else rup(kh * kw, 2 if big else 4)
+            Kp = ptaps * rup(inv.span, 32)
         # DB head of the PP-OCRv4 server detector: 3x3 over [1-channel full-res map, x2-upsampled 64-channel map] with
         # the fused 1-channel projection -> evaluated on the low-res grid with folded 2x2 taps (conv_head.hip)
         head = (dot is not None and (flags & ir.F_SRC2) and res is None and (kh, kw, ph, pw) == (3, 3, 1, 1)

@@ -224,3 +224,4 @@ int conv_gemm_config(int Np, int cinp, long M);   // index into the tile-configu
 int conv_gemm_mode(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int Kp, int inshift, int flags);
 int conv_patch_th(int kh, int kw, int OH, int bn);
 int conv_patch_bn(int Np);
+void conv_patch_plan(int kh, int kw, int OH, int Np, int flags, int* th, int* bn, int* mode);

@@ -23,6 +23,7 @@
 //   weights are packed [chunk][tap][Np][32] by the compiler for this kernel (F_PATCH) so the stream is sequential;
 //   taps in COLUMN-major order (dx outer, dy inner): consecutive taps of a column share one of their two activation
 //   fragments, which is carried in registers (LDS fragment reads per MFMA 1.0 -> 0.78 for 9x9).
+#include <stdlib.h>
 #include "conv_common.h"
 #ifdef VSE_TRACE
 #include <stdio.h>
@@ -47,20 +48,27 @@
 
 // BIGP (BN = 64 only): 960-pixel patch (16-row tiles under 9x9 / 7x7 filters) and a 64-row weight ring:
 //   2 x 60 KiB patch + 4 x 8 KiB ring + 4 KiB dummy = 156 KiB;  otherwise 2 x 40 KiB + 4 x 16 KiB = 144 KiB.
-template <int PTH, int BN, bool BIGP>
-__global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
+// MODE 2 = LIGHT (3x3 / 1xk filters on 8-row tiles): 352-pixel patch, ONE tap per step, 64 or 128 couts per tile:
+//   2 x 22 KiB patch + 4 x {4 | 8} KiB ring + dummies = 61 / 79 KiB -> TWO blocks per CU (4 waves per SIMD), the
+//   occupancy the implicit-GEMM kernel has, with the patch kernel's activation reuse.
+template <int PTH, int BN, int MODE>
+__global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(const ConvParams p) {
+    constexpr bool BIGP = MODE == 1, LIGHT = MODE == 2;
     static_assert(!BIGP || (BN == 64 && PTH == 16), "big patch variant");
+    static_assert(!LIGHT || PTH == 8, "light variant");
     constexpr int WCO = PTH == 16 ? 1 : 2;          // waves along cout
     constexpr int TN = BN / (32 * WCO);             // 32-cout MFMA tiles per wave
-    constexpr int PPIX = BIGP ? 960 : 640;          // patch capacity in pixels
-    constexpr int PNPL = BIGP ? 8 : 5;              // patch DMAs per thread per chunk (512 threads x 16 B each)
-    constexpr int RROWS = 64;                       // weight rows per tap in a ring stage (BN = 64 only)
-    constexpr int TPS = BIGP ? 2 : 4;               // filter taps per step: 16 / 32 MFMAs per wave between barriers
+    constexpr int PPIX = BIGP ? 960 : LIGHT ? 352 : 640;   // patch capacity in pixels
+    constexpr int PNPL = BIGP ? 8 : LIGHT ? 3 : 5;  // patch DMAs per thread per chunk (512 threads x 16 B each)
+    constexpr int RROWS = LIGHT ? BN : 64;          // weight rows per tap in a ring stage
+    constexpr int TPS = BIGP ? 2 : LIGHT ? 1 : 4;   // filter taps per step: 16 / 8 / 32 MFMAs per wave between barriers
     constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = TPS * RROWS * 32;
-    static_assert(BN == 64, "the patch kernel serves <= 64 couts per tile");
-    __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + PRING * WSTAGE_HALFS + (BIGP ? 4 * 512 : 0) + 4 * BN];   // the ONLY LDS object
+    // landing zone of surplus DMAs (whole wave instructions past the patch / past a 64-row weight stage)
+    constexpr int DUMMY_HALFS = BIGP ? 4 * 512 : LIGHT ? (2 + (BN == 64 ? 4 : 0)) * 512 : 0;
+    static_assert(BN == 64 || (LIGHT && BN == 128), "cout tile");
+    __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + PRING * WSTAGE_HALFS + DUMMY_HALFS + 4 * BN];   // the ONLY LDS object
     // ... + BN floats of bias + BN floats of F_DOT1 projection weights
-    float* const sbias = reinterpret_cast<float*>(lds + 2 * PATCH_HALFS + PRING * WSTAGE_HALFS + (BIGP ? 4 * 512 : 0));
+    float* const sbias = reinterpret_cast<float*>(lds + 2 * PATCH_HALFS + PRING * WSTAGE_HALFS + DUMMY_HALFS);
     float* const sdotw = sbias + BN;
     half_t* const patch0 = lds;
     half_t* const ring0 = lds + 2 * PATCH_HALFS;
@@ -110,12 +118,12 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
     }
     // weight DMA: thread -> cout row (tid>>2)&63; waves 0-3 fetch the even taps of a step, waves 4-7 the odd ones
     // (BIGP: 2 taps per step = 1 DMA per thread; otherwise 4 taps per step = 2 DMAs per thread)
-    const int wr = (tid >> 2) & 63;
+    const int wr = LIGHT ? (tid >> 2) : ((tid >> 2) & 63);     // LIGHT: one tap per step, thread -> row 0..127
     const bool wok = (wr < BN) && (n0 + wr < p.Np);
     // running DMA source of this thread: advanced by one step (TPS taps) per issue_w; the compiler appends
     // PATCH_WPAD_STEPS zero steps to the packed stream, so the look-ahead past the last real step reads real zeros
     // (no select in the loop); rows beyond the cout range park on the zero page and never move
-    const half_t* wptr = wok ? p.w + (long)(n0 + wr) * 32 + kv * 8 + (long)(wave >> 2) * p.Np * 32 : p.zero;
+    const half_t* wptr = wok ? p.w + (long)(n0 + wr) * 32 + kv * 8 + (LIGHT ? 0 : (long)(wave >> 2) * p.Np * 32) : p.zero;
     const long winc = wok ? (long)p.Np * 32 * TPS : 0;
 
     auto issue_patch = [&](int cc, int buf) {
@@ -128,12 +136,16 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
             if (live && pok[j]) src = second ? p.in2 + poff2[j] + cc * 32 : p.in + poff[j] + cc * 32;
             half_t* dst = base + (wave + 8 * j) * 16 * 32;
             if (BIGP && j == PNPL - 1 && wave >= 4) { src = p.zero; dst = dummy0 + (wave - 4) * 512; }   // pixels >= 960
+            if (LIGHT && j == PNPL - 1 && wave >= 6) { src = p.zero; dst = dummy0 + (wave - 6) * 512; }  // pixels >= 352
             glds16(src, dst);
         }
     };
     auto issue_w = [&](int s) {                            // ring stage = taps 2s, 2s+1 of the packed stream
         half_t* st = ring0 + (s & (PRING - 1)) * WSTAGE_HALFS;
-        if constexpr (BIGP) {
+        if constexpr (LIGHT) {
+            if (BN == 128 || wave < 4) glds16(wptr, st + wave * 16 * 32);
+            else glds16(p.zero, dummy0 + (wave - 2) * 512);                  // keeps every wave's vmcnt arithmetic alike
+        } else if constexpr (BIGP) {
             glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
         } else {
             // waves 0-3: taps 0 and 2 of the step, waves 4-7: taps 1 and 3
@@ -186,7 +198,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
 #ifdef VSE_TRACE
             const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
-            if constexpr (BIGP) {
+            if constexpr (LIGHT) {
+                if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else if constexpr (BIGP) {
                 if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             } else {
@@ -305,10 +320,28 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const ConvParams p) {
 #endif
 }
 
-// cout tile: 64 or 128, whichever pads Np less (ties -> 128)
+// Which variant serves a layer (mirrored by compiler.py, which packs the weight stream for it):
+//   mode 2 (LIGHT, 8-row tiles, 64 or 128 couts, two blocks per CU) when the halo patch of an 8 x 32 tile fits 352 pixels
+//   (3x3, 1xk) and no 1-channel projection is fused (that needs all couts of a pixel in one wave);
+//   else 64 couts per tile, 16-row tiles when they fit the 960-pixel patch (mode 1 above 640 pixels), else 8-row tiles.
+static int patch_light_policy() {       // VSE_PATCH_LIGHT: 0 never, 1 only layers with more than 64 couts, 2 every eligible layer
+    static const int v = [] { const char* e = getenv("VSE_PATCH_LIGHT"); return e && e[0] ? atoi(e) : 2; }();
+    return v;
+}
+void conv_patch_plan(int kh, int kw, int OH, int Np, int flags, int* th, int* bn, int* mode) {
+    const bool fits = (8 + kh - 1) * (PTW + kw - 1) <= 352 && !(flags & F_DOT1);
+    const int pol = patch_light_policy();
+    if (fits && (pol >= 2 || (pol == 1 && Np > 64))) {
+        *th = 8; *bn = Np > 64 ? 128 : 64; *mode = 2;
+        return;
+    }
+    *bn = 64;
+    *th = conv_patch_th(kh, kw, OH, 64);
+    *mode = (*th == 16 && (16 + kh - 1) * (PTW + kw - 1) > 640) ? 1 : 0;
+}
 int conv_patch_bn(int Np) {
     (void)Np;
-    return 64;      // the only cout tile the kernel is built for; wider layers take Np/64 tiles (the compiler sends them to conv_gemm)
+    return 64;
 }
 
 // Tile height: 16 rows when the halo patch fits the LDS patch buffer (960 pixels for BN = 64, else 640) and the map
@@ -325,10 +358,9 @@ int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
     ConvParams p = pin;
     if (p.sh != 1 || p.sw != 1 || p.kh * p.kw < 5 || (p.cinp & 7) || (p.flags & F_PIXSHUF)) return VSE_E_INVAL;
     if ((8 + p.kh - 1) * (PTW + p.kw - 1) > 640) return VSE_E_UNSUPPORTED;
-    const int bn = conv_patch_bn(p.Np);
-    if (bn != 64) return VSE_E_UNSUPPORTED;           // wider layers run on conv_gemm_kernel (compiler.py)
-    const int th = conv_patch_th(p.kh, p.kw, p.OH, bn);
-    const bool big = th == 16 && (16 + p.kh - 1) * (PTW + p.kw - 1) > 640;
+    int th, bn, mode;
+    conv_patch_plan(p.kh, p.kw, p.OH, p.Np, p.flags, &th, &bn, &mode);
+    const bool big = mode == 1;
     p.ntn = (unsigned)((p.Np + bn - 1) / bn);
     if ((p.flags & F_DOT1) && (th != 16 || p.ntn != 1 || (p.flags & F_RES) || !p.dotw || !p.dot_out)) return VSE_E_UNSUPPORTED;
     p.tiles_h = (p.OH + th - 1) / th;
@@ -346,9 +378,11 @@ int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
     }
     p.trace = trace_dev;
 #endif
-    if (big) hipLaunchKernelGGL((conv_patch_kernel<16, 64, true>), grid, block, 0, st, p);
-    else if (th == 16 && bn == 64) hipLaunchKernelGGL((conv_patch_kernel<16, 64, false>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((conv_patch_kernel<8, 64, false>), grid, block, 0, st, p);
+    if (mode == 2 && bn == 128) hipLaunchKernelGGL((conv_patch_kernel<8, 128, 2>), grid, block, 0, st, p);
+    else if (mode == 2) hipLaunchKernelGGL((conv_patch_kernel<8, 64, 2>), grid, block, 0, st, p);
+    else if (big) hipLaunchKernelGGL((conv_patch_kernel<16, 64, 1>), grid, block, 0, st, p);
+    else if (th == 16) hipLaunchKernelGGL((conv_patch_kernel<16, 64, 0>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_patch_kernel<8, 64, 0>), grid, block, 0, st, p);
 #ifdef VSE_TRACE
     {
         (void)hipStreamSynchronize(st);

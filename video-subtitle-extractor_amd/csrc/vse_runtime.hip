@@ -202,10 +202,10 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if (o.kind != OP_CONV) return 0;
     if (o.flags & F_UP2HEAD) return 400000;   // conv_head_up2_kernel
     if (o.flags & F_PATCH) {   // conv_patch_kernel<TH, BN, BIGP> -> 100000*BIGP + 1000*TH + BN
-        const int bn = conv_patch_bn(o.p[P_COUT]);
-        const int th = conv_patch_th(o.p[P_KH], o.p[P_KW], (o.flags & F_DOT1) ? o.out2.h : o.out.h, bn);
-        const bool big = th == 16 && (16 + o.p[P_KH] - 1) * (32 + o.p[P_KW] - 1) > 640;
-        return (big ? 100000 : 0) + 1000 * th + bn;
+        // conv_patch_kernel<TH, BN, MODE> -> 100000*MODE + 1000*TH + BN
+        int th, bn, mode;
+        conv_patch_plan(o.p[P_KH], o.p[P_KW], (o.flags & F_DOT1) ? o.out2.h : o.out.h, o.p[P_COUT], o.flags, &th, &bn, &mode);
+        return 100000 * mode + 1000 * th + bn;
     }
     // conv_gemm_kernel configuration c, MASK m -> 200000 + 10*c + m; conv_mfma_kernel<.., UPS> -> 10000*UPS + BN
     static const bool use_gemm = [] { const char* e = getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
