@@ -748,7 +748,7 @@ class Compiler:
         # k x k stride-1 convs on maps that tile well into 8x32 output patches go to the LDS-resident-patch kernel
         pbn = 64 if rup(coutp, 64) < rup(coutp, 128) else 128          # mirrors conv_patch_bn / conv_patch_th in csrc
         pcap = 960 if pbn == 64 else 640
-        th = 16 if (pbn == 64 and (16 + kh - 1) * (32 + kw - 1) <= pcap and -(-oh // 16) * 16 * 100 <= -(-oh // 8) * 8 * 120) else 8
+        th = 16 if (pbn == 64 and (16 + kh - 1) * (32 + kw - 1) <= pcap and -(-oh // 16) * 16 * 100 <= -(-oh // 8) * 8 * 112) else 8
         tile_eff = (oh * ow) / float(-(-oh // th) * th * -(-ow // 32) * 32)
         # (one block per CU: the fixed prologue/epilogue only amortises over a long enough K loop)
         patch_std = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 640

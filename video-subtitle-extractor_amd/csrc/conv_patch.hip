@@ -351,7 +351,7 @@ int conv_patch_th(int kh, int kw, int OH, int bn) {
     const int cap = 960;
     if ((16 + kh - 1) * (PTW + kw - 1) > cap) return 8;
     const int pad16 = (OH + 15) / 16 * 16, pad8 = (OH + 7) / 8 * 8;
-    return pad16 * 100 <= pad8 * 120 ? 16 : 8;      // accept <= 20 % extra row padding for the denser wave tile
+    return pad16 * 100 <= pad8 * 112 ? 16 : 8;      // accept <= 12 % extra row padding for the denser wave tile
 }
 
 int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
