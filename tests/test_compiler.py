@@ -86,3 +86,66 @@ def test_kernel_selection_and_head_fusion_at_full_size():
             p = o["p"]
             assert (p[ir.P_SH], p[ir.P_SW]) == (1, 1) and p[ir.P_KH] * p[ir.P_KW] >= 5
             assert (8 + p[ir.P_KH] - 1) * (32 + p[ir.P_KW] - 1) <= 640 and p[ir.P_COUT] <= 128
+
+
+def test_head_up2_folding_is_exact():
+    """conv3x3(concat[u, up2(x)]) == per-parity 2x2 convs over x with the folded weights + 3x3 over u (fp64 identity that
+    conv_head_up2_kernel relies on), including the zero padding at the map border."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    cout, hl, wl = 5, 6, 7
+    w = rng.standard_normal((cout, 65, 3, 3))
+    x = rng.standard_normal((2, 64, hl, wl))
+    u = rng.standard_normal((2, 1, 2 * hl, 2 * wl))
+    full = torch.cat([torch.from_numpy(u), torch.from_numpy(x).repeat_interleave(2, 2).repeat_interleave(2, 3)], 1)
+    ref = F.conv2d(full, torch.from_numpy(w), None, 1, 1).numpy()
+    # matrix in the compiler's K order: (tap, physical channel) with u at physical channel 0 and x at 8..71
+    mat = np.zeros((8, 9 * 72))
+    m4 = mat.reshape(8, 3, 3, 72)
+    m4[:cout, :, :, 0] = w[:, 0]
+    m4[:cout, :, :, 8:72] = np.transpose(w[:, 1:], (0, 2, 3, 1))
+    stream = compiler.Compiler.head_up2_weights(mat, 72).astype(np.float64)      # fp16-rounded folded weights
+    wx = stream[:2 * 4 * 4 * 64 * 32].reshape(2, 4, 4, 64, 32)
+    wu = stream[2 * 4 * 4 * 64 * 32:].reshape(64, 32)[:cout, :9].reshape(cout, 1, 3, 3)
+    got = F.conv2d(torch.from_numpy(u), torch.from_numpy(wu), None, 1, 1).numpy()
+    xp = np.pad(x, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    for a in range(2):
+        for b in range(2):
+            wk = np.concatenate([wx[0, a * 2 + b], wx[1, a * 2 + b]], axis=2)[:, :cout]          # [tap][cout][64]
+            w4 = np.ascontiguousarray(wk.reshape(2, 2, cout, 64).transpose(2, 3, 0, 1))
+            z = F.conv2d(torch.from_numpy(xp[:, :, a:a + hl + 1, b:b + wl + 1]), torch.from_numpy(w4)).numpy()
+            got[:, :, a::2, b::2] += z
+    # the only difference is the fp16 rounding of the (summed) weights
+    assert np.abs(got - ref).max() < 2e-2 * np.abs(ref).max()
+    # exactness of the folding itself: repeat with weights that are exactly representable in fp16
+    w_q = np.round(w * 8) / 8
+    m4[:] = 0
+    m4[:cout, :, :, 0] = w_q[:, 0]
+    m4[:cout, :, :, 8:72] = np.transpose(w_q[:, 1:], (0, 2, 3, 1))
+    stream = compiler.Compiler.head_up2_weights(mat, 72).astype(np.float64)
+    wx = stream[:2 * 4 * 4 * 64 * 32].reshape(2, 4, 4, 64, 32)
+    wu = stream[2 * 4 * 4 * 64 * 32:].reshape(64, 32)[:cout, :9].reshape(cout, 1, 3, 3)
+    ref = F.conv2d(full, torch.from_numpy(w_q), None, 1, 1).numpy()
+    got = F.conv2d(torch.from_numpy(u), torch.from_numpy(wu), None, 1, 1).numpy()
+    for a in range(2):
+        for b in range(2):
+            wk = np.concatenate([wx[0, a * 2 + b], wx[1, a * 2 + b]], axis=2)[:, :cout]
+            w4 = np.ascontiguousarray(wk.reshape(2, 2, cout, 64).transpose(2, 3, 0, 1))
+            got[:, :, a::2, b::2] += F.conv2d(torch.from_numpy(xp[:, :, a:a + hl + 1, b:b + wl + 1]), torch.from_numpy(w4)).numpy()
+    assert np.abs(got - ref).max() < 1e-9
+
+
+def test_light_patch_variant_selection():
+    """3x3 stride-1 convs with up to 128 couts on well-tiling maps take the LIGHT patch variant: taps are NOT padded
+    (one tap per step); 9x9 keeps two taps per step on 16-row tiles, and the same weights compile for both shapes."""
+    desc, w = net_ref.get_weights("V4_ch_det")
+    prog = compiler.compile_model(desc, w, 1, 544, 960)
+    seen = set()
+    for o in prog.ops:
+        if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_PATCH and not int(o["flags"]) & ir.F_UP2HEAD:
+            p = o["p"]
+            taps = int(p[ir.P_KH]) * int(p[ir.P_KW])
+            ptaps = int(p[ir.P_KTOT]) // ((int(p[ir.P_CINP]) + 31) // 32 * 32)
+            seen.add((taps, ptaps))
+    assert (9, 9) in seen and (81, 82) in seen and (49, 50) in seen and (25, 26) in seen
