@@ -112,9 +112,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (single-GPU boxes): VSE_DIST_BACKEND=gloo + VSE_BENCH_DEVICE=0 run several ranks on one device to
+    # exercise the multi-rank control flow; the driver's launches use RCCL (backend "nccl"), one rank per GPU
+    backend = os.environ.get("VSE_DIST_BACKEND", "nccl")
+    if "VSE_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["VSE_BENCH_DEVICE"])
     if world > 1:
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from vse_amd import engine, modelzoo, parallel, pipeline, shim, synth
 
     t_start = time.time()
@@ -145,13 +153,17 @@ def main():
     lo = rank * args.batch
     log(f"frames generated and uploaded ({frames_np.nbytes / 1e6:.0f} MB)")
 
-    def step():
+    coll_dev = ctx.tdev if backend == "nccl" else "cpu"
+
+    def step_local():
         maps = pipe.det_maps(frames)
         db = ctx.db_postprocess(maps, args.height, args.width, **pipe.db)
         boxes = [pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads
         res = pipe.recognize(frames, boxes)
-        recs = [(lo + f, np.asarray(boxes[f], np.float32).reshape(-1, 4, 2), res[f]) for f in range(args.batch)]
-        return parallel.gather_records(recs, device=ctx.tdev)
+        return [(lo + f, np.asarray(boxes[f], np.float32).reshape(-1, 4, 2), res[f]) for f in range(args.batch)]
+
+    def step():
+        return parallel.gather_records(step_local(), device=coll_dev)     # the one collective of the path (all ranks)
 
     def sync():
         if world > 1:
@@ -168,7 +180,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=ctx.tdev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     log(f"timed region: {args.steps} steps in {dt:.3f}s")
@@ -189,7 +201,7 @@ def main():
                        "records_gathered": len(out) if out is not None else 0},
         }
         if not args.no_roofline:
-            result["roofline"] = roofline(pipe, step)
+            result["roofline"] = roofline(pipe, step_local)     # rank 0 only: must not enter a collective
             log("roofline pass done")
         if not args.no_cpu_baseline and world == 1:
             from oracle import pipeline_ref as P
