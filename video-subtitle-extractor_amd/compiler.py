@@ -132,6 +132,8 @@ PATCH_MIN_K = int(os.environ.get("VSE_PATCH_MINK", "500"))
 # most couts sent to the patch kernel: with more than 64 couts the 256-pixel implicit-GEMM tiles (conv_gemm.hip,
 # activation tile fetched once for 128-256 couts) measure 15-50 % faster than the patch kernel on MI355X
 PATCH_MAX_COUT = 64
+# smallest useful fraction of a tile grid (8/16 x 32 output pixels) for the patch kernel; below it the map is too ragged
+PATCH_MIN_TILE_EFF = float(os.environ.get("VSE_PATCH_MINEFF", "0.5"))
 # LIGHT patch variant policy, mirrors VSE_PATCH_LIGHT in csrc/conv_patch.hip: 0 never, 1 layers with 65-128 couts, 2 all eligible
 PATCH_LIGHT = int(os.environ.get("VSE_PATCH_LIGHT", "2"))
 # evaluate the PP-OCRv4 server detector's last 3x3 conv on the low-res grid (conv_head.hip); VSE_HEAD_UP2=0 keeps it on
@@ -752,11 +754,11 @@ class Compiler:
         tile_eff = (oh * ow) / float(-(-oh // th) * th * -(-ow // 32) * 32)
         # (one block per CU: the fixed prologue/epilogue only amortises over a long enough K loop)
         patch_std = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 640
-                     and tile_eff >= 0.7 and kh * kw * cin >= PATCH_MIN_K and coutp <= PATCH_MAX_COUT and self.use_patch)
+                     and tile_eff >= PATCH_MIN_TILE_EFF and kh * kw * cin >= PATCH_MIN_K and coutp <= PATCH_MAX_COUT and self.use_patch)
         # LIGHT variant (conv_patch_plan in csrc/conv_patch.hip): 8-row tiles whose halo patch fits 352 pixels (3x3, 1xk),
         # 64 or 128 couts per tile, two blocks per CU; not combined with the fused 1-channel projection
         tile_eff8 = (oh * ow) / float(-(-oh // 8) * 8 * -(-ow // 32) * 32)
-        light_ok = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 352 and tile_eff8 >= 0.7
+        light_ok = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 352 and tile_eff8 >= PATCH_MIN_TILE_EFF
                     and kh * kw * cin >= PATCH_MIN_K and self.use_patch
                     and (PATCH_LIGHT >= 2 if coutp <= 64 else (coutp <= 128 and PATCH_LIGHT >= 1)))
         patch = patch_std or light_ok
