@@ -9,6 +9,8 @@
 #include <cstring>
 #include <vector>
 
+#include <algorithm>
+#include <mutex>
 #include "common.h"
 #include "db_geometry.h"
 
@@ -222,17 +224,23 @@ extern "C" int vse_db_postprocess(vse_ctx*, const float* d_prob, int n, int h, i
     if (hipMemcpyAsync(hcnt.data(), cnt, n * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return VSE_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
     std::vector<std::vector<int2>> hrecs(n);
+    int maxc = 0;
     for (int f = 0; f < n; ++f) {
         if (hcnt[f] > DB_RUN_CAP) {
             vse_set_error("vse_db_postprocess: run-record capacity exceeded (noise-like probability map)");
             return VSE_E_NOMEM;
         }
-        hrecs[f].resize(hcnt[f]);
-        if (hcnt[f] && hipMemcpyAsync(hrecs[f].data(), recs + (size_t)f * DB_RUN_CAP, hcnt[f] * sizeof(int2),
-                                      hipMemcpyDeviceToHost, st) != hipSuccess)
-            return VSE_E_HIP;
+        maxc = std::max(maxc, hcnt[f]);
     }
-    if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
+    if (maxc) {
+        // ONE strided copy for all frames (64 per-frame copies from pageable memory cost ~1 ms of GPU idle per step)
+        std::vector<int2> flat((size_t)n * maxc);
+        if (hipMemcpy2DAsync(flat.data(), (size_t)maxc * sizeof(int2), recs, (size_t)DB_RUN_CAP * sizeof(int2),
+                             (size_t)maxc * sizeof(int2), n, hipMemcpyDeviceToHost, st) != hipSuccess)
+            return VSE_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
+        for (int f = 0; f < n; ++f) hrecs[f].assign(flat.begin() + (size_t)f * maxc, flat.begin() + (size_t)f * maxc + hcnt[f]);
+    }
 
     // ---- host geometry, pass 1: components -> candidate quads ----------------------------------------
     struct Cand { int frame; dbgeo::Pt box[4]; };
@@ -498,9 +506,42 @@ extern "C" int vse_rec_preprocess(vse_ctx*, const void* d_bgr, int n_frames, int
         maxpix = std::max(maxpix, c.crop_w * c.crop_h);
     }
     if (off > scratch_bytes) return VSE_E_NOMEM;
-    if (hipMemcpyAsync(d_scratch, cd.data(), n_crops * sizeof(CropDev), hipMemcpyHostToDevice, st) != hipSuccess)
-        return VSE_E_HIP;
-    if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;   // cd is a stack-lifetime pageable buffer
+    // crop records go through a small ring of pinned host slots so that the upload is truly asynchronous: a stream
+    // synchronise here (needed for a pageable, stack-lifetime source) made every width group wait for the previous
+    // recogniser launch on its stream and left the GPU idle while the host prepared the next group
+    {
+        constexpr int PIN_N = 8;
+        constexpr size_t PIN_BYTES = 64 * 1024;
+        static struct PinRing {
+            void* buf[PIN_N] = {};
+            hipEvent_t ev[PIN_N] = {};
+            bool used[PIN_N] = {};
+            int next = 0;
+            std::mutex m;
+        } ring;
+        const size_t bytes = (size_t)n_crops * sizeof(CropDev);
+        bool done = false;
+        if (bytes <= PIN_BYTES) {
+            std::lock_guard<std::mutex> lk(ring.m);
+            const int sl = ring.next;
+            ring.next = (ring.next + 1) % PIN_N;
+            bool ok = true;
+            if (!ring.buf[sl]) ok = hipHostMalloc(&ring.buf[sl], PIN_BYTES, hipHostMallocDefault) == hipSuccess &&
+                                    hipEventCreateWithFlags(&ring.ev[sl], hipEventDisableTiming) == hipSuccess;
+            if (ok && ring.used[sl]) ok = hipEventSynchronize(ring.ev[sl]) == hipSuccess;     // slot's previous upload has finished
+            if (ok) {
+                memcpy(ring.buf[sl], cd.data(), bytes);
+                if (hipMemcpyAsync(d_scratch, ring.buf[sl], bytes, hipMemcpyHostToDevice, st) != hipSuccess) return VSE_E_HIP;
+                if (hipEventRecord(ring.ev[sl], st) != hipSuccess) return VSE_E_HIP;
+                ring.used[sl] = true;
+                done = true;
+            }
+        }
+        if (!done) {     // oversized batch or no pinned memory: pageable source, keep it alive until the copy has run
+            if (hipMemcpyAsync(d_scratch, cd.data(), bytes, hipMemcpyHostToDevice, st) != hipSuccess) return VSE_E_HIP;
+            if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
+        }
+    }
     const CropDev* dcd = reinterpret_cast<const CropDev*>(d_scratch);
     uint8_t* scr = reinterpret_cast<uint8_t*>(d_scratch);
     dim3 g1(std::min((maxpix + 255) / 256, 1024), n_crops);

@@ -39,6 +39,10 @@ class Crop(C.Structure):
                 ("resized_w", C.c_int), ("rotate", C.c_int)]
 
 
+CROP_DT = np.dtype([("quad", "<f4", (4, 2)), ("frame", "<i4"), ("crop_w", "<i4"), ("crop_h", "<i4"), ("resized_w", "<i4"),
+                    ("rotate", "<i4")])
+assert CROP_DT.itemsize == C.sizeof(Crop)
+
 _lib = None
 
 
@@ -171,15 +175,15 @@ class Context:
         """crops: list of dict(quad[4][2], frame, crop_w, crop_h, resized_w, rotate) -> fp16 [n,rec_h,rec_w,8]."""
         t = self.torch
         n = len(crops)
+        # the vse_crop records are filled through a numpy view of the ctypes array (same bytes, no per-field Python loop:
+        # this sits on the GPU-idle path between the detector's boxes and the first recogniser launch)
         arr = (Crop * n)()
-        mw = mh = 1
-        for i, c in enumerate(crops):
-            for k in range(4):
-                arr[i].quad[k][0] = float(c["quad"][k][0])
-                arr[i].quad[k][1] = float(c["quad"][k][1])
-            arr[i].frame, arr[i].crop_w, arr[i].crop_h = c["frame"], c["crop_w"], c["crop_h"]
-            arr[i].resized_w, arr[i].rotate = c["resized_w"], c["rotate"]
-            mw, mh = max(mw, c["crop_w"]), max(mh, c["crop_h"])
+        rec = np.frombuffer(arr, dtype=CROP_DT, count=n)
+        rec["quad"] = np.asarray([c["quad"] for c in crops], dtype=np.float32).reshape(n, 4, 2)
+        for name in ("frame", "crop_w", "crop_h", "resized_w", "rotate"):
+            rec[name] = [c[name] for c in crops]
+        mw = max(1, int(rec["crop_w"].max())) if n else 1
+        mh = max(1, int(rec["crop_h"].max())) if n else 1
         nbytes = self.lib.vse_rec_preprocess_scratch_bytes(n, mw, mh)
         crop_ws = t.empty(nbytes, dtype=t.uint8, device=self.tdev)     # per call: groups may run on different streams
         out = t.empty((n, rec_h, rec_w, 8), dtype=t.float16, device=self.tdev)
