@@ -157,7 +157,10 @@ class Context:
         if getattr(self, "_db_ws", None) is None or self._db_ws.numel() < nbytes:
             self._db_ws = t.empty(nbytes, dtype=t.uint8, device=self.tdev)
         max_boxes = max_boxes or n * 1024
-        boxes = (Box * max_boxes)()
+        if getattr(self, "_db_boxes_cap", 0) < max_boxes:           # reused across calls (2.6 MB for 64 frames; only nb.value
+            self._db_boxes = (Box * max_boxes)()                    # records are read back, and they are copied below)
+            self._db_boxes_cap = max_boxes
+        boxes = self._db_boxes
         nb = C.c_int(0)
         prm = DbParams(thresh, box_thresh, unclip_ratio, max_candidates, min_size)
         _check(self.lib.vse_db_postprocess(self.handle, C.c_void_p(prob.data_ptr()), n, h, w, src_h, src_w,
@@ -165,10 +168,18 @@ class Context:
                                            max_boxes, C.byref(nb), self.stream()), "vse_db_postprocess")
         arr = np.frombuffer(boxes, dtype=np.dtype([("pts", "<f4", (4, 2)), ("score", "<f4"), ("frame", "<i4")]),
                             count=nb.value)
+        # records come grouped by frame in ascending order: split by counts instead of 64 boolean masks
         out = []
-        for f in range(n):
-            sel = arr[arr["frame"] == f]
-            out.append((sel["pts"].copy(), sel["score"].copy()))
+        if nb.value and np.all(np.diff(arr["frame"]) >= 0):
+            cnt = np.bincount(arr["frame"], minlength=n)
+            end = np.cumsum(cnt)
+            pts, sc = arr["pts"].copy(), arr["score"].copy()
+            for f in range(n):
+                out.append((pts[end[f] - cnt[f]:end[f]], sc[end[f] - cnt[f]:end[f]]))
+        else:
+            for f in range(n):
+                sel = arr[arr["frame"] == f]
+                out.append((sel["pts"].copy(), sel["score"].copy()))
         return out
 
     def rec_preprocess(self, frames_u8, crops, rec_h, rec_w):

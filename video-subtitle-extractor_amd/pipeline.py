@@ -93,9 +93,25 @@ class OcrPipeline:
     # ---- recognition -------------------------------------------------------------------------------------
     def _crop_specs(self, boxes_per_frame):
         specs = []
+        # crop sizes for all boxes at once when the corners are integer-valued (DB boxes always are): the squared side
+        # lengths are then exact in float32, so the batched sqrt(x0^2 + x1^2) equals np.linalg.norm's sqrt(dot(x, x)) bit
+        # for bit; otherwise the per-box form of the reference is kept.  (This runs while the GPU waits for the crops.)
+        flat = [np.asarray(q, np.float32).reshape(4, 2) for boxes in boxes_per_frame for q in boxes]
+        geo = None
+        if flat:
+            Q = np.stack(flat)
+            if np.all(Q == np.rint(Q)) and np.abs(Q).max() < 4000:
+                def side(a, b):
+                    d = Q[:, a] - Q[:, b]
+                    return np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1])
+                cws = np.maximum(side(0, 1), side(2, 3)).astype(np.int64)
+                chs = np.maximum(side(0, 3), side(1, 2)).astype(np.int64)
+                geo = [(int(a), int(b), 1 if (a > 0 and b * 1.0 / a >= 1.5) else 0) for a, b in zip(cws, chs)]
+        gi = 0
         for f, boxes in enumerate(boxes_per_frame):
             for k, q in enumerate(boxes):
-                cw, ch, rot = crop_geometry(q)
+                cw, ch, rot = geo[gi] if geo is not None else crop_geometry(q)
+                gi += 1
                 iw, ih = (ch, cw) if rot else (cw, ch)
                 specs.append(dict(frame=f, slot=k, quad=np.asarray(q, np.float32), crop_w=max(cw, 1),
                                   crop_h=max(ch, 1), rotate=rot, ratio=(iw / float(ih)) if ih > 0 else 1.0,
