@@ -7,7 +7,9 @@ from oracle import ir_emul, net_ref
 pytestmark = pytest.mark.gpu
 
 CASES = [("V4_ch_det", (2, 3, 96, 160)), ("V4_ch_det", (1, 3, 128, 256)),    # 2nd shape: 9x9 convs on 16-row big-patch tiles
-         ("V4_ch_det", (1, 3, 160, 224)),                                        # ragged tile edges in both directions ("V4_ch_det_fast", (2, 3, 96, 160)), ("V3_ch_det_fast", (1, 3, 96, 160)),
+         ("V4_ch_det", (1, 3, 160, 224)),                                        # ragged tile edges in both directions
+         ("V4_ch_det", (2, 3, 96, 224)),                                         # head kernel: half-empty last column tile
+         ("V4_ch_det_fast", (2, 3, 96, 160)), ("V3_ch_det_fast", (1, 3, 96, 160)),
          ("V2_ch_det", (1, 3, 64, 96)), ("V4_ch_rec", (3, 3, 48, 200)), ("V4_ch_rec_fast", (2, 3, 48, 320)),
          ("V4_en_rec_fast", (6, 3, 48, 352)), ("V3_ch_rec_fast", (2, 3, 48, 160)), ("V3_latin_rec_fast", (2, 3, 48, 160)),
          ("V2_ch_rec", (2, 3, 32, 128))]
