@@ -980,7 +980,8 @@ class Compiler:
             out.segs, out.span = list(x.segs), x.span
             if out.buf.ld != x.span:
                 out = View(self.new_buf(x.n, 1, 1, x.span), 0, x.n, 1, 1, list(x.segs), x.span)
-            splits = max(1, min(64, (x.h * x.w) // 2048))
+            # enough blocks to hide the load latency on small maps too (one block streams 64 channels of h*w/splits pixels)
+            splits = max(1, min(64, (x.h * x.w) // 256))
             sb = self.new_buf(x.n, splits, 1, x.span, esize=4)
             scratch = View(sb, 0, x.n, splits, 1, [(0, x.span)], x.span)
             self.emit(ir.OP_GAP, name, [x, None, scratch], out)

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void gap_partial_kernel(TView in, float* __res
     const long p0 = s * per, p1 = min(hw, p0 + per);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (g < cg) {
+#pragma unroll 4
         for (long pp = p0 + pl; pp < p1; pp += 32) {
             const half8 x = ld8(in, n * hw + pp, g * 8);
 #pragma unroll
