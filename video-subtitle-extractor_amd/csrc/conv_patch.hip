@@ -46,8 +46,8 @@
 #define TR_STAMP(i) do { } while (0)
 #endif
 
-// BIGP (BN = 64 only): 960-pixel patch (16-row tiles under 9x9 / 7x7 filters) and a 64-row weight ring:
-//   2 x 60 KiB patch + 4 x 8 KiB ring + 4 KiB dummy = 156 KiB;  otherwise 2 x 40 KiB + 4 x 16 KiB = 144 KiB.
+// MODE 1 = BIGP: 960-pixel patch (16-row tiles under 9x9 / 7x7 / 5x5 filters) and a TWO-stage weight ring of 4-tap stages:
+//   2 x 60 KiB patch + 2 x 16 KiB ring + 4 KiB dummy = 156 KiB;  MODE 0: 2 x 40 KiB + 4 x 16 KiB = 144 KiB.
 // MODE 2 = LIGHT (3x3 / 1xk filters on 8-row tiles): 352-pixel patch, ONE tap per step, 64 or 128 couts per tile:
 //   2 x 22 KiB patch + 4 x {4 | 8} KiB ring + dummies = 61 / 79 KiB -> TWO blocks per CU (4 waves per SIMD), the
 //   occupancy the implicit-GEMM kernel has, with the patch kernel's activation reuse.
@@ -61,18 +61,20 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
     constexpr int PPIX = BIGP ? 960 : LIGHT ? 352 : 640;   // patch capacity in pixels
     constexpr int PNPL = BIGP ? 8 : LIGHT ? 3 : 5;  // patch DMAs per thread per chunk (512 threads x 16 B each)
     constexpr int RROWS = LIGHT ? BN : 64;          // weight rows per tap in a ring stage
-    constexpr int TPS = BIGP ? 2 : LIGHT ? 1 : 4;   // filter taps per step: 16 / 8 / 32 MFMAs per wave between barriers
+    constexpr int TPS = LIGHT ? 1 : 4;              // filter taps per step: 8 / 32 MFMAs per wave between barriers
+    constexpr int RING = BIGP ? 2 : PRING;          // weight ring stages (the 960-pixel patch leaves room for 2 x 16 KiB)
+    constexpr int LOOK = RING - 1;                  // stages in flight ahead of the one being consumed
     constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = TPS * RROWS * 32;
     // landing zone of surplus DMAs (whole wave instructions past the patch / past a 64-row weight stage)
     constexpr int DUMMY_HALFS = BIGP ? 4 * 512 : LIGHT ? (2 + (BN == 64 ? 4 : 0)) * 512 : 0;
     static_assert(BN == 64 || (LIGHT && BN == 128), "cout tile");
-    __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + PRING * WSTAGE_HALFS + DUMMY_HALFS + 4 * BN];   // the ONLY LDS object
+    __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + RING * WSTAGE_HALFS + DUMMY_HALFS + 4 * BN];   // the ONLY LDS object
     // ... + BN floats of bias + BN floats of F_DOT1 projection weights
-    float* const sbias = reinterpret_cast<float*>(lds + 2 * PATCH_HALFS + PRING * WSTAGE_HALFS + DUMMY_HALFS);
+    float* const sbias = reinterpret_cast<float*>(lds + 2 * PATCH_HALFS + RING * WSTAGE_HALFS + DUMMY_HALFS);
     float* const sdotw = sbias + BN;
     half_t* const patch0 = lds;
     half_t* const ring0 = lds + 2 * PATCH_HALFS;
-    half_t* const dummy0 = ring0 + PRING * WSTAGE_HALFS;   // BIGP: landing zone of the 4 surplus patch DMAs
+    half_t* const dummy0 = ring0 + RING * WSTAGE_HALFS;   // BIGP: landing zone of the 4 surplus patch DMAs
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -141,12 +143,10 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
         }
     };
     auto issue_w = [&](int s) {                            // ring stage = taps 2s, 2s+1 of the packed stream
-        half_t* st = ring0 + (s & (PRING - 1)) * WSTAGE_HALFS;
+        half_t* st = ring0 + (s & (RING - 1)) * WSTAGE_HALFS;
         if constexpr (LIGHT) {
             if (BN == 128 || wave < 4) glds16(wptr, st + wave * 16 * 32);
             else glds16(p.zero, dummy0 + (wave - 2) * 512);                  // keeps every wave's vmcnt arithmetic alike
-        } else if constexpr (BIGP) {
-            glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
         } else {
             // waves 0-3: taps 0 and 2 of the step, waves 4-7: taps 1 and 3
             glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
@@ -179,9 +179,8 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
     conv_stage_consts(sbias, p.bias, p.zero, n0, BN, p.Np, wave, lane);                      // waves 0 .. BN/64-1
     if (p.flags & F_DOT1) conv_stage_consts(sdotw, p.dotw, p.zero, n0, BN, p.Np, wave - 4, lane);   // waves 4 ..
     issue_patch(0, 0);
-    issue_w(0);
-    issue_w(1);
-    issue_w(2);
+#pragma unroll
+    for (int k = 0; k < LOOK; ++k) issue_w(k);
 
     int s = 0;
     for (int cc = 0; cc < nchunks; ++cc) {
@@ -202,8 +201,10 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
                 if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             } else if constexpr (BIGP) {
-                if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                // 2-stage ring: the stage consumed now is the youngest weight DMA; only the next chunk's patch DMAs, issued
+                // AFTER it in the previous step, may still fly
+                if (pr == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else {
                 if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -217,10 +218,15 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
             if (s == 0) TR_STAMP(2);
 #endif
 #if VSE_ABLATE != 3
-            if (pr == 0) issue_patch(cc + 1, (cc + 1) & 1);
-            issue_w(s + 3);
+            if constexpr (BIGP) {                          // weights first: the patch may then outlive the next wait
+                issue_w(s + LOOK);
+                if (pr == 0) issue_patch(cc + 1, (cc + 1) & 1);
+            } else {
+                if (pr == 0) issue_patch(cc + 1, (cc + 1) & 1);
+                issue_w(s + LOOK);
+            }
 #endif
-            const unsigned wsb = (unsigned)(s & (PRING - 1)) * (WSTAGE_HALFS * 2);
+            const unsigned wsb = (unsigned)(s & (RING - 1)) * (WSTAGE_HALFS * 2);
             const char* const pb = reinterpret_cast<const char*>(pbuf);
 #pragma unroll
             for (int h = 0; h < TPS; ++h) {
