@@ -4,9 +4,9 @@
 R=$GRAFT_REPO_ROOT; cd $R/video-subtitle-extractor_amd/csrc
 OBJS="build/vse_runtime.hip.o build/conv_mfma.hip.o build/conv_gemm.hip.o build/conv_patch.hip.o build/conv_head.hip.o build/simple_ops.hip.o build/prepost.hip.o"
 for A in ${ABL:-0 1 2 3 4}; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DVSE_ABLATE=$A -c conv_patch.hip -o build/conv_patch.hip.o build/conv_head.hip.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DVSE_ABLATE=$A -c conv_patch.hip -o build/conv_patch.hip.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvse_hip.so $OBJS
   echo "ABLATE=$A"; (cd $R && python tools/gpu_profile_net.py V4_ch_det 16 544 960 --top 70 2>&1 | grep -E "op 65 |op 99 |op 96 |op 89 |op 69 " )
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -c conv_patch.hip -o build/conv_patch.hip.o build/conv_head.hip.o 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -c conv_patch.hip -o build/conv_patch.hip.o 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvse_hip.so $OBJS
