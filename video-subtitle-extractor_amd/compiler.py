@@ -791,11 +791,11 @@ class Compiler:
             ins.append(inv.parts[1])
         dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch_std and th == 16 and coutp <= 128) else None
         if patch:
-            # taps padded to whole kernel steps (1 tap in the LIGHT variant, else 4), channels to 32
+            # taps padded to whole kernel steps (2 taps in the LIGHT variant, else 4), channels to 32
             light = light_ok and dot is None
             assert light or patch_std
             big = (not light) and th == 16 and (16 + kh - 1) * (32 + kw - 1) > 640
-            ptaps = kh * kw if light else rup(kh * kw, 4)
+            ptaps = rup(kh * kw, 2 if light else 4)
             Kp = ptaps * rup(inv.span, 32)
         # DB head of the PP-OCRv4 server detector: 3x3 over [1-channel full-res map, x2-upsampled 64-channel map] with
         # the fused 1-channel projection -> evaluated on the low-res grid with folded 2x2 taps (conv_head.hip)

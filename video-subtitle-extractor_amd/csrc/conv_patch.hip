@@ -48,8 +48,8 @@
 
 // MODE 1 = BIGP: 960-pixel patch (16-row tiles under 9x9 / 7x7 / 5x5 filters) and a TWO-stage weight ring of 4-tap stages:
 //   2 x 60 KiB patch + 2 x 16 KiB ring + 4 KiB dummy = 156 KiB;  MODE 0: 2 x 40 KiB + 4 x 16 KiB = 144 KiB.
-// MODE 2 = LIGHT (3x3 / 1xk filters on 8-row tiles): 352-pixel patch, ONE tap per step, 64 or 128 couts per tile:
-//   2 x 22 KiB patch + 4 x {4 | 8} KiB ring + dummies = 61 / 79 KiB -> TWO blocks per CU (4 waves per SIMD), the
+// MODE 2 = LIGHT (3x3 / 1xk filters on 8-row tiles): 352-pixel patch, TWO taps per step, 64 or 128 couts per tile:
+//   2 x 22 KiB patch + 2 x {8 | 16} KiB ring + dummies = 63 / 79 KiB -> TWO blocks per CU (4 waves per SIMD), the
 //   occupancy the implicit-GEMM kernel has, with the patch kernel's activation reuse.
 template <int PTH, int BN, int MODE>
 __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(const ConvParams p) {
@@ -61,12 +61,12 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
     constexpr int PPIX = BIGP ? 960 : LIGHT ? 352 : 640;   // patch capacity in pixels
     constexpr int PNPL = BIGP ? 8 : LIGHT ? 3 : 5;  // patch DMAs per thread per chunk (512 threads x 16 B each)
     constexpr int RROWS = LIGHT ? BN : 64;          // weight rows per tap in a ring stage
-    constexpr int TPS = LIGHT ? 1 : 4;              // filter taps per step: 8 / 32 MFMAs per wave between barriers
-    constexpr int RING = BIGP ? 2 : PRING;          // weight ring stages (the 960-pixel patch leaves room for 2 x 16 KiB)
+    constexpr int TPS = LIGHT ? 2 : 4;              // filter taps per step: 16 / 32 MFMAs per wave between barriers
+    constexpr int RING = (BIGP || LIGHT) ? 2 : PRING;   // weight ring stages (2 where LDS is tight: 960-pixel patch, two blocks per CU)
     constexpr int LOOK = RING - 1;                  // stages in flight ahead of the one being consumed
     constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = TPS * RROWS * 32;
     // landing zone of surplus DMAs (whole wave instructions past the patch / past a 64-row weight stage)
-    constexpr int DUMMY_HALFS = BIGP ? 4 * 512 : LIGHT ? (2 + (BN == 64 ? 4 : 0)) * 512 : 0;
+    constexpr int DUMMY_HALFS = BIGP ? 4 * 512 : LIGHT ? 2 * 512 : 0;
     static_assert(BN == 64 || (LIGHT && BN == 128), "cout tile");
     __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + RING * WSTAGE_HALFS + DUMMY_HALFS + 4 * BN];   // the ONLY LDS object
     // ... + BN floats of bias + BN floats of F_DOT1 projection weights
@@ -120,12 +120,12 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
     }
     // weight DMA: thread -> cout row (tid>>2)&63; waves 0-3 fetch the even taps of a step, waves 4-7 the odd ones
     // (BIGP: 2 taps per step = 1 DMA per thread; otherwise 4 taps per step = 2 DMAs per thread)
-    const int wr = LIGHT ? (tid >> 2) : ((tid >> 2) & 63);     // LIGHT: one tap per step, thread -> row 0..127
+    const int wr = (LIGHT && BN == 128) ? (tid >> 2) : ((tid >> 2) & 63);     // 128-cout tiles: thread -> row 0..127
     const bool wok = (wr < BN) && (n0 + wr < p.Np);
     // running DMA source of this thread: advanced by one step (TPS taps) per issue_w; the compiler appends
     // PATCH_WPAD_STEPS zero steps to the packed stream, so the look-ahead past the last real step reads real zeros
     // (no select in the loop); rows beyond the cout range park on the zero page and never move
-    const half_t* wptr = wok ? p.w + (long)(n0 + wr) * 32 + kv * 8 + (LIGHT ? 0 : (long)(wave >> 2) * p.Np * 32) : p.zero;
+    const half_t* wptr = wok ? p.w + (long)(n0 + wr) * 32 + kv * 8 + ((LIGHT && BN == 128) ? 0 : (long)(wave >> 2) * p.Np * 32) : p.zero;
     const long winc = wok ? (long)p.Np * 32 * TPS : 0;
 
     auto issue_patch = [&](int cc, int buf) {
@@ -144,9 +144,11 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
     };
     auto issue_w = [&](int s) {                            // ring stage = taps 2s, 2s+1 of the packed stream
         half_t* st = ring0 + (s & (RING - 1)) * WSTAGE_HALFS;
-        if constexpr (LIGHT) {
-            if (BN == 128 || wave < 4) glds16(wptr, st + wave * 16 * 32);
-            else glds16(p.zero, dummy0 + (wave - 2) * 512);                  // keeps every wave's vmcnt arithmetic alike
+        if constexpr (LIGHT && BN == 128) {          // two taps x 128 rows: both taps from every thread
+            glds16(wptr, st + wave * 16 * 32);
+            glds16(wptr + (wok ? (long)p.Np * 32 : 0), st + RROWS * 32 + wave * 16 * 32);
+        } else if constexpr (LIGHT) {                // two taps x 64 rows: waves 0-3 tap 0, waves 4-7 tap 1
+            glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
         } else {
             // waves 0-3: taps 0 and 2 of the step, waves 4-7: taps 1 and 3
             glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
@@ -197,9 +199,9 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
 #ifdef VSE_TRACE
             const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
 #endif
-            if constexpr (LIGHT) {
-                if (pr == 1 || pr == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if constexpr (LIGHT) {                         // 2-stage ring as below, 3 patch DMAs per thread
+                if (pr == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             } else if constexpr (BIGP) {
                 // 2-stage ring: the stage consumed now is the youngest weight DMA; only the next chunk's patch DMAs, issued
                 // AFTER it in the previous step, may still fly
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
             if (s == 0) TR_STAMP(2);
 #endif
 #if VSE_ABLATE != 3
-            if constexpr (BIGP) {                          // weights first: the patch may then outlive the next wait
+            if constexpr (BIGP || LIGHT) {                 // weights first: the patch may then outlive the next wait
                 issue_w(s + LOOK);
                 if (pr == 0) issue_patch(cc + 1, (cc + 1) & 1);
             } else {
