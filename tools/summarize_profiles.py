@@ -3,6 +3,12 @@
 
   gpurun_out/prof_rNN/bench_kernel_stats.csv      -> profiles/rNN_kernel_stats.csv   (verbatim, top rows)
   gpurun_out/pmc_fetch + pmc_write counter CSVs    -> profiles/rNN_traffic.json       (HBM bytes per launch per kernel)
+  gpurun_out/pmc_sq counter CSV                    -> profiles/rNN_mfma_busy.json     (matrix-pipe busy fraction per kernel)
+
+MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES counts shader cycles summed over the chip's 1024 SIMDs (32 per
+v_mfma_f32_32x32x16_f16, MI355X_MICROARCH.md per-instruction table), so busy fraction = counter / (kernel duration in
+ns x 2.4 GHz x 1024); at 1024 FLOP per SIMD-cycle this is also (padded FLOP/s) / 2.5 PFLOP/s.  The wave-state
+fractions are the SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY shares of SQ_WAVE_CYCLES (disjoint buckets).
 
 HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE are collected in SEPARATE
 --pmc passes, are in KiB, and on gfx950 FETCH_SIZE reports exactly half of the bytes of wide coalesced reads, so
@@ -60,6 +66,43 @@ def main():
                                  "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction)",
                        "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_fetch_pass"]))},
                       fh, indent=1)
+    sq = os.path.join(go, "pmc_sq", "bench_counter_collection.csv")
+    if os.path.exists(sq):
+        cnt = collections.defaultdict(lambda: collections.defaultdict(float))
+        dur = collections.defaultdict(float)
+        launches = collections.Counter()
+        seen = set()
+        for r in csv.DictReader(open(sq)):
+            k = short(r["Kernel_Name"])
+            cnt[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Dispatch_Id"] not in seen:
+                seen.add(r["Dispatch_Id"])
+                dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                launches[k] += 1
+        total = sum(dur.values())
+        ks = {}
+        for k in sorted(dur, key=lambda k: -dur[k]):
+            c = cnt[k]
+            if dur[k] < 0.002 * total:
+                continue
+            wc = max(c.get("SQ_WAVE_CYCLES", 0.0), 1.0)
+            ks[k] = {"launches": launches[k], "total_us": round(dur[k] / 1e3, 1), "share_of_gpu_time": round(dur[k] / total, 4),
+                     "mfma_busy_frac": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (dur[k] * 2.4 * 1024), 4),
+                     "mfma_mops_f16_per_us": round(c.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0.0) / (dur[k] / 1e3), 1),
+                     "grbm_gui_active_over_duration": round(c.get("GRBM_GUI_ACTIVE", 0.0) / (dur[k] * 2.4), 3),
+                     "wave_wait_any": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 3),
+                     "wave_wait_inst_any": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3),
+                     "wave_active_inst_any": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3)}
+        conv = [k for k in ks if k.startswith("conv_")]
+        tot_busy = sum(cnt[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for k in conv)
+        tot_dur = sum(dur[k] for k in conv)
+        with open(os.path.join(out, f"{tag}_mfma_busy.json"), "w") as fh:
+            json.dump({"method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
+                                 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE over "
+                                 "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline`; "
+                                 "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (duration_ns * 2.4 * 1024 SIMDs)",
+                       "all_conv_kernels_mfma_busy_frac": round(tot_busy / (tot_dur * 2.4 * 1024), 4) if tot_dur else None,
+                       "kernels": ks}, fh, indent=1)
     print("wrote", sorted(os.listdir(out)))
 
 

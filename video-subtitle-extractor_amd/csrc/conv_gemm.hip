@@ -52,7 +52,7 @@ void conv_gemm_kernel(const ConvParams p) {
     constexpr int LPT = NA + NB;
     constexpr int STAGE_HALFS = (BM + BNR) * BKT;
     static_assert(BKT == 32 || BKT == 64, "BK");
-    static_assert(ST >= 2 && ST <= 4 && (ST - 2) * LPT <= 16, "ring depth");
+    static_assert(ST >= 2 && ST <= 5 && (ST - 2) * LPT <= 16, "ring depth");
     static_assert(TM >= 1 && TN >= 1 && NA >= 1 && NB >= 1 && BM % (RPI * NW) == 0 && BNR % (RPI * NW) == 0, "tile shape");
     static_assert(ST * STAGE_HALFS * 2 + BN * 4 <= 160 * 1024, "LDS");
 
@@ -186,7 +186,8 @@ void conv_gemm_kernel(const ConvParams p) {
         // tile kt has landed once only the loads of the ST-2 tiles behind it can be outstanding (vmcnt retires in order)
         const int rem = p.nk - 1 - kt;
         if (rem >= ST - 2) wait_vm<(ST - 2) * LPT>();
-        else if (ST == 4 && rem == 1) wait_vm<LPT>();
+        else if (ST >= 5 && rem == 2) wait_vm<2 * LPT>();
+        else if (ST >= 4 && rem == 1) wait_vm<LPT>();
         else wait_vm<0>();
 #if VSE_ABLATE != 1
         __builtin_amdgcn_s_barrier();              // every thread's part of tile kt is in LDS; compute(kt-1) is over
@@ -238,6 +239,7 @@ void conv_gemm_kernel(const ConvParams p) {
         step(std::integral_constant<int, 1>{}); ++kt;
         if constexpr (ST >= 3) { step(std::integral_constant<int, 2>{}); ++kt; }
         if constexpr (ST >= 4) { step(std::integral_constant<int, 3>{}); ++kt; }
+        if constexpr (ST >= 5) { step(std::integral_constant<int, 4>{}); ++kt; }
     }
     if (kt < p.nk) {
         step(std::integral_constant<int, 0>{}); ++kt;
@@ -246,6 +248,9 @@ void conv_gemm_kernel(const ConvParams p) {
         }
         if constexpr (ST >= 4) {
             if (kt < p.nk) { step(std::integral_constant<int, 2>{}); ++kt; }
+        }
+        if constexpr (ST >= 5) {
+            if (kt < p.nk) { step(std::integral_constant<int, 3>{}); ++kt; }
         }
     }
 
@@ -286,7 +291,10 @@ int conv_gemm_mode(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int
 // the names).  Measured and dropped on MI355X (tools/bench_conv.py): BK = 64 rings with 2-3 stages (fewer
 // bytes in flight per CU, -5..-25 %), 4-stage 128 x 128 (2 blocks/CU, -10 %), 512 x 128, 8-wave 256 x 256 (VGPR
 // spills), and a persistent one-block-per-slot variant of every shape (-5..-15 %: the hardware already overlaps
-// one block's store tail with its neighbours' K loops, and stores share vmcnt with the LDS-DMAs).
+// one block's store tail with its neighbours' K loops, and stores share vmcnt with the LDS-DMAs); 4-stage rings for
+// the 16-wave tiles (128 / 112 KiB, 0..-12 %: more bytes in flight do not help, tools/ubench/fill.hip shows why: the
+// L2 takes ~1 request per channel clock, i.e. ~32 B/clk/CU of 64-byte row segments chip-wide, HBM streams at ~10 B/clk/CU,
+// and a stream that mixes both gets ~15 B/clk/CU), BK 64 / 2 stages for 256 x 256 (8x slower: spills).
 //   0: 128 x 128,  4 waves (2 x 2), BK 32, 3 stages  (48 KiB LDS, 3 blocks/CU)  — the conv_mfma_kernel shape
 //   1: 256 x  64,  4 waves (4 x 1), BK 32, 3 stages  (60 KiB, 2 blocks/CU)
 //   2: 256 x  32,  4 waves (4 x 1), BK 32, 3 stages
