@@ -6,7 +6,7 @@ OBJS="build/vse_runtime.hip.o build/conv_mfma.hip.o build/conv_gemm.hip.o build/
 for A in ${ABL:-0 1 2 3 4}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DVSE_ABLATE=$A -c conv_patch.hip -o build/conv_patch.hip.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvse_hip.so $OBJS
-  echo "ABLATE=$A"; (cd $R && python tools/gpu_profile_net.py V4_ch_det 16 544 960 --top 70 2>&1 | grep -E "op 65 |op 99 |op 96 |op 89 |op 69 " )
+  echo "ABLATE=$A"; (cd $R && python tools/gpu_profile_net.py V4_ch_det 16 544 960 --top 70 2>&1 | grep -E "op 65 |op  2 |op  4 |op 96 |op 89 |op 69 " )
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -c conv_patch.hip -o build/conv_patch.hip.o 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvse_hip.so $OBJS

@@ -40,6 +40,17 @@ __device__ __forceinline__ void glds16(const void* g, half_t* l) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)l, 16, 0, 0);
 }
 
+// The same DMA as an asm statement, hidden from hipcc's s_waitcnt bookkeeping: with the builtin inside a loop, hipcc
+// (ROCm 7.2) drains lgkmcnt to 0 in front of every DMA and degrades every LDS wait of the loop to lgkmcnt(0), which
+// defeats fragment prefetching.  The caller counts completion itself (s_waitcnt vmcnt(N) + barrier before the ds_reads)
+// and guarantees that no ds_read of the destination is outstanding.  M0 (destination base) is saved and restored.
+__device__ __forceinline__ void glds16_asm(const void* g, half_t* l) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)l);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(dst) : "memory");
+}
+
 // Buffer-addressed LDS-DMA helpers (conv_gemm.hip): an offset with bit 31 set is out of range for the
 // 2 GiB descriptors these kernels build, so the DMA writes zeros.
 #define OOB 0x80000000u
@@ -111,12 +122,22 @@ template <int N> __device__ __forceinline__ void vse_act_n(float (&v)[N], int co
 // The staging itself is a 4-byte-per-lane LDS-DMA issued BEFORE the prologue DMAs: it is then the oldest entry of the
 // issuing wave's vmcnt queue, so every counted wait of the K loop covers it without changing a literal, no VGPR is
 // involved and the compiler adds no wait of its own.  Wave w stages couts 64w .. 64w+63 of the block's cout tile.
+// ASM = true issues it as an asm statement (kernels whose other DMAs are glds16_asm: ONE builtin LDS-DMA anywhere in a
+// kernel is enough for hipcc to drop counted lgkmcnt waits everywhere in it).
+template <bool ASM = false>
 __device__ __forceinline__ void conv_stage_consts(float* dst, const float* src, const half_t* zero, int n0, int bn, int Np,
                                                   int wave, int lane) {
     if (wave >= 0 && wave * 64 < bn) {
         const int c = wave * 64 + lane;
         const void* g = (c < bn && n0 + c < Np) ? (const void*)(src + n0 + c) : (const void*)zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + wave * 64), 4, 0, 0);
+        if constexpr (ASM) {
+            unsigned keep;
+            const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)(dst + wave * 64));
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(g), "s"(d) : "memory");
+        } else {
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + wave * 64), 4, 0, 0);
+        }
     }
 }
 // `tab` = the staged table of this block's cout tile, `c` = first cout of the 32-cout accumulator tile inside it

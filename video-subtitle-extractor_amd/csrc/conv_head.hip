@@ -64,8 +64,8 @@ __global__ __launch_bounds__(512) void conv_head_up2_kernel(const ConvParams p) 
 
     // ---- prologue: everything but the weight stream is staged once --------------------------------------------------
     const int kv = (lane & 3) ^ ((lane >> 4) & 3);           // logical k-vector this lane fetches (source-side swizzle)
-    conv_stage_consts(sbias, p.bias, p.zero, 0, 64, p.Np, wave, lane);            // wave 0
-    conv_stage_consts(sdotw, p.dotw, p.zero, 0, 64, p.Np, wave - 4, lane);        // wave 4
+    conv_stage_consts<true>(sbias, p.bias, p.zero, 0, 64, p.Np, wave, lane);            // wave 0
+    conv_stage_consts<true>(sdotw, p.dotw, p.zero, 0, 64, p.Np, wave - 4, lane);        // wave 4
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -75,16 +75,16 @@ __global__ __launch_bounds__(512) void conv_head_up2_kernel(const ConvParams p) 
             const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
             const bool ok = (q < HP) && (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
             const half_t* src = ok ? p.in2 + ((img * Hl + iy) * Wl + ix) * (long)p.in2_ld + c * 32 + kv * 8 : p.zero;
-            glds16(src, patch0 + c * PATCHC_HALFS + (wave + 8 * j) * 16 * 32);
+            glds16_asm(src, patch0 + c * PATCHC_HALFS + (wave + 8 * j) * 16 * 32);
         }
     const half_t* const wu = p.w + (long)NSTEP * WSTAGE_HALFS;
-    if (wave < 4) glds16(wu + (wave * 16 + (lane >> 2)) * 32 + kv * 8, uw0 + wave * 16 * 32);
+    if (wave < 4) glds16_asm(wu + (wave * 16 + (lane >> 2)) * 32 + kv * 8, uw0 + wave * 16 * 32);
     // weight ring: thread -> cout row (tid>>2)&63; waves 0-3 fetch taps 0 and 2 of a stage, waves 4-7 taps 1 and 3
     const half_t* wptr = p.w + ((long)(wave >> 2) * 64 + ((tid >> 2) & 63)) * 32 + kv * 8;
     auto issue_w = [&](int s) __attribute__((always_inline)) {
         half_t* st = ring0 + (s & 3) * WSTAGE_HALFS;
-        glds16(wptr, st + (wave >> 2) * 64 * 32 + (wave & 3) * 16 * 32);
-        glds16(wptr + 2 * 64 * 32, st + (2 + (wave >> 2)) * 64 * 32 + (wave & 3) * 16 * 32);
+        glds16_asm(wptr, st + (wave >> 2) * 64 * 32 + (wave & 3) * 16 * 32);
+        glds16_asm(wptr + 2 * 64 * 32, st + (2 + (wave >> 2)) * 64 * 32 + (wave & 3) * 16 * 32);
         wptr += WSTAGE_HALFS;
     };
     issue_w(0);

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
     constexpr int RROWS = LIGHT ? BN : 64;          // weight rows per tap in a ring stage
     constexpr int TPS = LIGHT ? 2 : 4;              // filter taps per step: 16 / 32 MFMAs per wave between barriers
     constexpr int RING = (BIGP || LIGHT) ? 2 : PRING;   // weight ring stages (2 where LDS is tight: 960-pixel patch, two blocks per CU)
+    constexpr bool PIPE = VSE_ABLATE == 0 && !(LIGHT && BN == 128);   // fast step (below); the 128-cout LIGHT tile has no registers to spare
     constexpr int LOOK = RING - 1;                  // stages in flight ahead of the one being consumed
     constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = TPS * RROWS * 32;
     // landing zone of surplus DMAs (whole wave instructions past the patch / past a 64-row weight stage)
@@ -139,20 +140,20 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
             half_t* dst = base + (wave + 8 * j) * 16 * 32;
             if (BIGP && j == PNPL - 1 && wave >= 4) { src = p.zero; dst = dummy0 + (wave - 4) * 512; }   // pixels >= 960
             if (LIGHT && j == PNPL - 1 && wave >= 6) { src = p.zero; dst = dummy0 + (wave - 6) * 512; }  // pixels >= 352
-            glds16(src, dst);
+            glds16_asm(src, dst);
         }
     };
     auto issue_w = [&](int s) {                            // ring stage = taps 2s, 2s+1 of the packed stream
         half_t* st = ring0 + (s & (RING - 1)) * WSTAGE_HALFS;
         if constexpr (LIGHT && BN == 128) {          // two taps x 128 rows: both taps from every thread
-            glds16(wptr, st + wave * 16 * 32);
-            glds16(wptr + (wok ? (long)p.Np * 32 : 0), st + RROWS * 32 + wave * 16 * 32);
+            glds16_asm(wptr, st + wave * 16 * 32);
+            glds16_asm(wptr + (wok ? (long)p.Np * 32 : 0), st + RROWS * 32 + wave * 16 * 32);
         } else if constexpr (LIGHT) {                // two taps x 64 rows: waves 0-3 tap 0, waves 4-7 tap 1
-            glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
+            glds16_asm(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
         } else {
             // waves 0-3: taps 0 and 2 of the step, waves 4-7: taps 1 and 3
-            glds16(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
-            glds16(wptr + (wok ? (long)p.Np * 64 : 0), st + (2 + (wave >> 2)) * RROWS * 32 + (wave & 3) * 16 * 32);
+            glds16_asm(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
+            glds16_asm(wptr + (wok ? (long)p.Np * 64 : 0), st + (2 + (wave >> 2)) * RROWS * 32 + (wave & 3) * 16 * 32);
         }
         wptr += winc;
     };
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     TR_STAMP(1);
-    conv_stage_consts(sbias, p.bias, p.zero, n0, BN, p.Np, wave, lane);                      // waves 0 .. BN/64-1
-    if (p.flags & F_DOT1) conv_stage_consts(sdotw, p.dotw, p.zero, n0, BN, p.Np, wave - 4, lane);   // waves 4 ..
+    conv_stage_consts<true>(sbias, p.bias, p.zero, n0, BN, p.Np, wave, lane);                      // waves 0 .. BN/64-1
+    if (p.flags & F_DOT1) conv_stage_consts<true>(sdotw, p.dotw, p.zero, n0, BN, p.Np, wave - 4, lane);   // waves 4 ..
     issue_patch(0, 0);
 #pragma unroll
     for (int k = 0; k < LOOK; ++k) issue_w(k);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
         int tapoff = 0, dx = 0, dy = 0, tap = 0;           // tapoff = dy*PW + dx of tap
         half8 xc[2];                                       // row-1 fragments of the previous tap (k halves)
         xc[0] = xc[1] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        for (int pr = 0; pr < pairs; ++pr, ++s) {
+        auto sync_issue = [&](int pr) __attribute__((always_inline)) {
             // stages s+1, s+2 may still fly (+ the next chunk's patch DMAs when they were issued 1-2 steps ago)
 #ifdef VSE_TRACE
             const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
@@ -228,8 +229,81 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
                 issue_w(s + LOOK);
             }
 #endif
+        };
+        int pr = 0;
+        // FAST STEPS: all TPS taps are real and at most one of them starts a filter column (kh >= TPS).  Straight-line code,
+        // software-pipelined over the 2*TPS (tap, k half) groups: the fragment reads of group g+1 are issued before the MFMAs
+        // of group g into the registers of the other k half, so a wave's LDS latency hides under its own MFMAs (hipcc only
+        // counts lgkmcnt when NO LDS-DMA builtin is in the kernel: glds16_asm).  The one row-0 fragment a column start needs
+        // is read unconditionally at the top of the step (two reads per step) and selected per group by a block-uniform
+        // compare, so there is no branch between the reads.  (Reading the next step's first activation fragments across the
+        // wait + barrier was measured: +57 VGPRs from the peeled loop, 7 % slower.)
+        if (PIPE && p.kh >= TPS) {
+            for (; tap + TPS <= taps; ++pr, ++s) {
+                sync_issue(pr);
+                const unsigned wsb = (unsigned)(s & (RING - 1)) * (WSTAGE_HALFS * 2);
+                const char* const pb = reinterpret_cast<const char*>(pbuf);
+                int toff[TPS];
+                int hstar = -1, offstar = tapoff;
+#pragma unroll
+                for (int h = 0; h < TPS; ++h) {
+                    toff[h] = tapoff;
+                    hstar = dy == 0 ? h : hstar;
+                    offstar = dy == 0 ? tapoff : offstar;
+                    ++tap;
+                    const bool wrap = ++dy == p.kh;
+                    dx += wrap ? 1 : 0;
+                    tapoff = wrap ? dx : tapoff + PW;
+                    dy = wrap ? 0 : dy;
+                }
+                half8 x0s[2], wfb[2][TN], x1b[2];
+                {
+                    const unsigned q0 = (unsigned)(qb0 + offstar);
+                    const unsigned a0 = (q0 << 6) + ((fj ^ ((q0 >> 2) & 3)) << 4);
+                    x0s[0] = *reinterpret_cast<const half8*>(pb + a0);
+                    x0s[1] = *reinterpret_cast<const half8*>(pb + (a0 ^ 32u));
+                }
+                unsigned a1t[TPS];
+#pragma unroll
+                for (int h = 0; h < TPS; ++h) {
+                    const unsigned q1 = (unsigned)(qb1 + toff[h]);
+                    a1t[h] = (q1 << 6) + ((fj ^ ((q1 >> 2) & 3)) << 4);
+                }
+                auto load = [&](int g) __attribute__((always_inline)) {
+                    const int h = g >> 1, ks = g & 1;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        wfb[ks][j] = *reinterpret_cast<const half8*>(ring_b + wsb + h * (RROWS * 64) + (woffb[j] ^ (ks << 5)));
+                    x1b[ks] = *reinterpret_cast<const half8*>(pb + (a1t[h] ^ (ks << 5)));
+                };
+                auto compute = [&](int g) __attribute__((always_inline)) {
+                    const int h = g >> 1, ks = g & 1;
+                    const half8 xf0 = hstar == h ? x0s[ks] : xc[ks];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfb[ks][j], xf0, acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfb[ks][j], x1b[ks], acc[1][j], 0, 0, 0);
+                    }
+                    xc[ks] = x1b[ks];
+                };
+                load(0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 + TN + 1, 0);      // x0s, group 0
+#pragma unroll
+                for (int g = 0; g < 2 * TPS; ++g) {
+                    if (g + 1 < 2 * TPS) {
+                        load(g + 1);
+                        __builtin_amdgcn_sched_group_barrier(0x100, TN + 1, 0);  // reads of group g+1 ...
+                    }
+                    compute(g);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);      // ... then the MFMAs of group g
+                }
+            }
+        }
+        for (; pr < pairs; ++pr, ++s) {
+            sync_issue(pr);
             const unsigned wsb = (unsigned)(s & (RING - 1)) * (WSTAGE_HALFS * 2);
             const char* const pb = reinterpret_cast<const char*>(pbuf);
+            // GENERIC STEP (partial last step of a chunk, filters with fewer rows than taps per step, ablation builds)
 #pragma unroll
             for (int h = 0; h < TPS; ++h) {
                 if (h >= 1 && tap >= taps) break;          // tap count not a multiple of TPS: the appended zero-weight taps do no work
