@@ -82,7 +82,7 @@ def main():
             net = nets["p" if c == "p" else "g"]
             compiler.PATCH_MIN_K = 500 if c == "p" else 1 << 30      # plans are compiled lazily on the first run
             compiler.PATCH_MAX_COUT = 256 if c == "p" else 64       # "p": also try the patch kernel on wide layers (two+ cout tiles)
-            os.environ["VSE_GEMM_CFG"] = "" if c == "p" else c
+            os.environ["VSE_GEMM_CFG"] = "" if c in ("p", "d") else c      # "d": the launcher's own choice
             out = net.run(x)
             torch.cuda.synchronize()
             o = out[0].float()

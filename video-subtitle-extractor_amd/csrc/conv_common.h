@@ -55,6 +55,22 @@ __device__ __forceinline__ void glds16_asm(const void* g, half_t* l) {
 // 2 GiB descriptors these kernels build, so the DMA writes zeros.
 #define OOB 0x80000000u
 typedef __attribute__((address_space(3))) void* ldsv_t;
+typedef int rsrc4_t __attribute__((ext_vector_type(4)));
+// raw buffer descriptor over [base, base + 2 GiB): stride 0, num_records 0x7fffffff, dword3 0x00020000 (what
+// __builtin_amdgcn_make_buffer_rsrc builds), as four SGPRs an asm statement can take
+__device__ __forceinline__ rsrc4_t make_rsrc4(const void* base) {
+    const unsigned long long b = (unsigned long long)base;
+    return rsrc4_t{(int)__builtin_amdgcn_readfirstlane((unsigned)b), (int)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu),
+                   0x7fffffff, 0x00020000};
+}
+// `buffer_load_dwordx4 voff, rsrc, soff offen lds` as an asm statement (see glds16_asm for why); `l` is the wave-uniform
+// LDS destination.  The leading s_nop covers a descriptor / soffset SGPR freshly written by v_readfirstlane.
+__device__ __forceinline__ void bufdma16_asm(rsrc4_t rsrc, unsigned voff, int soff, const void* l) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)l);
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(dst) : "memory");
+}
 
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N <= 16, "vmcnt literal");

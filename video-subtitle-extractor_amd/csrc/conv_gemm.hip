@@ -20,6 +20,9 @@
 #include <type_traits>
 #include "conv_common.h"
 
+#ifndef VSE_GEMM_ASM
+#define VSE_GEMM_ASM 0    // 1: LDS-DMAs as asm statements (counted lgkmcnt waits survive; measured 1-3 % SLOWER here: the kernel is bound by the DMA stream, the asm form adds issue slots); 0: builtins.  A/B on one box: tools/ab_gemm.sh
+#endif
 #ifndef VSE_ABLATE
 #define VSE_ABLATE 0      // 1: no s_barrier  2: no fragment ds_reads  3: no DMA in the loop  4: no MFMA  5: no epilogue   (timing experiments only)
 #endif
@@ -87,8 +90,13 @@ void conv_gemm_kernel(const ConvParams p) {
         const long n = t / p.OH;
         pix0 = (n * p.Hs + (long)oh * p.sh - p.ph) * p.Ws + (long)ow * p.sw - p.pw;
     }
+#if VSE_GEMM_ASM
+    const rsrc4_t rsA = make_rsrc4(p.in + pix0 * p.in_ld);
+    const rsrc4_t rsW = make_rsrc4(p.w + (long)n0 * 64);
+#else
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + pix0 * p.in_ld), 0, 0x7fffffff, 0x00020000);
     const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * 64), 0, 0x7fffffff, 0x00020000);
+#endif
 
     // ---- per-thread, loop-invariant offsets ------------------------------------------------------------------
     // wave instruction j of this wave covers tile rows (j*NW + wave)*RPI .. +RPI-1; lane l -> row + l/KV, physical
@@ -137,13 +145,20 @@ void conv_gemm_kernel(const ConvParams p) {
         for (int j = 0; j < NA; ++j) {
             unsigned off = voffA[j];
             if constexpr (MASK) off |= __builtin_amdgcn_ubfe(ntap[j], (unsigned)tap, 1u) << 31;   // v_bfe_u32 + v_lshl_or_b32
+#if VSE_GEMM_ASM
+            bufdma16_asm(rsA, off, soffA, base + (j * NW + wave) * RPI * BKT);
+#else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsv_t)(base + (j * NW + wave) * RPI * BKT), 16, (int)off, soffA, 0, 0);
+#endif
         }
         const int soffW = BKT == 64 ? (int)((unsigned)kt * wstep) : (int)((unsigned)(kt >> 1) * wstep + (unsigned)(kt & 1) * 64u);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (ldsv_t)(base + BM * BKT + (j * NW + wave) * RPI * BKT), 16,
-                                                     (int)voffW[j], soffW, 0, 0);
+#if VSE_GEMM_ASM
+            bufdma16_asm(rsW, voffW[j], soffW, base + BM * BKT + (j * NW + wave) * RPI * BKT);
+#else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (ldsv_t)(base + BM * BKT + (j * NW + wave) * RPI * BKT), 16, (int)voffW[j], soffW, 0, 0);
+#endif
         kc += BKT;
         if (kc >= p.cinp) {
             kc = 0;
@@ -160,7 +175,7 @@ void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    conv_stage_consts(sbias, p.bias, p.zero, n0, BN, p.Np, wave, lane);
+    conv_stage_consts<VSE_GEMM_ASM != 0>(sbias, p.bias, p.zero, n0, BN, p.Np, wave, lane);
 #pragma unroll
     for (int s = 0; s < ST - 1; ++s)
         if (s < p.nk) issue(s, s);
