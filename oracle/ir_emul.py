@@ -161,8 +161,9 @@ class Emulator:
             row_major = [(t % kw) * kh + t // kw for t in range(taps)]     # stream is column-major: t' = dx*kh + dy
             wmat = np.ascontiguousarray(wfull[:, :taps, :cinp][:, row_major, :]).reshape(Np, taps * cinp)
         else:
-            wt = self.wread(int(r["w_off"]), (Kp // KT) * Np * KT, np.float16).astype(np.float32)
-            wmat = wt.reshape(Kp // KT, Np, KT).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]
+            kt = 32 if int(r["flags"]) & ir.F_WK32 else KT
+            wt = self.wread(int(r["w_off"]), (Kp // kt) * Np * kt, np.float16).astype(np.float32)
+            wmat = wt.reshape(Kp // kt, Np, kt).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]
         w4 = torch.from_numpy(np.ascontiguousarray(wmat.reshape(Np, kh, kw, cinp).transpose(0, 3, 1, 2)))
         bias = torch.from_numpy(self.wread(int(r["b_off"]), Np, np.float32).copy())
         y = F.conv2d(x.permute(0, 3, 1, 2), w4, bias, (sh, sw), (ph, pw)).permute(0, 2, 3, 1)

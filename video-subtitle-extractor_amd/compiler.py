@@ -138,6 +138,7 @@ PATCH_MIN_TILE_EFF = float(os.environ.get("VSE_PATCH_MINEFF", "0.5"))
 PATCH_LIGHT = int(os.environ.get("VSE_PATCH_LIGHT", "2"))
 # evaluate the PP-OCRv4 server detector's last 3x3 conv on the low-res grid (conv_head.hip); VSE_HEAD_UP2=0 keeps it on
 # the patch kernel (experiments / A-B)
+WK32 = os.environ.get("VSE_WK32", "1") != "0"      # 32-deep weight tiles for conv_gemm_kernel (contiguous wave DMAs)
 HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
 
 
@@ -596,11 +597,21 @@ class Compiler:
         return mat, coutp, Kp
 
     @staticmethod
-    def tile_weights(mat):
-        """[Np][Kp] -> [Kp/KT][Np][KT] fp16."""
+    def tile_weights(mat, kt=ir.KT):
+        """[Np][Kp] -> [Kp/kt][Np][kt] fp16."""
         npad, kp = mat.shape
-        t = mat.reshape(npad, kp // ir.KT, ir.KT).transpose(1, 0, 2)
+        t = mat.reshape(npad, kp // kt, kt).transpose(1, 0, 2)
         return np.ascontiguousarray(t).astype(np.float16)
+
+    @staticmethod
+    def gemm_eligible(kh, kw, ph, pw, cinp, inshift, flags):
+        """Mirror of conv_gemm_mode() (csrc/conv_gemm.hip): the layer runs on conv_gemm_kernel.  The launcher refuses an
+        F_WK32 op it cannot send there, so a drift between the two rules fails loudly instead of computing garbage."""
+        if os.environ.get("VSE_CONV_GEMM", "1")[:1] == "0":
+            return False
+        if inshift or (flags & (ir.F_PATCH | ir.F_DOT1 | ir.F_SRC2 | ir.F_UP2HEAD)):
+            return False
+        return cinp % 32 == 0 and kh * kw <= 31 and kh >= 2 * ph + 1 and kw >= 2 * pw
 
     def _try_fuse_dot1(self, name, cout, coutp):
         """`name` (conv output after its epilogue) -> conv2d 1x1 to ONE channel (+bias, +sigmoid): fold it into the
@@ -814,8 +825,11 @@ class Compiler:
                                      lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh, kw,
                                                                 inv.span, ptaps))
         else:
-            w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"]),
-                                     lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0]))
+            wk32 = WK32 and dot is None and self.gemm_eligible(kh, kw, ph, pw, inv.span, inv_main.up, flags)
+            if wk32:
+                flags |= ir.F_WK32
+            w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"], wk32),
+                                     lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], 32 if wk32 else ir.KT))
         b_off = self.add_weights(("convb", wname, ep["out_name"]), bias)
         if dot is not None:
             aux_off = self.add_weights(("dot1", dot["wname"], ep["out_name"]), dot["w"])

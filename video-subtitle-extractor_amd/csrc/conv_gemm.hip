@@ -92,10 +92,10 @@ void conv_gemm_kernel(const ConvParams p) {
     }
 #if VSE_GEMM_ASM
     const rsrc4_t rsA = make_rsrc4(p.in + pix0 * p.in_ld);
-    const rsrc4_t rsW = make_rsrc4(p.w + (long)n0 * 64);
+    const rsrc4_t rsW = make_rsrc4(p.w + (long)n0 * ((p.flags & F_WK32) ? 32 : 64));
 #else
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + pix0 * p.in_ld), 0, 0x7fffffff, 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * 64), 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * ((p.flags & F_WK32) ? 32 : 64)), 0, 0x7fffffff, 0x00020000);
 #endif
 
     // ---- per-thread, loop-invariant offsets ------------------------------------------------------------------
@@ -127,14 +127,17 @@ void conv_gemm_kernel(const ConvParams p) {
             }
         }
     }
+    const bool wk32 = BKT == 32 && (p.flags & F_WK32);
     unsigned voffW[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const int r = (j * NW + wave) * RPI + rsub;
         const int kv = (lane % KV) ^ swz(r);
-        voffW[j] = (r < BN && n0 + r < p.Np) ? (unsigned)(r * 128 + kv * 16) : OOB;   // weights tiled [Kp/64][Np][64]
+        // weights tiled [Kp/64][Np][64], or (F_WK32, BK 32 only) [Kp/32][Np][32]: a wave DMA then covers 1 KiB of
+        // CONTIGUOUS memory = 8 whole 128-byte lines instead of 16 half lines (half the L2 requests of the weight stream)
+        voffW[j] = (r < BN && n0 + r < p.Np) ? (unsigned)(r * (wk32 ? 64 : 128) + kv * 16) : OOB;
     }
-    const unsigned wstep = (unsigned)p.Np * 128u;       // bytes per 64-deep weight K tile
+    const unsigned wstep = (unsigned)p.Np * (wk32 ? 64u : 128u);       // bytes per weight K tile
 
     // ---- block-uniform K walk (SALU) ---------------------------------------------------------------------------
     int kc = 0, dx = 0, dy = 0, tap = 0;
@@ -151,7 +154,7 @@ void conv_gemm_kernel(const ConvParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsv_t)(base + (j * NW + wave) * RPI * BKT), 16, (int)off, soffA, 0, 0);
 #endif
         }
-        const int soffW = BKT == 64 ? (int)((unsigned)kt * wstep) : (int)((unsigned)(kt >> 1) * wstep + (unsigned)(kt & 1) * 64u);
+        const int soffW = (BKT == 64 || wk32) ? (int)((unsigned)kt * wstep) : (int)((unsigned)(kt >> 1) * wstep + (unsigned)(kt & 1) * 64u);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #if VSE_GEMM_ASM
@@ -361,6 +364,7 @@ int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st) {
     if (span > 1.9e9 || (double)Kp * p.Np * 2 > 1.9e9) return VSE_E_UNSUPPORTED;
     const int c = conv_gemm_config(p.Np, p.cinp, p.M);
     const GemmCfg& g = kCfg[c];
+    if ((p.flags & F_WK32) && g.bk != 32) return VSE_E_UNSUPPORTED;
     p.ntn = (unsigned)((p.Np + g.bn - 1) / g.bn);
     p.nk = Kp / g.bk;
     const unsigned long long tiles = (unsigned long long)((p.M + g.bm - 1) / g.bm) * p.ntn;

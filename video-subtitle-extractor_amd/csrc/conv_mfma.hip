@@ -284,6 +284,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
         const int rc = launch_conv_gemm(p, a.Kp, st);
         if (rc != VSE_E_UNSUPPORTED) return rc;
     }
+    if (a.flags & F_WK32) return VSE_E_UNSUPPORTED;     // 32-deep weight tiles are read by conv_gemm_kernel only
     const int bn = conv_tile_bn(a.Np);
     dim3 block(256);
     const int bm = bn == 128 ? 128 : 256;

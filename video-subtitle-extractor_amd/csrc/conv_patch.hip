@@ -34,6 +34,9 @@
 #define VSE_ABLATE 0      // 1: no s_barrier  2: no fragment ds_reads  3: no weight/patch DMA  4: no MFMA   (timing experiments only)
 #endif
 
+#ifndef VSE_PIPE128
+#define VSE_PIPE128 0
+#endif
 #define PTW 32
 #define PRING 4
 
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
     constexpr int RROWS = LIGHT ? BN : 64;          // weight rows per tap in a ring stage
     constexpr int TPS = LIGHT ? 2 : 4;              // filter taps per step: 16 / 32 MFMAs per wave between barriers
     constexpr int RING = (BIGP || LIGHT) ? 2 : PRING;   // weight ring stages (2 where LDS is tight: 960-pixel patch, two blocks per CU)
-    constexpr bool PIPE = VSE_ABLATE == 0 && !(LIGHT && BN == 128);   // fast step (below); the 128-cout LIGHT tile has no registers to spare
+    constexpr bool PIPE = VSE_ABLATE == 0 && (VSE_PIPE128 || !(LIGHT && BN == 128));   // fast step (below); the 128-cout LIGHT tile has no registers to spare
     constexpr int LOOK = RING - 1;                  // stages in flight ahead of the one being consumed
     constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = TPS * RROWS * 32;
     // landing zone of surplus DMAs (whole wave instructions past the patch / past a 64-row weight stage)
