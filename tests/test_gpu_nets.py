@@ -83,6 +83,8 @@ CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (64, 64, (9, 9), (1, 1), (4, 4), 40, 70, 1),       # <8,64>: 40 rows pad to 48 (> 20 %) and a ragged right edge
     (128, 160, (3, 3), (1, 1), (1, 1), 16, 64, 2),     # 160 couts -> three 64-cout tiles, one half empty
     (128, 128, (3, 3), (1, 1), (1, 1), 24, 96, 1),     # <8,128>
+    (128, 128, (3, 3), (1, 1), (1, 1), 32, 96, 2),     # LIGHT <8,128,2>, map of whole 16-row tiles
+    (96, 80, (3, 3), (1, 1), (1, 1), 48, 40, 1),       # LIGHT <8,128,2> with a cout tail (80 of 128) and a column tail (40 of 64)
     (72, 64, (3, 3), (1, 1), (1, 1), 32, 64, 1),       # channel tail (72 = 2*32 + 8), <16,64,false>
     (32, 32, (7, 7), (1, 1), (3, 3), 16, 96, 2),       # 49 taps (odd): last step has a single tap
     (96, 40, (7, 1), (1, 1), (3, 0), 16, 64, 1), (96, 40, (1, 7), (1, 1), (0, 3), 16, 64, 1),

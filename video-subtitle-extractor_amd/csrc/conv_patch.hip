@@ -432,7 +432,9 @@ int conv_patch_bn(int Np) {
 // Tile height: 16 rows when the halo patch fits the LDS patch buffer (960 pixels for BN = 64, else 640) and the map
 // tiles at least as well as with 8 rows.
 int conv_patch_th(int kh, int kw, int OH, int bn) {
-    if (bn != 64) return 8;      // measured: the 64 px x 128 cout wave tile (204 VGPRs) loses to two 64 x 64 waves
+    if (bn != 64) return 8;      // measured twice: a 16-row x 128-cout tile (64 px x 128 couts per wave, one block per CU, 3 or 4
+                                 // taps per step, pipelined fast step, 254 VGPRs) is 7-20 % slower than LIGHT's two 8-row blocks:
+                                 // a 3x3 K loop is too short to amortise an un-overlapped prologue + 128-cout epilogue
     const int cap = 960;
     if ((16 + kh - 1) * (PTW + kw - 1) > cap) return 8;
     const int pad16 = (OH + 15) / 16 * 16, pad8 = (OH + 7) / 8 * 8;
