@@ -767,10 +767,10 @@ class Compiler:
         patch_std = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 640
                      and tile_eff >= PATCH_MIN_TILE_EFF and kh * kw * cin >= PATCH_MIN_K and coutp <= PATCH_MAX_COUT and self.use_patch)
         # LIGHT variant (conv_patch_plan in csrc/conv_patch.hip): 8-row tiles whose halo patch fits 352 pixels (3x3, 1xk),
-        # 64 or 128 couts per tile, two blocks per CU; not combined with the fused 1-channel projection
+        # 64 or 128 couts per tile, two blocks per CU; not combined with the fused 1-channel projection or a virtual concat
         tile_eff8 = (oh * ow) / float(-(-oh // 8) * 8 * -(-ow // 32) * 32)
         light_ok = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 352 and tile_eff8 >= PATCH_MIN_TILE_EFF
-                    and kh * kw * cin >= PATCH_MIN_K and self.use_patch
+                    and kh * kw * cin >= PATCH_MIN_K and self.use_patch and inv.parts is None
                     and (PATCH_LIGHT >= 2 if coutp <= 64 else (coutp <= 128 and PATCH_LIGHT >= 1)))
         patch = patch_std or light_ok
         self.env_dims_tmp = (inv.n, oh, ow)

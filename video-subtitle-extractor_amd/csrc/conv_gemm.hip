@@ -21,7 +21,7 @@
 #include "conv_common.h"
 
 #ifndef VSE_GEMM_ASM
-#define VSE_GEMM_ASM 0    // 1: LDS-DMAs as asm statements (counted lgkmcnt waits survive; measured 1-3 % SLOWER here: the kernel is bound by the DMA stream, the asm form adds issue slots); 0: builtins.  A/B on one box: tools/ab_gemm.sh
+#define VSE_GEMM_ASM 0    // 1: LDS-DMAs as asm statements (counted lgkmcnt waits survive; measured 1-3 % SLOWER here: the kernel is bound by the DMA stream, the asm form adds issue slots); 0: builtins.  A/B on one box: tools/ab.sh
 #endif
 #ifndef VSE_ABLATE
 #define VSE_ABLATE 0      // 1: no s_barrier  2: no fragment ds_reads  3: no DMA in the loop  4: no MFMA  5: no epilogue   (timing experiments only)

@@ -34,8 +34,17 @@
 #define VSE_ABLATE 0      // 1: no s_barrier  2: no fragment ds_reads  3: no weight/patch DMA  4: no MFMA   (timing experiments only)
 #endif
 
+#ifndef VSE_PIPE
+#define VSE_PIPE 1        // software-pipelined fast step (A/B on one box: tools/ab.sh conv_patch VSE_PIPE ...)
+#endif
 #ifndef VSE_PIPE128
-#define VSE_PIPE128 0
+#define VSE_PIPE128 0     // ... also for the 128-cout LIGHT tile (spills: 68 bytes of scratch per lane)
+#endif
+#ifndef VSE_PIPE
+#define VSE_PIPE 1        // software-pipelined fast step (A/B on one box: tools/ab.sh conv_patch VSE_PIPE ...)
+#endif
+#ifndef VSE_PIPE128
+#define VSE_PIPE128 0     // ... also for the 128-cout LIGHT tile (spills: 68 bytes of scratch per lane)
 #endif
 #define PTW 32
 #define PRING 4
@@ -66,7 +75,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
     constexpr int RROWS = LIGHT ? BN : 64;          // weight rows per tap in a ring stage
     constexpr int TPS = LIGHT ? 2 : 4;              // filter taps per step: 16 / 32 MFMAs per wave between barriers
     constexpr int RING = (BIGP || LIGHT) ? 2 : PRING;   // weight ring stages (2 where LDS is tight: 960-pixel patch, two blocks per CU)
-    constexpr bool PIPE = VSE_ABLATE == 0 && (VSE_PIPE128 || !(LIGHT && BN == 128));   // fast step (below); the 128-cout LIGHT tile has no registers to spare
+    constexpr bool PIPE = VSE_ABLATE == 0 && VSE_PIPE && (VSE_PIPE128 || !(LIGHT && BN == 128));   // fast step (below); the 128-cout LIGHT tile has no registers to spare
     constexpr int LOOK = RING - 1;                  // stages in flight ahead of the one being consumed
     constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = TPS * RROWS * 32;
     // landing zone of surplus DMAs (whole wave instructions past the patch / past a 64-row weight stage)
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
 
     // ---- DMA source state ---------------------------------------------------------------------------------
     const int kv = (lane & 3) ^ ((lane >> 4) & 3);        // logical k-vector this lane fetches (source-side swizzle)
-    const bool src2 = p.flags & F_SRC2;                    // virtual concat: vectors >= nv0 come from p.in2
+    const bool src2 = !LIGHT && (p.flags & F_SRC2);        // virtual concat: vectors >= nv0 come from p.in2 (never planned onto LIGHT)
     long poff[PNPL], poff2[PNPL];
     bool pok[PNPL];
 #pragma unroll
@@ -414,7 +423,7 @@ static int patch_light_policy() {       // VSE_PATCH_LIGHT: 0 never, 1 only laye
     return v;
 }
 void conv_patch_plan(int kh, int kw, int OH, int Np, int flags, int* th, int* bn, int* mode) {
-    const bool fits = (8 + kh - 1) * (PTW + kw - 1) <= 352 && !(flags & F_DOT1);
+    const bool fits = (8 + kh - 1) * (PTW + kw - 1) <= 352 && !(flags & (F_DOT1 | F_SRC2));
     const int pol = patch_light_policy();
     if (fits && (pol >= 2 || (pol == 1 && Np > 64))) {
         *th = 8; *bn = Np > 64 ? 128 : 64; *mode = 2;
