@@ -127,7 +127,7 @@ void conv_gemm_kernel(const ConvParams p) {
             }
         }
     }
-    const bool wk32 = BKT == 32 && (p.flags & F_WK32);
+    const bool wk32 = p.flags & F_WK32;
     unsigned voffW[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -135,7 +135,9 @@ void conv_gemm_kernel(const ConvParams p) {
         const int kv = (lane % KV) ^ swz(r);
         // weights tiled [Kp/64][Np][64], or (F_WK32, BK 32 only) [Kp/32][Np][32]: a wave DMA then covers 1 KiB of
         // CONTIGUOUS memory = 8 whole 128-byte lines instead of 16 half lines (half the L2 requests of the weight stream)
-        voffW[j] = (r < BN && n0 + r < p.Np) ? (unsigned)(r * (wk32 ? 64 : 128) + kv * 16) : OOB;
+        // (BK 64 over 32-deep tiles: k-vectors 4..7 of a row come from the next tile, Np * 64 bytes further)
+        voffW[j] = !(r < BN && n0 + r < p.Np) ? OOB
+                 : wk32 ? (unsigned)((kv >> 2) * p.Np * 64 + r * 64 + (kv & 3) * 16) : (unsigned)(r * 128 + kv * 16);
     }
     const unsigned wstep = (unsigned)p.Np * (wk32 ? 64u : 128u);       // bytes per weight K tile
 
@@ -154,7 +156,8 @@ void conv_gemm_kernel(const ConvParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsv_t)(base + (j * NW + wave) * RPI * BKT), 16, (int)off, soffA, 0, 0);
 #endif
         }
-        const int soffW = (BKT == 64 || wk32) ? (int)((unsigned)kt * wstep) : (int)((unsigned)(kt >> 1) * wstep + (unsigned)(kt & 1) * 64u);
+        const int soffW = wk32 ? (int)((unsigned)kt * (BKT / 32) * wstep)
+                         : BKT == 64 ? (int)((unsigned)kt * wstep) : (int)((unsigned)(kt >> 1) * wstep + (unsigned)(kt & 1) * 64u);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
 #if VSE_GEMM_ASM
@@ -215,7 +218,9 @@ void conv_gemm_kernel(const ConvParams p) {
         if (kt + ST - 1 < p.nk) issue(kt + ST - 1, (S + ST - 1) % ST);
 #endif
         // fragment reads in groups of KG k sub-steps (<= 16 ds_read_b128 in flight), each followed by its MFMAs
-        constexpr int KG = (KS * (TM + TN) <= 16) ? KS : (KS / 2 * (TM + TN) <= 16 ? KS / 2 : 1);
+        // (16-wave tiles run 4 waves per SIMD = 128 VGPRs: at most 8 fragments = 32 VGPRs in flight beside the accumulators)
+        constexpr int FCAP = NW >= 16 ? 8 : 16;
+        constexpr int KG = (KS * (TM + TN) <= FCAP) ? KS : (KS / 2 * (TM + TN) <= FCAP ? KS / 2 : 1);
 #pragma unroll
         for (int k0 = 0; k0 < KS; k0 += KG) {
             half8 wf[KG][TN], xf[KG][TM];
@@ -319,10 +324,11 @@ int conv_gemm_mode(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int
 //   6: 256 x 128,  8 waves (4 x 2), BK 32, 3 stages  (72 KiB, 2 blocks/CU)
 //  16: 256 x 256, 16 waves (4 x 4), BK 32, 3 stages  (96 KiB, 1 block/CU)
 //  17: 256 x 192, 16 waves (8 x 2), BK 32, 3 stages  (96 KiB, 1 block/CU; weight rows staged as 256)
+//  18 / 19: the same two tiles with BK 64 and 2 stages (128 KiB) for layers with cin % 64 == 0
 struct GemmCfg { int bm, bn, bk; };
 static const GemmCfg kCfg[] = {{128, 128, 32}, {256, 64, 32}, {256, 32, 32}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {256, 128, 32},
                                {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0},
-                               {256, 256, 32}, {256, 192, 32}};
+                               {256, 256, 32}, {256, 192, 32}, {256, 256, 64}, {256, 192, 64}};
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 // Which configuration serves a layer.  The kernel is bound by the L2 -> LDS fill (ablation: MFMAs and fragment reads
@@ -336,16 +342,19 @@ int conv_gemm_config(int Np, int cinp, long M) {
         if (c >= 0 && c < kNumCfg && kCfg[c].bm && cinp % kCfg[c].bk == 0) return c;
     }
     auto ntn = [&](int bn) { return (long)((Np + bn - 1) / bn); };
+    // the 16-wave tiles run 64-deep K tiles in a 2-stage ring where the channels allow it (whole 128-byte lines per
+    // activation row and half the barriers; A/B on one box: -2..-4 %); the 8-wave 256 x 128 tile loses its second block per CU
+    auto deep = [&](int c) { return cinp % 64 == 0 ? c + 2 : c; };          // 16 -> 18, 17 -> 19
     if (Np <= 32) return 2;
     if (Np <= 64) return 1;
     const long mt = (M + 255) / 256;
     if (Np <= 128) return mt >= 256 ? 6 : 0;
-    if (Np <= 192) return mt >= 192 ? 17 : (mt >= 128 ? 6 : 0);
+    if (Np <= 192) return mt >= 192 ? deep(17) : (mt >= 128 ? 6 : 0);
     const double w256 = (double)ntn(256) * 256 / Np, w192 = (double)ntn(192) * 192 / Np;
     const bool pick256 = ntn(256) < ntn(192) || (ntn(256) == ntn(192) && w256 <= w192);
-    if (pick256 && mt * ntn(256) >= 192 && w256 <= 1.34) return 16;
-    if (mt * ntn(192) >= 192 && w192 <= 1.34) return 17;
-    if (mt * ntn(256) >= 192 && w256 <= 1.34) return 16;
+    if (pick256 && mt * ntn(256) >= 192 && w256 <= 1.34) return deep(16);
+    if (mt * ntn(192) >= 192 && w192 <= 1.34) return deep(17);
+    if (mt * ntn(256) >= 192 && w256 <= 1.34) return deep(16);
     return mt * ntn(128) >= 512 ? 6 : 0;
 }
 
@@ -364,7 +373,6 @@ int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st) {
     if (span > 1.9e9 || (double)Kp * p.Np * 2 > 1.9e9) return VSE_E_UNSUPPORTED;
     const int c = conv_gemm_config(p.Np, p.cinp, p.M);
     const GemmCfg& g = kCfg[c];
-    if ((p.flags & F_WK32) && g.bk != 32) return VSE_E_UNSUPPORTED;
     p.ntn = (unsigned)((p.Np + g.bn - 1) / g.bn);
     p.nk = Kp / g.bk;
     const unsigned long long tiles = (unsigned long long)((p.M + g.bm - 1) / g.bm) * p.ntn;
@@ -376,6 +384,8 @@ int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st) {
         case 6: launch_cfg<256, 128, 4, 2, 32, 3>(p, mode, grid, st); break;
         case 16: launch_cfg<256, 256, 4, 4, 32, 3>(p, mode, grid, st); break;
         case 17: launch_cfg<256, 192, 8, 2, 32, 3>(p, mode, grid, st); break;
+        case 18: launch_cfg<256, 256, 4, 4, 64, 2>(p, mode, grid, st); break;
+        case 19: launch_cfg<256, 192, 8, 2, 64, 2>(p, mode, grid, st); break;
         default: launch_cfg<128, 128, 2, 2, 32, 3>(p, mode, grid, st); break;
     }
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
