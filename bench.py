@@ -225,7 +225,7 @@ def variant_kernel_name(code):
                16: "256, 256, 4, 4, 32, 3", 17: "256, 192, 8, 2, 32, 3", 18: "256, 256, 4, 4, 64, 2",
                19: "256, 192, 8, 2, 64, 2"}.get((code - 200000) // 10)
         return f"conv_gemm_kernel<{cfg}, {code % 10}>" if cfg else f"conv_gemm_kernel<cfg {(code - 200000) // 10}>"
-    if code >= 1000 and code % 1000 in (64, 128) and (code // 1000) % 100 in (8, 16):
+    if code >= 1000 and code % 1000 in (32, 64, 128) and (code // 1000) % 100 in (8, 16):
         return f"conv_patch_kernel<{(code // 1000) % 100}, {code % 1000}, {code // 100000}>"
     return f"conv_mfma_kernel<{tiles[code % 1000]}, {'true' if code >= 10000 else 'false'}>"
 

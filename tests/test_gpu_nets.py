@@ -86,7 +86,8 @@ CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (128, 128, (3, 3), (1, 1), (1, 1), 32, 96, 2),     # LIGHT <8,128,2>, map of whole 16-row tiles
     (96, 80, (3, 3), (1, 1), (1, 1), 48, 40, 1),       # LIGHT <8,128,2> with a cout tail (80 of 128) and a column tail (40 of 64)
     (72, 64, (3, 3), (1, 1), (1, 1), 32, 64, 1),       # channel tail (72 = 2*32 + 8), <16,64,false>
-    (32, 32, (7, 7), (1, 1), (3, 3), 16, 96, 2),       # 49 taps (odd): last step has a single tap
+    (32, 32, (7, 7), (1, 1), (3, 3), 16, 96, 2),       # 49 taps (odd): last step has a single tap; <16,32,1>
+    (64, 24, (5, 5), (1, 1), (2, 2), 32, 64, 1),       # <16,32,1> with a cout tail (24 of 32), two channel chunks
     (96, 40, (7, 1), (1, 1), (3, 0), 16, 64, 1), (96, 40, (1, 7), (1, 1), (0, 3), 16, 64, 1),
     # scalar-addressed implicit GEMM (conv_gemm_kernel: cin % 32 == 0, <= 31 taps); VSE_CONV_GEMM=0 sends the same
     # cases through conv_mfma_kernel

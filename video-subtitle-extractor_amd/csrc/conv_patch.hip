@@ -66,7 +66,7 @@
 template <int PTH, int BN, int MODE>
 __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(const ConvParams p) {
     constexpr bool BIGP = MODE == 1, LIGHT = MODE == 2;
-    static_assert(!BIGP || (BN == 64 && PTH == 16), "big patch variant");
+    static_assert(!BIGP || ((BN == 64 || BN == 32) && PTH == 16), "big patch variant");
     static_assert(!LIGHT || PTH == 8, "light variant");
     constexpr int WCO = PTH == 16 ? 1 : 2;          // waves along cout
     constexpr int TN = BN / (32 * WCO);             // 32-cout MFMA tiles per wave
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
     constexpr int PATCH_HALFS = PPIX * 32, WSTAGE_HALFS = TPS * RROWS * 32;
     // landing zone of surplus DMAs (whole wave instructions past the patch / past a 64-row weight stage)
     constexpr int DUMMY_HALFS = BIGP ? 4 * 512 : LIGHT ? 2 * 512 : 0;
-    static_assert(BN == 64 || (LIGHT && BN == 128), "cout tile");
+    static_assert(BN == 64 || (LIGHT && BN == 128) || (BIGP && BN == 32), "cout tile");
     __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + RING * WSTAGE_HALFS + DUMMY_HALFS + 4 * BN];   // the ONLY LDS object
     // ... + BN floats of bias + BN floats of F_DOT1 projection weights
     float* const sbias = reinterpret_cast<float*>(lds + 2 * PATCH_HALFS + RING * WSTAGE_HALFS + DUMMY_HALFS);
@@ -163,7 +163,9 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
         } else if constexpr (LIGHT) {                // two taps x 64 rows: waves 0-3 tap 0, waves 4-7 tap 1
             glds16_asm(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
         } else {
-            // waves 0-3: taps 0 and 2 of the step, waves 4-7: taps 1 and 3
+            // waves 0-3: taps 0 and 2 of the step, waves 4-7: taps 1 and 3; 32-cout tiles (BIGP only: its waits do not count
+            // weight DMAs) read rows 0..31 of the 64-row stage and the waves of rows 32..63 issue nothing
+            if (BN == 32 && (wave & 2)) return;
             glds16_asm(wptr, st + (wave >> 2) * RROWS * 32 + (wave & 3) * 16 * 32);
             glds16_asm(wptr + (wok ? (long)p.Np * 64 : 0), st + (2 + (wave >> 2)) * RROWS * 32 + (wave & 3) * 16 * 32);
         }
@@ -432,6 +434,7 @@ void conv_patch_plan(int kh, int kw, int OH, int Np, int flags, int* th, int* bn
     *bn = 64;
     *th = conv_patch_th(kh, kw, OH, 64);
     *mode = (*th == 16 && (16 + kh - 1) * (PTW + kw - 1) > 640) ? 1 : 0;
+    if (*mode == 1 && Np <= 32 && !(flags & F_DOT1)) *bn = 32;      // half the MFMAs and weight DMAs of a 64-cout tile
 }
 int conv_patch_bn(int Np) {
     (void)Np;
@@ -476,6 +479,7 @@ int launch_conv_patch(const ConvParams& pin, int n_img, hipStream_t st) {
 #endif
     if (mode == 2 && bn == 128) hipLaunchKernelGGL((conv_patch_kernel<8, 128, 2>), grid, block, 0, st, p);
     else if (mode == 2) hipLaunchKernelGGL((conv_patch_kernel<8, 64, 2>), grid, block, 0, st, p);
+    else if (big && bn == 32) hipLaunchKernelGGL((conv_patch_kernel<16, 32, 1>), grid, block, 0, st, p);
     else if (big) hipLaunchKernelGGL((conv_patch_kernel<16, 64, 1>), grid, block, 0, st, p);
     else if (th == 16) hipLaunchKernelGGL((conv_patch_kernel<16, 64, 0>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv_patch_kernel<8, 64, 0>), grid, block, 0, st, p);
