@@ -62,6 +62,21 @@ __global__ __launch_bounds__(512) void conv_head_up2_kernel(const ConvParams p) 
     const int oy0 = ty * HT_ROWS, ox0 = tx * HT_COLS;        // low-res origin of the tile
     const int Hl = p.in2_hs, Wl = p.in2_ws;                  // low-res map; the output is 2Hl x 2Wl
 
+    // u tile: full-res rows 2*oy0-1 .. 2*oy0+16, cols 2*ox0-1 .. 2*ox0+64 of channel 0, zero outside the map.  The (plain)
+    // loads are issued FIRST, all three per thread back to back, and land in LDS after the one vmcnt(0) below: a load ->
+    // ds_write loop after the DMAs made hipcc wait for the whole DMA queue and then for two more memory round trips.
+    half_t uval[3];
+    {
+        const half_t* ub = p.in + img * (long)(2 * Hl) * (2 * Wl) * p.in_ld;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = tid + 512 * k;
+            const int uy = idx / 66, ux = idx - uy * 66;
+            const int fy = 2 * oy0 - 1 + uy, fx2 = 2 * ox0 - 1 + ux;
+            uval[k] = (half_t)0.f;
+            if (idx < UTH * 66 && fy >= 0 && fy < 2 * Hl && fx2 >= 0 && fx2 < 2 * Wl) uval[k] = ub[((long)fy * (2 * Wl) + fx2) * p.in_ld];
+        }
+    }
     // ---- prologue: everything but the weight stream is staged once --------------------------------------------------
     const int kv = (lane & 3) ^ ((lane >> 4) & 3);           // logical k-vector this lane fetches (source-side swizzle)
     conv_stage_consts<true>(sbias, p.bias, p.zero, 0, 64, p.Np, wave, lane);            // wave 0
@@ -90,18 +105,6 @@ __global__ __launch_bounds__(512) void conv_head_up2_kernel(const ConvParams p) 
     issue_w(0);
     issue_w(1);
     issue_w(2);
-    // u tile: full-res rows 2*oy0-1 .. 2*oy0+16, cols 2*ox0-1 .. 2*ox0+64 of channel 0, zero outside the map
-    {
-        const half_t* ub = p.in + img * (long)(2 * Hl) * (2 * Wl) * p.in_ld;
-        for (int idx = tid; idx < UTH * 66; idx += 512) {
-            const int uy = idx / 66, ux = idx - uy * 66;
-            const int fy = 2 * oy0 - 1 + uy, fx2 = 2 * ox0 - 1 + ux;
-            half_t v = (half_t)0.f;
-            if (fy >= 0 && fy < 2 * Hl && fx2 >= 0 && fx2 < 2 * Wl) v = ub[((long)fy * (2 * Wl) + fx2) * p.in_ld];
-            ut0[uy * UTW + ux] = v;
-        }
-    }
-
     float16v acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -116,6 +119,12 @@ __global__ __launch_bounds__(512) void conv_head_up2_kernel(const ConvParams p) 
     const char* const ring_b = reinterpret_cast<const char*>(ring0);
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int idx = tid + 512 * k;
+        const int uy = idx / 66, ux = idx - uy * 66;
+        if (idx < UTH * 66) ut0[uy * UTW + ux] = uval[k];
+    }
     __syncthreads();
 
     // ---- K loop -----------------------------------------------------------------------------------------------------
