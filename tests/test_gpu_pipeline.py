@@ -16,7 +16,7 @@ def _iou(a, b):
     return iw * ih / u if u > 0 else 1.0
 
 
-@pytest.mark.parametrize("hw", [(720, 1280), (1080, 1920)])
+@pytest.mark.parametrize("hw", [(720, 1280), (1080, 1920), (2160, 3840)])      # BASELINE configs C1 / C2 / C3 frame sizes
 def test_ocr_pipeline_vs_oracle(ctx, hw):
     """Boxes: IoU >= 0.99 (in fact identical integers).  Strings: identical after CTC collapse, except that a
     time step may differ where the ORACLE's own top-2 margin is below 5 % — the recogniser weights are stand-ins
@@ -26,7 +26,7 @@ def test_ocr_pipeline_vs_oracle(ctx, hw):
     det = net_ref.get_weights("V3_ch_det_fast")            # the one model with real weights
     rec = net_ref.get_weights("V4_en_rec_fast")            # calibrated stand-in weights
     charset = P.en_charset()
-    frames = synth.make_frames(3, hw[0], hw[1], seed=hw[0], p_two_lines=0.5)
+    frames = synth.make_frames(3 if hw[0] < 2000 else 2, hw[0], hw[1], seed=hw[0], p_two_lines=0.5)
     pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="reference")
     dev = torch.from_numpy(frames).cuda()
     got = pipe.ocr(dev)
@@ -59,7 +59,32 @@ def test_ocr_pipeline_vs_oracle(ctx, hw):
                     assert len(ops) <= shaky, (text, ref_text, shaky)
                 assert abs(score - conf) < 2e-2
                 nbox += 1
-    assert nbox >= 3 and exact >= 1
+    assert nbox >= 2 and exact >= 1
+
+
+def test_blank_and_mixed_frames(ctx):
+    """Frames without text give empty results (arrays with len 0, as the reference's callers expect), also in the middle
+    of a batch; the frames with text are unaffected by their neighbours."""
+    import torch
+    from vse_amd import pipeline, synth
+    det = net_ref.get_weights("V3_ch_det_fast")
+    rec = net_ref.get_weights("V4_en_rec_fast")
+    charset = P.en_charset()
+    text = synth.make_frames(2, 720, 1280, seed=5, p_two_lines=1.0)
+    blank = np.full((720, 1280, 3), 40, np.uint8)
+    frames = np.stack([blank, text[0], blank, text[1], np.zeros_like(blank)])
+    pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="reference")
+    got = pipe.ocr(torch.from_numpy(frames).cuda())
+    alone = pipe.ocr(torch.from_numpy(text).cuda())
+    for f in (0, 2, 4):
+        x, _ = P.det_preprocess(frames[f])
+        prob = net_ref.run_graph(det[0], det[1], x)[0].numpy()[0, 0]
+        assert len(P.db_postprocess(prob, 720, 1280)[0]) == 0          # the oracle finds nothing either
+        assert len(got[f][0]) == 0 and len(got[f][1]) == 0
+    for f, g in ((1, 0), (3, 1)):
+        assert len(got[f][0]) == len(alone[g][0]) >= 1
+        assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got[f][0], alone[g][0]))
+        assert [t for t, _s in got[f][1]] == [t for t, _s in alone[g][1]]
 
 
 def test_drop_in_call_sites(ctx):
