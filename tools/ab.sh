@@ -8,6 +8,7 @@ F=$1; M=$2; C=$3; L=$4
 for V in 0 1 0 1; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -D$M=$V -c $F.hip -o build/$F.hip.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvse_hip.so $OBJS
+  export $M=$V       # (switches mirrored by the graph compiler read the same name from the environment)
   echo "$M=$V"; (cd $R && python tools/bench_conv.py --cfgs $C --layers $L 2>&1 | grep -v amdgpu.ids | cut -c1-80)
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -c $F.hip -o build/$F.hip.o 2>/dev/null
