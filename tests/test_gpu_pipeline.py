@@ -147,3 +147,23 @@ def test_accurate_mode_selector_on_engine(ctx):
     assert [(t[0], t[1], t[2] is None) for t in tasks] == [(t[0], t[1], t[2] is None) for t in ref]
     nos = [t[1] for t in tasks]
     assert 3 in nos and 5 in nos and nos == sorted(nos)        # first subtitle spans frames 3..5
+
+
+def test_streaming_form_is_identical(ctx):
+    """ocr_stream(): the detector of batch k+1 overlaps post-processing + recognition of batch k (second HIP stream,
+    alternate workspace slot); every batch's result equals the one-batch-at-a-time result, odd batch counts included."""
+    import torch
+    from vse_amd import pipeline, synth
+    det = net_ref.get_weights("V3_ch_det_fast")
+    rec = net_ref.get_weights("V4_en_rec_fast")
+    pipe = pipeline.OcrPipeline(ctx, det, rec, P.en_charset(), rec_mode="bucketed")
+    batches = [torch.from_numpy(synth.make_frames(3, 720, 1280, seed=40 + k, p_two_lines=0.5)).cuda() for k in range(3)]
+    seq = [pipe.ocr(b) for b in batches]
+    got = list(pipe.ocr_stream(iter(batches)))
+    assert len(got) == 3
+    for a, b in zip(seq, got):
+        assert len(a) == len(b)
+        for (ab, ar), (bb, br) in zip(a, b):
+            assert len(ab) == len(bb) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(ab, bb))
+            assert ar == br
+    assert list(pipe.ocr_stream(iter([]))) == []

@@ -75,12 +75,13 @@ class OcrPipeline:
         return net.run(x, slot)
 
     # ---- detection ---------------------------------------------------------------------------------------
-    def det_maps(self, frames):
-        """frames: cuda uint8 [N,H,W,3] -> cuda fp32 prob maps [N,h,w]."""
+    def det_maps(self, frames, slot=0):
+        """frames: cuda uint8 [N,H,W,3] -> cuda fp32 prob maps [N,h,w].  `slot` selects the detector workspace: two
+        batches may be in flight on different streams when they use different slots."""
         n, h, w, _ = frames.shape
         rh, rw = det_resize_shape(h, w, self.limit)
         x = self.ctx.det_preprocess(frames, rh, rw)
-        out = self._run(self.det, x)[0]     # [N,rh,rw,1] fp32
+        out = self._run(self.det, x, slot)[0]     # [N,rh,rw,1] fp32
         return out.view(n, rh, rw)
 
     def detect(self, frames):
@@ -198,6 +199,38 @@ class OcrPipeline:
     def ocr(self, frames):
         """-> list per frame of (list of float32 [4,2] boxes, list of (text, score)) — paddleocr TextSystem output."""
         det = self.detect(frames)
+        return self._finish(frames, det)
+
+    def ocr_stream(self, batches):
+        """Generator over an iterable of frame batches (cuda uint8 [N,H,W,3]): yields ocr(batch) for each, in order, with
+        the detector of batch k+1 running (own HIP stream, alternate workspace slot) while batch k is post-processed and
+        recognised — the steady state of a whole-video extraction.  Results are identical to calling ocr() per batch."""
+        t = self.ctx.torch
+        if getattr(self, "_det_stream", None) is None:
+            self._det_stream = t.cuda.Stream(device=self.ctx.tdev)
+        main = t.cuda.current_stream(self.ctx.tdev)
+        self._det_stream.wait_stream(main)
+        prev = None
+        for k, frames in enumerate(batches):
+            with t.cuda.stream(self._det_stream):
+                maps = self.det_maps(frames, slot=k & 1)
+                ev = t.cuda.Event()
+                ev.record(self._det_stream)
+            if prev is not None:
+                yield self._finish_maps(*prev)
+            prev = (frames, maps, ev)
+        if prev is not None:
+            yield self._finish_maps(*prev)
+
+    def _finish_maps(self, frames, maps, ev):
+        main = self.ctx.torch.cuda.current_stream(self.ctx.tdev)
+        main.wait_event(ev)
+        maps.record_stream(main)
+        n, h, w, _ = frames.shape
+        res = self.ctx.db_postprocess(maps, h, w, **self.db)
+        return self._finish(frames, [r[0] for r in res])
+
+    def _finish(self, frames, det):
         ordered = [sorted_boxes(b) for b in det]
         rec = self.recognize(frames, ordered)
         out = []
