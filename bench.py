@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="finish batch k before the detector of batch k+1 starts")
+    ap.add_argument("--det-depth", type=int, default=1, help="detector batches in flight ahead of the one being recognised")
     return ap.parse_args()
 
 
@@ -170,13 +171,15 @@ def main():
     # goes through DB post-processing, the host-side box logic, the recogniser launches and the record gather — what a
     # whole-video extraction does with consecutive frame batches.  Every batch started inside the timed region is also
     # finished inside it (run_steps drains its last batch), so K steps = K complete det + rec passes.
-    det_stream = torch.cuda.Stream(device=ctx.tdev)
+    depth = max(1, args.det_depth)
+    det_streams = [torch.cuda.Stream(device=ctx.tdev) for _ in range(depth)]
 
     def stage1(k):
-        with torch.cuda.stream(det_stream):
-            maps = pipe.det_maps(frames, slot=k & 1)
+        st = det_streams[k % depth]
+        with torch.cuda.stream(st):
+            maps = pipe.det_maps(frames, slot=k % (depth + 1))
             ev = torch.cuda.Event()
-            ev.record(det_stream)
+            ev.record(st)
         return maps, ev
 
     def stage2(handle):
@@ -196,15 +199,15 @@ def main():
             for _ in range(n):
                 out = step()
             return out
-        det_stream.wait_stream(torch.cuda.current_stream(ctx.tdev))
-        out, prev = None, None
+        for st in det_streams:
+            st.wait_stream(torch.cuda.current_stream(ctx.tdev))
+        out, queue = None, []
         for k in range(n):
-            cur = stage1(k)
-            if prev is not None:
-                out = stage2(prev)
-            prev = cur
-        if prev is not None:
-            out = stage2(prev)
+            queue.append(stage1(k))
+            if len(queue) > depth:
+                out = stage2(queue.pop(0))
+        while queue:
+            out = stage2(queue.pop(0))
         return out
 
     def sync():
