@@ -192,6 +192,9 @@ class Emulator:
         p, f = r["p"], r["f"]
         kh, kw, sh, sw, ph, pw = (int(p[i]) for i in range(6))
         x = self.read(r["in0"])
+        if int(r["flags"]) & ir.F_GATE:       # SE gate applied on load, rounded to fp16 like the separate scale pass
+            g = self.read(r["in1"])
+            x = ((x * g + x) if int(r["flags"]) & ir.F_RES else x * g).half().float()
         cp = x.shape[3]
         wk = self.wread(int(r["w_off"]), kh * kw * cp, np.float16).astype(np.float32).reshape(kh, kw, cp)
         w4 = torch.from_numpy(np.ascontiguousarray(wk.transpose(2, 0, 1)[:, None]))

@@ -138,6 +138,7 @@ PATCH_MIN_TILE_EFF = float(os.environ.get("VSE_PATCH_MINEFF", "0.5"))
 PATCH_LIGHT = int(os.environ.get("VSE_PATCH_LIGHT", "2"))
 # evaluate the PP-OCRv4 server detector's last 3x3 conv on the low-res grid (conv_head.hip); VSE_HEAD_UP2=0 keeps it on
 # the patch kernel (experiments / A-B)
+GATE_DW = os.environ.get("VSE_GATE_DW", "1") != "0"   # SE gate folded into a depthwise consumer
 WK32 = os.environ.get("VSE_WK32", "1") != "0"      # 32-deep weight tiles for conv_gemm_kernel (contiguous wave DMAs)
 HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
 
@@ -149,6 +150,7 @@ class Compiler:
         self.W = dict(weights)
         self.ops = list(desc["ops"])
         self.merged_gmac_credit = {}          # merged conv weight name -> algorithmic MAC factor of the original branches
+        self.pending_gate = {}                # SE output name -> gate view its depthwise consumer applies on load (F_GATE)
         self._merge_parallel_convs()
         self.N, self.H, self.Wd = batch, height, width
         self.fetch_cols = tuple(fetch_cols)
@@ -859,6 +861,7 @@ class Compiler:
         wname = op["in"]["Filter"][0]
         c, _, kh, kw = w.shape
         assert c == inv.c and inv.segs == [(0, c)]
+        gate = self.pending_gate.pop(op["in"]["Input"][0], None)
         inv = self.materialize(inv, outname)
         ep = self.absorb_epilogue(outname, i, c, allow_res=False)
         oh = (inv.h + 2 * ph - kh) // sh + 1
@@ -871,7 +874,8 @@ class Compiler:
         out = self.alloc_out(ep["out_name"], inv.n, oh, ow, c)
         w_off = self.add_weights(("dw", wname, ep["out_name"]), wk.astype(np.float16))
         b_off = self.add_weights(("dwb", wname, ep["out_name"]), bias)
-        self.emit(ir.OP_DWCONV, ep["out_name"], [inv], out,
+        self.emit(ir.OP_DWCONV, ep["out_name"], [inv] if gate is None else [inv, gate[0]], out,
+                  flags=0 if gate is None else (ir.F_GATE | gate[1]),
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
                      ir.P_ACT: ep["act"]},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
@@ -1061,6 +1065,18 @@ class Compiler:
                     outname = o2["out"]["Out"][0]
                     self.done.add(cons[0])
             assert big.segs == [(0, big.c)] and gate.segs == [(0, gate.c)]
+            # SE gate whose only consumer is a depthwise conv (the stage transitions of the HGNet recognisers): the conv
+            # applies the gate on load and the scaled tensor is never written
+            cons2 = self._live_consumers(outname)
+            if GATE_DW and len(cons2) == 1 and outname not in self.placement:
+                o2 = self.ops[cons2[0]]
+                if o2["type"] in ("conv2d", "depthwise_conv2d") and o2["in"]["Input"][0] == outname:
+                    w2 = self.W[o2["in"]["Filter"][0]]
+                    g2 = o2["attrs"].get("groups", 1)
+                    if (o2["type"] == "depthwise_conv2d" or (g2 > 1 and g2 == w2.shape[0])) and w2.shape[1] == 1 and w2.shape[0] == big.c:
+                        self.pending_gate[outname] = (gate, flags)
+                        self.env[outname] = big
+                        return
             out = self.alloc_out(outname, big.n, big.h, big.w, big.c)
             self.emit(ir.OP_SCALE, outname, [big, gate], out, flags=flags)
             self.env[outname] = out

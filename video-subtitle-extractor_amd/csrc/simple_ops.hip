@@ -22,10 +22,24 @@ __device__ __forceinline__ void st8(const TView& v, long pix, int c, half8 x) {
 }
 
 // ------------------------------------------------------------------------------------------------ depthwise
-__global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, const half_t* __restrict__ w,
+// gate.ptr != nullptr (F_GATE): the input is the un-gated tensor of an SE block; x * gate[n, c] is rounded to fp16 on load,
+// exactly what the separate scale pass would have stored.
+// mode 0: off, 1: x * g, 2: x * g + x (residual SE, OP_SCALE with F_RES)
+__device__ __forceinline__ half8 dw_gate(half8 x, const half8& g, int mode) {
+    if (mode) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (float)x[e] * (float)g[e];
+            x[e] = (half_t)(mode == 2 ? v + (float)x[e] : v);
+        }
+    }
+    return x;
+}
+__global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView gate, int gmode, const half_t* __restrict__ w,
                                                      const float* __restrict__ bias, int kh, int kw, int sh, int sw,
                                                      int ph, int pw, int act, float act_a, float act_b, float post_a,
                                                      float post_b) {
+    const int gated = gate.ptr != nullptr ? gmode : 0;
     const int cg = in.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -38,13 +52,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, const 
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = bias[g * 8 + e];
+        const half8 gv = gated ? ld8(gate, n, g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
         for (int dy = 0; dy < kh; ++dy) {
             const int ih = oh * sh - ph + dy;
             if (ih < 0 || ih >= in.h) continue;
             for (int dx = 0; dx < kw; ++dx) {
                 const int iw = ow * sw - pw + dx;
                 if (iw < 0 || iw >= in.w) continue;
-                const half8 x = ld8(in, (n * in.h + ih) * in.w + iw, g * 8);
+                const half8 x = dw_gate(ld8(in, (n * in.h + ih) * in.w + iw, g * 8), gv, gated);
                 const half8 k = *reinterpret_cast<const half8*>(w + (long)(dy * kw + dx) * in.c + g * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += (float)x[e] * (float)k[e];
@@ -62,10 +77,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, const 
 // weight vector once per tap instead of once per output.  Same accumulation order per output as dwconv_kernel (bias, then
 // taps row-major) -> bit-identical results.  The mobile (PP-LCNetV3 / MobileNetV3) models spend half of their time here.
 template <int KW, int SW>
-__global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, const half_t* __restrict__ w,
+__global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TView gate, int gmode, const half_t* __restrict__ w,
                                                          const float* __restrict__ bias, int kh, int sh, int ph, int pw,
                                                          int act, float act_a, float act_b, float post_a, float post_b) {
     constexpr int OUTW = 4, WIN = (OUTW - 1) * SW + KW;
+    const int gated = gate.ptr != nullptr ? gmode : 0;
     const int cg = in.c >> 3;
     const int owq = (out.w + OUTW - 1) / OUTW;
     const long total = (long)out.n * out.h * owq * cg;
@@ -82,6 +98,7 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, co
         for (int o = 0; o < OUTW; ++o)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[o][e] = bias[g * 8 + e];
+        const half8 gv = gated ? ld8(gate, n, g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
         for (int dy = 0; dy < kh; ++dy) {
             const int ih = oh * sh - ph + dy;
             if (ih < 0 || ih >= in.h) continue;
@@ -90,7 +107,7 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, co
 #pragma unroll
             for (int c = 0; c < WIN; ++c) {
                 const int iw = iw0 + c;
-                x[c] = (iw >= 0 && iw < in.w) ? ld8(in, rowpix + iw, g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+                x[c] = (iw >= 0 && iw < in.w) ? dw_gate(ld8(in, rowpix + iw, g * 8), gv, gated) : half8{0, 0, 0, 0, 0, 0, 0, 0};
             }
 #pragma unroll
             for (int dx = 0; dx < KW; ++dx) {
@@ -493,10 +510,14 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             const half_t* wk = reinterpret_cast<const half_t*>(wbase + op.w_off);
             const float* bk = reinterpret_cast<const float*>(wbase + op.b_off);
             const int kw = p[P_KW], sw = p[P_SW];
+            TView gate = in1;
+            const int gmode = (op.flags & F_RES) ? 2 : 1;
+            if (!(op.flags & F_GATE)) gate.ptr = nullptr;
+            else if (!in1.ptr || in1.c != in0.c || in1.n != in0.n || in1.esize != 2) return VSE_E_INVAL;
             if ((kw == 3 || kw == 5) && (sw == 1 || sw == 2)) {
                 const long items4 = (long)out.n * out.h * ((out.w + 3) / 4) * (in0.c >> 3);
                 const dim3 g4(grid_for(items4, 256)), b4(256);
-#define DW_ROW(KW_, SW_) hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_>), g4, b4, 0, st, in0, out, wk, bk, p[P_KH], p[P_SH], \
+#define DW_ROW(KW_, SW_) hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_>), g4, b4, 0, st, in0, out, gate, gmode, wk, bk, p[P_KH], p[P_SH], \
                                             p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B])
                 if (kw == 3 && sw == 1) DW_ROW(3, 1);
                 else if (kw == 3) DW_ROW(3, 2);
@@ -505,7 +526,7 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
 #undef DW_ROW
                 break;
             }
-            hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, wk, bk, p[P_KH], p[P_KW],
+            hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, gate, gmode, wk, bk, p[P_KH], p[P_KW],
                                p[P_SH], p[P_SW], p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A],
                                f[FS_POST_B]);
             break;
