@@ -160,6 +160,10 @@ class Emulator:
             assert not wfull[:, taps:].any() and not wfull[:, :, cinp:].any()
             row_major = [(t % kw) * kh + t // kw for t in range(taps)]     # stream is column-major: t' = dx*kh + dy
             wmat = np.ascontiguousarray(wfull[:, :taps, :cinp][:, row_major, :]).reshape(Np, taps * cinp)
+        elif int(r["flags"]) & ir.F_STEM:
+            wt = self.wread(int(r["w_off"]), Np * 80, np.float16).astype(np.float32).reshape(Np, 10, 8)
+            assert not wt[:, 9:].any() and not wt[:, :, 4:].any() and (kh, kw, cinp) == (3, 3, 8)
+            wmat = np.ascontiguousarray(wt[:, :9]).reshape(Np, 72)
         else:
             kt = 32 if int(r["flags"]) & ir.F_WK32 else KT
             wt = self.wread(int(r["w_off"]), (Kp // kt) * Np * kt, np.float16).astype(np.float32)

@@ -98,6 +98,11 @@ CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (160, 72, (5, 5), (1, 1), (2, 2), 10, 12, 1),      # 25 taps, map too small for the patch kernel
     (32, 48, (2, 2), (2, 2), (0, 0), 18, 22, 2),       # even kernel, no padding
     (64, 200, (1, 1), (2, 2), (0, 0), 19, 27, 1),      # strided 1x1, cout tail inside the second tile
+    # conv_stem_kernel (3x3 over <= 4 real channels; the 1x1 in front keeps 3 channels)
+    (3, 64, (3, 3), (2, 2), (1, 1), 37, 70, 2),        # stride 2, odd map, row / column tile tails
+    (3, 16, (3, 3), (2, 2), (1, 1), 48, 64, 1),        # 16 couts (mobile stems): second cout tile idle
+    (3, 40, (3, 3), (1, 1), (1, 1), 19, 45, 2),        # stride 1, cout tail inside the second tile
+    (4, 64, (3, 3), (2, 2), (1, 1), 16, 32, 1),        # 4 real channels, exactly one tile
 ]
 
 

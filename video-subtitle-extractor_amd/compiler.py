@@ -138,6 +138,7 @@ PATCH_MIN_TILE_EFF = float(os.environ.get("VSE_PATCH_MINEFF", "0.5"))
 PATCH_LIGHT = int(os.environ.get("VSE_PATCH_LIGHT", "2"))
 # evaluate the PP-OCRv4 server detector's last 3x3 conv on the low-res grid (conv_head.hip); VSE_HEAD_UP2=0 keeps it on
 # the patch kernel (experiments / A-B)
+STEM = os.environ.get("VSE_STEM", "1") != "0"         # conv_stem_kernel for 3x3 convs over <= 4 real channels
 GATE_DW = os.environ.get("VSE_GATE_DW", "1") != "0"   # SE gate folded into a depthwise consumer
 WK32 = os.environ.get("VSE_WK32", "1") != "0"      # 32-deep weight tiles for conv_gemm_kernel (contiguous wave DMAs)
 HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
@@ -606,6 +607,17 @@ class Compiler:
         return np.ascontiguousarray(t).astype(np.float16)
 
     @staticmethod
+    def stem_weights(mat):
+        """[Np][9 taps x 8 padded channels (+ K padding)] -> [Np][10 taps][8 channels] fp16 (tap 9 and channels 4..7 zero):
+        the generic kernels' K order, so the accumulation order (and every output bit) stays theirs."""
+        npad = mat.shape[0]
+        full = mat[:, :72].reshape(npad, 9, 8)
+        assert not full[:, :, 4:].any(), "stem kernel: more than 4 real input channels"
+        out = np.zeros((npad, 10, 8), np.float64)
+        out[:, :9] = full
+        return out.reshape(-1).astype(np.float16)
+
+    @staticmethod
     def gemm_eligible(kh, kw, ph, pw, cinp, inshift, flags):
         """Mirror of conv_gemm_mode() (csrc/conv_gemm.hip): the layer runs on conv_gemm_kernel.  The launcher refuses an
         F_WK32 op it cannot send there, so a drift between the two rules fails loudly instead of computing garbage."""
@@ -826,6 +838,12 @@ class Compiler:
             w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"], ptaps),
                                      lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh, kw,
                                                                 inv.span, ptaps))
+        elif (STEM and (kh, kw, ph, pw) == (3, 3, 1, 1) and (sh, sw) in ((1, 1), (2, 2)) and inv.span == 8 and cin <= 4
+              and coutp <= 64 and inv.parts is None and inv_main.up == 0 and dot is None and flags in (0, ir.F_RES)):
+            # stem over an image-like input (conv_stem.hip)
+            flags |= ir.F_STEM
+            w_off = self.add_weights(("convs", wname, tuple(inv.segs), ep["out_name"]),
+                                     lambda: self.stem_weights(self.pack_conv_weights(w, ep["scale"], inv)[0]))
         else:
             wk32 = WK32 and dot is None and self.gemm_eligible(kh, kw, ph, pw, inv.span, inv_main.up, flags)
             if wk32:

@@ -255,6 +255,8 @@ __device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const fl
 int launch_conv_patch(const ConvParams& p, int n_img, hipStream_t st);
 // DB head evaluated on the low-resolution grid (conv_head.hip, F_UP2HEAD)
 int launch_conv_head_up2(const ConvParams& p, int n_img, hipStream_t st);
+// 3x3 stem over <= 4 real input channels (conv_stem.hip, F_STEM)
+int launch_conv_stem(const ConvParams& p, int n_img, hipStream_t st);
 // scalar-addressed implicit GEMM (conv_gemm.hip): VSE_E_UNSUPPORTED when the layer is not eligible
 int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st);
 int conv_gemm_config(int Np, int cinp, long M);   // index into the tile-configuration table of conv_gemm.hip

@@ -277,6 +277,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     if ((a.flags & (F_DOT1 | F_SRC2)) && !(a.flags & F_PATCH)) return VSE_E_UNSUPPORTED;
     if (!a.zero) return VSE_E_INVAL;
     if (a.flags & F_UP2HEAD) return launch_conv_head_up2(p, a.in.n, st);
+    if (a.flags & F_STEM) return launch_conv_stem(p, a.in.n, st);
     if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
     if (a.Kp % 64) return VSE_E_INVAL;
     static const bool use_gemm = [] { const char* e = getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();

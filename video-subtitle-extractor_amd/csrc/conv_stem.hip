@@ -1,0 +1,114 @@
+// 3x3 stem convolution over an image-like input (<= 4 real channels, stored 8-channel padded): F_STEM.
+//
+// The generic kernels treat the stem as an implicit GEMM with K = 9 taps x 8 padded channels = 72 -> 128: 79 % of the
+// MFMA work multiplies padding and every tap re-gathers its pixels through L2 (0.65 ms for the detector's 64 x 544 x 960
+// stem against 0.27 ms of compulsory HBM traffic).  Here a block stages the input patch of an 8 x 32 output tile in LDS
+// ONCE (first 4 channels = 8 bytes per pixel) and the whole weight matrix (<= 64 couts x 80) lives in 40 VGPRs per lane.
+// K keeps the generic kernels' order — k slice ks = taps 2ks and 2ks+1 with 8 channels each (4..7 zero, tap 9 zero) — so
+// the fp32 accumulation order, and with it every output bit, is the one of conv_mfma_kernel (a 12-tap x 4-channel K
+// would save 8 of 20 MFMAs per wave, but changes the rounding of a few outputs per million, and box corners of the real
+// detector moved by a pixel in the parity test; the kernel is bound by its loads and stores, not by the MFMAs).
+//   block = 256 threads = 4 waves, wave w -> output rows 2w, 2w+1 of the tile, all couts (2 x 32-cout MFMA tiles)
+//   LDS   = ((8-1)*sh+3) x ((32-1)*sw+3) pixels x 8 B  (17 x 65 x 8 = 8.8 KiB at stride 2) + bias
+//   B fragment of k slice ks for lane (px, fj): tap 2 ks + fj -> one ds_read_b64 at the pixel that tap addresses (upper four
+//   channels zero); tap 9 carries zero weights and reads tap 0's pixel.
+// Same epilogue as every other conv kernel (conv_epilogue_tile).  Weights are packed [Np][10 taps][8] by the compiler.
+#include "conv_common.h"
+
+#define ST_ROWS 8
+#define ST_COLS 32
+
+template <int SH, int SW>
+__global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
+    constexpr int PH_ = (ST_ROWS - 1) * SH + 3, PW_ = (ST_COLS - 1) * SW + 3, NPIX = PH_ * PW_;
+    __shared__ __attribute__((aligned(16))) half_t patch[NPIX * 4 + 128];      // + 64 floats of bias
+    float* const sbias = reinterpret_cast<float*>(patch + NPIX * 4);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- weights: lane (f = lane & 31, fj) supplies cout conv_wrow(f) of each 32-cout tile, k = 16 ks + 8 fj .. +7 ----------
+    const int fx = lane & 31, fj = lane >> 5;
+    half8 wf[2][5];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * 32 + conv_wrow(fx);
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks)
+            wf[j][ks] = r < p.Np ? *reinterpret_cast<const half8*>(p.w + (long)r * 80 + ks * 16 + fj * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    if (tid < 64) sbias[tid] = tid < p.Np ? p.bias[tid] : 0.f;
+
+    // (one tile per block: a block that walks 8 consecutive tiles was measured 15 % slower — its tiles run back to back
+    // and nothing overlaps inside it, while 4 resident blocks per CU overlap each other's load / compute / store phases)
+    unsigned t = blockIdx.x;
+    const int tx = t % p.tiles_w;  t /= p.tiles_w;
+    const int ty = t % p.tiles_h;
+    const long img = t / p.tiles_h;
+    const int oy0 = ty * ST_ROWS, ox0 = tx * ST_COLS;
+    const int iy0 = oy0 * SH - p.ph, ix0 = ox0 * SW - p.pw;
+
+    // ---- input patch: channels 0..3 of every pixel, zeros outside the image ---------------------------------------------------
+    const half_t* base = p.in + img * (long)p.Hs * p.Ws * p.in_ld;
+    for (int q = tid; q < NPIX; q += 256) {
+        const int py = q / PW_, px = q - py * PW_;
+        const int iy = iy0 + py, ix = ix0 + px;
+        half4 v = half4{0, 0, 0, 0};
+        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const half4*>(base + ((long)iy * p.Ws + ix) * p.in_ld);
+        *reinterpret_cast<half4*>(patch + q * 4) = v;
+    }
+    __syncthreads();
+
+    // ---- 20 MFMAs per wave -------------------------------------------------------------------------------------------------------
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+        int t0 = 2 * ks + fj;
+        t0 = t0 < 9 ? t0 : 0;                      // zero-weight tap: any valid pixel
+        const int o0 = (t0 / 3) * PW_ + t0 % 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = ((2 * wave + i) * SH) * PW_ + fx * SW;
+            const half4 a = *reinterpret_cast<const half4*>(patch + (q + o0) * 4);
+            const half8 xf = half8{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], xf, acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int oy = oy0 + 2 * wave + i, ox = ox0 + fx;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        const long m = (img * p.OH + oy) * p.OW + ox;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j * 32 >= p.Np) continue;
+            float bias[16];
+            conv_epilogue_consts(sbias, j * 32, lane, bias);
+            conv_epilogue_tile(p, acc[i][j], bias, m, img, oy, ox, j * 32, lane);
+        }
+    }
+}
+
+int launch_conv_stem(const ConvParams& pin, int n_img, hipStream_t st) {
+    ConvParams p = pin;
+    if (p.kh != 3 || p.kw != 3 || p.ph != 1 || p.pw != 1 || p.cinp != 8 || p.inshift != 0 || p.Np > 64) return VSE_E_INVAL;
+    if (p.flags & (F_PIXSHUF | F_DOT1 | F_SRC2 | F_PATCH | F_UP2HEAD)) return VSE_E_INVAL;
+    if (!((p.sh == 1 && p.sw == 1) || (p.sh == 2 && p.sw == 2))) return VSE_E_INVAL;
+    p.tiles_h = (p.OH + ST_ROWS - 1) / ST_ROWS;
+    p.tiles_w = (p.OW + ST_COLS - 1) / ST_COLS;
+    const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w;
+    if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
+    if (p.sh == 2) hipLaunchKernelGGL((conv_stem_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_stem_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}

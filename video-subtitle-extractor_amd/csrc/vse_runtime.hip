@@ -201,6 +201,7 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     const vse_op& o = p->ops[i];
     if (o.kind != OP_CONV) return 0;
     if (o.flags & F_UP2HEAD) return 400000;   // conv_head_up2_kernel
+    if (o.flags & F_STEM) return 500000;      // conv_stem_kernel
     if (o.flags & F_PATCH) {   // conv_patch_kernel<TH, BN, BIGP> -> 100000*BIGP + 1000*TH + BN
         // conv_patch_kernel<TH, BN, MODE> -> 100000*MODE + 1000*TH + BN
         int th, bn, mode;
