@@ -162,7 +162,8 @@ class OcrPipeline:
         main = t.cuda.current_stream(self.ctx.tdev)
         if nstreams > 1:
             if len(getattr(self, "_streams", [])) < nstreams:
-                self._streams = [t.cuda.Stream(device=self.ctx.tdev) for _ in range(nstreams)]
+                self._streams = [t.cuda.Stream(device=self.ctx.tdev, priority=getattr(self, "rec_stream_priority", -1))
+                                 for _ in range(nstreams)]
             for st in self._streams[:nstreams]:
                 st.wait_stream(main)
         for gi, (idx, img_w) in enumerate(groups):
