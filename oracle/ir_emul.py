@@ -166,7 +166,10 @@ class Emulator:
             wmat = np.ascontiguousarray(wt[:, :9]).reshape(Np, 72)
         else:
             kt = 32 if int(r["flags"]) & ir.F_WK32 else KT
-            wt = self.wread(int(r["w_off"]), (Kp // kt) * Np * kt, np.float16).astype(np.float32)
+            cnt = (Kp // kt) * Np * kt
+            wt = self.wread(int(r["w_off"]), cnt, np.float16).astype(np.float32)
+            if int(r["flags"]) & ir.F_HILO:           # w = hi + lo (the lo tiles follow the hi tiles)
+                wt = wt + self.wread(int(r["w_off"]) + 2 * cnt, cnt, np.float16).astype(np.float32)
             wmat = wt.reshape(Kp // kt, Np, kt).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]
         w4 = torch.from_numpy(np.ascontiguousarray(wmat.reshape(Np, kh, kw, cinp).transpose(0, 3, 1, 2)))
         bias = torch.from_numpy(self.wread(int(r["b_off"]), Np, np.float32).copy())
@@ -200,7 +203,10 @@ class Emulator:
             g = self.read(r["in1"])
             x = ((x * g + x) if int(r["flags"]) & ir.F_RES else x * g).half().float()
         cp = x.shape[3]
-        wk = self.wread(int(r["w_off"]), kh * kw * cp, np.float16).astype(np.float32).reshape(kh, kw, cp)
+        wk = self.wread(int(r["w_off"]), kh * kw * cp, np.float16).astype(np.float32)
+        if int(r["flags"]) & ir.F_HILO:
+            wk = wk + self.wread(int(r["w_off"]) + 2 * kh * kw * cp, kh * kw * cp, np.float16).astype(np.float32)
+        wk = wk.reshape(kh, kw, cp)
         w4 = torch.from_numpy(np.ascontiguousarray(wk.transpose(2, 0, 1)[:, None]))
         bias = torch.from_numpy(self.wread(int(r["b_off"]), cp, np.float32).copy())
         y = F.conv2d(x.permute(0, 3, 1, 2), w4, bias, (sh, sw), (ph, pw), groups=cp).permute(0, 2, 3, 1)

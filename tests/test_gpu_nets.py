@@ -134,3 +134,33 @@ def test_conv_shapes(ctx, cin, cout, k, s, p, h, w, n):
     assert got.shape == ref.shape
     err = np.abs(got - ref).max()
     assert err < 2e-2 * max(1.0, np.abs(ref).max()), err
+
+
+@pytest.mark.parametrize("mid", ["V3_ch_det_fast", "V4_ch_det_fast", "V2_ch_det"])
+def test_hilo_weights_on_gpu(ctx, mid):
+    """fp16 hi + lo weight pairs (F_HILO: two K passes in conv_gemm_kernel / conv_mfma_kernel, hi + lo tables in the depthwise
+    kernels) against the CPU emulator of the same program and against the fp32 interpreter."""
+    import torch
+    from vse_amd import compiler, engine
+    desc, w = net_ref.get_weights(mid)
+    if mid == "V3_ch_det_fast":
+        from vse_amd import synth
+        from oracle import pipeline_ref
+        x = np.concatenate([pipeline_ref.det_preprocess(f)[0] for f in synth.make_frames(2, 270, 480, seed=5)])
+    else:
+        x = np.random.default_rng(0).uniform(-1, 1, (2, 3, 96, 160)).astype(np.float32)
+    x = x.astype(np.float16).astype(np.float32)
+    ref = net_ref.run_graph(desc, w, x)[0].numpy()[:, 0]
+    maps = {}
+    for hilo in (False, True):
+        net = engine.Net(ctx, desc, w, hilo=hilo)
+        maps[hilo] = net.run(torch.from_numpy(ir_emul.to_nhwc8(x).astype(np.float16)).cuda())[0].cpu().numpy()[..., 0]
+    prog = compiler.compile_model(desc, w, x.shape[0], x.shape[2], x.shape[3], hilo=True)
+    emu = ir_emul.Emulator(prog, round_f16=True).run(ir_emul.to_nhwc8(x).astype(np.float16))[0][..., 0]
+    # same program with fp16 storage emulated (summation order differs; the real-weight net's head amplifies fp16 ulp flips ~15x)
+    real = mid == "V3_ch_det_fast"
+    assert np.abs(maps[True] - emu).max() < (3e-2 if real else 2e-3)
+    e_lo, e_hi = np.abs(maps[False] - ref).max(), np.abs(maps[True] - ref).max()
+    assert e_hi < (5e-2 if real else 1e-2) and e_hi <= e_lo + 1e-4, (e_lo, e_hi)
+    if real:        # (stand-in nets put arbitrary pixels next to the threshold: flip counts mean nothing there)
+        assert ((maps[True] > 0.3) != (ref > 0.3)).sum() <= ((maps[False] > 0.3) != (ref > 0.3)).sum()

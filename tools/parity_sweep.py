@@ -20,13 +20,17 @@ def iou(a, b):
 
 
 def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-    h = int(sys.argv[2]) if len(sys.argv) > 2 else 1080
-    w = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
+    args = [a for a in sys.argv[1:] if not a.startswith("-")]
+    sys.argv = [sys.argv[0]] + args + [a for a in sys.argv[1:] if a.startswith("-")]
+    n = int(sys.argv[1]) if len(args) > 0 else 32
+    h = int(sys.argv[2]) if len(args) > 1 else 1080
+    w = int(sys.argv[3]) if len(args) > 2 else 1920
     ctx = engine.Context(0)
     det = net_ref.get_weights("V3_ch_det_fast")
     rec = net_ref.get_weights("V4_en_rec_fast")
-    pipe = pipeline.OcrPipeline(ctx, det, rec, P.en_charset(), rec_mode="reference")
+    dw = "fp16" if "--fp16" in sys.argv else "auto"          # auto = fp16 hi + lo weight pairs for this (mobile) detector
+    pipe = pipeline.OcrPipeline(ctx, det, rec, P.en_charset(), rec_mode="reference", det_weights=dw)
+    print("detector weights:", pipe.det_weights)
     frames = synth.make_frames(n, h, w, seed=777, p_two_lines=0.5)
     got = pipe.ocr(torch.from_numpy(frames).cuda())
     nb = same = cnt_mismatch = 0

@@ -151,6 +151,7 @@ class Compiler:
         self.W = dict(weights)
         self.ops = list(desc["ops"])
         self.merged_gmac_credit = {}          # merged conv weight name -> algorithmic MAC factor of the original branches
+        self.hilo = False                     # fp16 hi + lo weight pairs (compile_model(hilo=True))
         self.pending_gate = {}                # SE output name -> gate view its depthwise consumer applies on load (F_GATE)
         self._merge_parallel_convs()
         self.N, self.H, self.Wd = batch, height, width
@@ -600,11 +601,15 @@ class Compiler:
         return mat, coutp, Kp
 
     @staticmethod
-    def tile_weights(mat, kt=ir.KT):
-        """[Np][Kp] -> [Kp/kt][Np][kt] fp16."""
+    def tile_weights(mat, kt=ir.KT, hilo=False):
+        """[Np][Kp] -> [Kp/kt][Np][kt] fp16; hilo: the tiles of hi = fp16(w) followed by the tiles of lo = fp16(w - hi)."""
         npad, kp = mat.shape
-        t = mat.reshape(npad, kp // kt, kt).transpose(1, 0, 2)
-        return np.ascontiguousarray(t).astype(np.float16)
+        t = np.ascontiguousarray(mat.reshape(npad, kp // kt, kt).transpose(1, 0, 2))
+        hi = t.astype(np.float16)
+        if not hilo:
+            return hi
+        lo = (t - hi.astype(np.float64)).astype(np.float16)
+        return np.concatenate([hi.reshape(-1), lo.reshape(-1)])
 
     @staticmethod
     def stem_weights(mat):
@@ -750,9 +755,10 @@ class Compiler:
                 bias[q * coutp:q * coutp + cout] = ep["shift"]
             oh, ow = inv.h * 2, inv.w * 2
             out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
-            w_off = self.add_weights(("convT", wname, tuple(inv.segs), ep["out_name"]), self.tile_weights(mat))
+            w_off = self.add_weights(("convT", wname, tuple(inv.segs), ep["out_name"], self.hilo),
+                                     self.tile_weights(mat, hilo=self.hilo))
             b_off = self.add_weights(("convTb", wname, ep["out_name"]), bias)
-            self.emit(ir.OP_CONV, ep["out_name"], [inv], out, flags=ir.F_PIXSHUF,
+            self.emit(ir.OP_CONV, ep["out_name"], [inv], out, flags=ir.F_PIXSHUF | (ir.F_HILO if self.hilo else 0),
                       p={ir.P_KH: 1, ir.P_KW: 1, ir.P_SH: 1, ir.P_SW: 1, ir.P_PH: 0, ir.P_PW: 0,
                          ir.P_ACT: ep["act"], ir.P_ACT2: 0, ir.P_COUT: 4 * coutp, ir.P_KTOT: Kp,
                          ir.P_INSHIFT: 0, ir.P_RESSHIFT: 0, ir.P_CINP: inv.span},
@@ -827,7 +833,7 @@ class Compiler:
         head = (dot is not None and (flags & ir.F_SRC2) and res is None and (kh, kw, ph, pw) == (3, 3, 1, 1)
                 and in2shift == 1 and inv_main.up == 0 and inv_main.span == 8 and inv_main.c == 1
                 and inv.parts[1].span == 64 and inv.span == 72 and coutp <= 64
-                and (oh, ow) == (inv.parts[1].h, inv.parts[1].w) and oh % 2 == 0 and ow % 2 == 0 and HEAD_UP2)
+                and (oh, ow) == (inv.parts[1].h, inv.parts[1].w) and oh % 2 == 0 and ow % 2 == 0 and HEAD_UP2 and not self.hilo)
         if head:
             flags |= ir.F_UP2HEAD
             Kp = 2 * 4 * 4 * 32 + 32
@@ -838,7 +844,7 @@ class Compiler:
             w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"], ptaps),
                                      lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh, kw,
                                                                 inv.span, ptaps))
-        elif (STEM and (kh, kw, ph, pw) == (3, 3, 1, 1) and (sh, sw) in ((1, 1), (2, 2)) and inv.span == 8 and cin <= 4
+        elif (STEM and not self.hilo and (kh, kw, ph, pw) == (3, 3, 1, 1) and (sh, sw) in ((1, 1), (2, 2)) and inv.span == 8 and cin <= 4
               and coutp <= 64 and inv.parts is None and inv_main.up == 0 and dot is None and flags in (0, ir.F_RES)):
             # stem over an image-like input (conv_stem.hip)
             flags |= ir.F_STEM
@@ -848,8 +854,11 @@ class Compiler:
             wk32 = WK32 and dot is None and self.gemm_eligible(kh, kw, ph, pw, inv.span, inv_main.up, flags)
             if wk32:
                 flags |= ir.F_WK32
-            w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"], wk32),
-                                     lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], 32 if wk32 else ir.KT))
+            if self.hilo:
+                flags |= ir.F_HILO
+            w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"], wk32, self.hilo),
+                                     lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], 32 if wk32 else ir.KT,
+                                                               hilo=self.hilo))
         b_off = self.add_weights(("convb", wname, ep["out_name"]), bias)
         if dot is not None:
             aux_off = self.add_weights(("dot1", dot["wname"], ep["out_name"]), dot["w"])
@@ -890,10 +899,13 @@ class Compiler:
         bias = np.zeros(cp, np.float32)
         bias[:c] = ep["shift"]
         out = self.alloc_out(ep["out_name"], inv.n, oh, ow, c)
-        w_off = self.add_weights(("dw", wname, ep["out_name"]), wk.astype(np.float16))
+        wk_hi = wk.astype(np.float16)
+        if self.hilo:       # [2][taps][cp]: hi table, then lo = fp16(w - hi)
+            wk_hi = np.concatenate([wk_hi.reshape(-1), (wk.astype(np.float64) - wk_hi.astype(np.float64)).astype(np.float16).reshape(-1)])
+        w_off = self.add_weights(("dw", wname, ep["out_name"], self.hilo), wk_hi)
         b_off = self.add_weights(("dwb", wname, ep["out_name"]), bias)
         self.emit(ir.OP_DWCONV, ep["out_name"], [inv] if gate is None else [inv, gate[0]], out,
-                  flags=0 if gate is None else (ir.F_GATE | gate[1]),
+                  flags=(0 if gate is None else (ir.F_GATE | gate[1])) | (ir.F_HILO if self.hilo else 0),
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
                      ir.P_ACT: ep["act"]},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
@@ -1357,6 +1369,12 @@ class Compiler:
         return r
 
 
-def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True):
-    """reuse=False gives every buffer its own workspace range (debugging: all intermediates stay readable)."""
-    return Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse).compile()
+def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True, hilo=False):
+    """reuse=False gives every buffer its own workspace range (debugging: all intermediates stay readable).
+    hilo=True stores every conv / depthwise / transposed-conv weight as an fp16 hi + lo pair (F_HILO): ~22-bit weights for
+    twice the MFMA work — for nets whose boxes must track an fp32 reference closely."""
+    c = Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse)
+    c.hilo = bool(hilo)
+    if c.hilo:
+        c.use_patch = False          # the two-pass K walk lives in the implicit-GEMM kernels only
+    return c.compile()

@@ -14,6 +14,7 @@ struct ConvParams {
     long M;
     int kh, kw, sh, sw, ph, pw;
     int Np, nk;
+    int nkh;                // F_HILO: K tiles of ONE pass over the taps (nk = 2 * nkh: hi weights, then lo weights); else = nk
     int out_ld, out_f32;
     int res_ld, resshift, res_hs, res_ws;
     int act, act2;

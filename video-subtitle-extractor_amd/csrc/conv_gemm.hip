@@ -171,6 +171,7 @@ void conv_gemm_kernel(const ConvParams p) {
             ++tap;
             if (++dx == p.kw) { dx = 0; ++dy; }
         }
+        if (kt + 1 == p.nkh) { kc = 0; dx = 0; dy = 0; tap = 0; }      // F_HILO: second pass (lo weight tiles), same activations
     };
 
     float16v acc[TM][TN];
@@ -375,6 +376,8 @@ int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st) {
     const GemmCfg& g = kCfg[c];
     p.ntn = (unsigned)((p.Np + g.bn - 1) / g.bn);
     p.nk = Kp / g.bk;
+    p.nkh = p.nk;
+    if (p.flags & F_HILO) p.nk *= 2;
     const unsigned long long tiles = (unsigned long long)((p.M + g.bm - 1) / g.bm) * p.ntn;
     if (tiles == 0 || tiles > 0x7fffffffull) return VSE_E_INVAL;
     dim3 grid((unsigned)tiles);

@@ -128,6 +128,13 @@ __global__ __launch_bounds__(256, (BM + (BN < 64 ? 64 : BN)) <= 256 ? 3 : 2) voi
             kc -= p.cinp;
             if (++dx == p.kw) { dx = 0; ++dy; }
         }
+        if (kt + 1 == p.nkh) {                   // F_HILO: the walk over the taps starts again for the lo weight tiles
+            kc = kv * 8; dy = 0; dx = 0;
+            while (kc >= p.cinp) {
+                kc -= p.cinp;
+                if (++dx == p.kw) { dx = 0; ++dy; }
+            }
+        }
     };
 
     float16v acc[TM][TN];
@@ -244,6 +251,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.M = (long)a.in.n * p.OH * p.OW;
     p.Np = a.Np;
     p.nk = a.Kp / BK;
+    p.nkh = p.nk;
+    if (a.flags & F_HILO) p.nk *= 2;          // second pass over the same activations with the lo weight tiles
     p.zero = a.zero;
     p.out_ld = a.out.ld;
     p.out_f32 = (a.flags & F_OUT_F32) ? 1 : 0;

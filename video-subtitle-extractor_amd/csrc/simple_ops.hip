@@ -35,7 +35,7 @@ __device__ __forceinline__ half8 dw_gate(half8 x, const half8& g, int mode) {
     }
     return x;
 }
-__global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView gate, int gmode, const half_t* __restrict__ w,
+__global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView gate, int gmode, int hilo, const half_t* __restrict__ w,
                                                      const float* __restrict__ bias, int kh, int kw, int sh, int sw,
                                                      int ph, int pw, int act, float act_a, float act_b, float post_a,
                                                      float post_b) {
@@ -61,8 +61,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
                 if (iw < 0 || iw >= in.w) continue;
                 const half8 x = dw_gate(ld8(in, (n * in.h + ih) * in.w + iw, g * 8), gv, gated);
                 const half8 k = *reinterpret_cast<const half8*>(w + (long)(dy * kw + dx) * in.c + g * 8);
+                float kf[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (float)x[e] * (float)k[e];
+                for (int e = 0; e < 8; ++e) kf[e] = (float)k[e];
+                if (hilo) {                     // F_HILO: the lo table follows the kh*kw*C hi entries
+                    const half8 kl = *reinterpret_cast<const half8*>(w + (long)(kh * kw + dy * kw + dx) * in.c + g * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) kf[e] += (float)kl[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)x[e] * kf[e];
             }
         }
         half8 o;
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
 // weight vector once per tap instead of once per output.  Same accumulation order per output as dwconv_kernel (bias, then
 // taps row-major) -> bit-identical results.  The mobile (PP-LCNetV3 / MobileNetV3) models spend half of their time here.
 template <int KW, int SW>
-__global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TView gate, int gmode, const half_t* __restrict__ w,
+__global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TView gate, int gmode, int hilo, const half_t* __restrict__ w,
                                                          const float* __restrict__ bias, int kh, int sh, int ph, int pw,
                                                          int act, float act_a, float act_b, float post_a, float post_b) {
     constexpr int OUTW = 4, WIN = (OUTW - 1) * SW + KW;
@@ -112,12 +120,20 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
 #pragma unroll
             for (int dx = 0; dx < KW; ++dx) {
                 const half8 k = *reinterpret_cast<const half8*>(w + (long)(dy * KW + dx) * in.c + g * 8);
+                float kf[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kf[e] = (float)k[e];
+                if (hilo) {
+                    const half8 kl = *reinterpret_cast<const half8*>(w + (long)(kh * KW + dy * KW + dx) * in.c + g * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) kf[e] += (float)kl[e];
+                }
 #pragma unroll
                 for (int o = 0; o < OUTW; ++o) {
                     const int iw = iw0 + o * SW + dx;
                     if (iw < 0 || iw >= in.w) continue;           // the reference kernel skips padded taps (no +0 rounding issue, same sums)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[o][e] += (float)x[o * SW + dx][e] * (float)k[e];
+                    for (int e = 0; e < 8; ++e) acc[o][e] += (float)x[o * SW + dx][e] * kf[e];
                 }
             }
         }
@@ -512,12 +528,13 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             const int kw = p[P_KW], sw = p[P_SW];
             TView gate = in1;
             const int gmode = (op.flags & F_RES) ? 2 : 1;
+            const int hilo = (op.flags & F_HILO) ? 1 : 0;
             if (!(op.flags & F_GATE)) gate.ptr = nullptr;
             else if (!in1.ptr || in1.c != in0.c || in1.n != in0.n || in1.esize != 2) return VSE_E_INVAL;
             if ((kw == 3 || kw == 5) && (sw == 1 || sw == 2)) {
                 const long items4 = (long)out.n * out.h * ((out.w + 3) / 4) * (in0.c >> 3);
                 const dim3 g4(grid_for(items4, 256)), b4(256);
-#define DW_ROW(KW_, SW_) hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_>), g4, b4, 0, st, in0, out, gate, gmode, wk, bk, p[P_KH], p[P_SH], \
+#define DW_ROW(KW_, SW_) hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_>), g4, b4, 0, st, in0, out, gate, gmode, hilo, wk, bk, p[P_KH], p[P_SH], \
                                             p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B])
                 if (kw == 3 && sw == 1) DW_ROW(3, 1);
                 else if (kw == 3) DW_ROW(3, 2);
@@ -526,7 +543,7 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
 #undef DW_ROW
                 break;
             }
-            hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, gate, gmode, wk, bk, p[P_KH], p[P_KW],
+            hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, gate, gmode, hilo, wk, bk, p[P_KH], p[P_KW],
                                p[P_SH], p[P_SW], p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A],
                                f[FS_POST_B]);
             break;

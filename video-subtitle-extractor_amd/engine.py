@@ -223,12 +223,14 @@ class Context:
 class Net:
     """One model (descriptor + fp32 weights) with plans compiled per static input shape."""
 
-    def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True):
+    def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True, hilo=False):
+        """hilo=True: conv weights as fp16 hi + lo pairs (compiler.compile_model): ~22-bit weights, twice the MFMA work."""
         self.ctx = ctx
         self.desc = desc
         self.weights = weights
         self.fetch_cols = fetch_cols
         self.want_probs = want_probs
+        self.hilo = bool(hilo)
         self.store = compiler.WeightStore()
         self.plans = {}
         self.wid = None
@@ -239,7 +241,7 @@ class Net:
         key = (n, h, w)
         if key not in self.plans:
             prog = compiler.compile_model(self.desc, self.weights, n, h, w, self.fetch_cols, self.want_probs,
-                                          self.store)
+                                          self.store, hilo=self.hilo)
             self.plans[key] = [prog, None]
         return self.plans[key][0]
 

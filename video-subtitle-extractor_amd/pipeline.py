@@ -47,13 +47,27 @@ def crop_geometry(q):
     return cw, ch, rotate
 
 
+def resolve_det_weights(det_weights, weights):
+    """"auto" -> "fp16x2" (fp16 hi + lo weight pairs) for detectors under 4 M parameters, else "fp16"."""
+    if det_weights == "auto":
+        nparam = sum(int(np.prod(v.shape)) for v in weights.values())
+        det_weights = "fp16x2" if nparam < 4_000_000 else "fp16"
+    assert det_weights in ("fp16", "fp16x2"), det_weights
+    return det_weights
+
+
 class OcrPipeline:
     def __init__(self, ctx, det_model, rec_model, charset, rec_batch_num=6, rec_h=48, rec_base_w=320,
                  limit_side_len=960, db_thresh=0.3, db_box_thresh=0.6, db_unclip_ratio=1.5, drop_score=0.0,
-                 rec_mode="reference", bucket=64, batch_round=1, max_rec_batch=64):
-        """det_model / rec_model: (descriptor, weights dict)."""
+                 rec_mode="reference", bucket=64, batch_round=1, max_rec_batch=64, det_weights="auto"):
+        """det_model / rec_model: (descriptor, weights dict).
+        det_weights: "fp16" | "fp16x2" | "auto".  fp16x2 stores the detector's conv weights as fp16 hi + lo pairs (two K
+        passes into the same fp32 accumulators): the rounding of BN-folded weights to fp16 is what moves box borders against
+        an fp32 reference.  "auto" uses it for the mobile detectors (< 4 M parameters), where the second pass
+        hides behind the memory traffic, and plain fp16 for the server models."""
         self.ctx = ctx
-        self.det = engine.Net(ctx, det_model[0], det_model[1], fetch_cols=(0,))
+        self.det_weights = det_weights = resolve_det_weights(det_weights, det_model[1])
+        self.det = engine.Net(ctx, det_model[0], det_model[1], fetch_cols=(0,), hilo=det_weights == "fp16x2")
         self.rec = engine.Net(ctx, rec_model[0], rec_model[1], want_probs=False)
         self.charset = charset
         self.rec_batch_num = rec_batch_num
