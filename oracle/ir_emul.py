@@ -161,7 +161,10 @@ class Emulator:
             row_major = [(t % kw) * kh + t // kw for t in range(taps)]     # stream is column-major: t' = dx*kh + dy
             wmat = np.ascontiguousarray(wfull[:, :taps, :cinp][:, row_major, :]).reshape(Np, taps * cinp)
         elif int(r["flags"]) & ir.F_STEM:
-            wt = self.wread(int(r["w_off"]), Np * 80, np.float16).astype(np.float32).reshape(Np, 10, 8)
+            wt = self.wread(int(r["w_off"]), Np * 80, np.float16).astype(np.float32)
+            if int(r["flags"]) & ir.F_HILO:
+                wt = wt + self.wread(int(r["w_off"]) + 2 * Np * 80, Np * 80, np.float16).astype(np.float32)
+            wt = wt.reshape(Np, 10, 8)
             assert not wt[:, 9:].any() and not wt[:, :, 4:].any() and (kh, kw, cinp) == (3, 3, 8)
             wmat = np.ascontiguousarray(wt[:, :9]).reshape(Np, 72)
         else:

@@ -25,7 +25,7 @@ def main():
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 25
     desc, wts = modelzoo.get_model(mid)
     ctx = engine.Context(0)
-    net = engine.Net(ctx, desc, wts, want_probs=False)
+    net = engine.Net(ctx, desc, wts, want_probs=False, hilo="--hilo" in sys.argv)
     x = (torch.rand((n, h, w, 8), device="cuda") * 2 - 1).half()
     x[..., 3:] = 0
     for _ in range(2):

@@ -612,7 +612,7 @@ class Compiler:
         return np.concatenate([hi.reshape(-1), lo.reshape(-1)])
 
     @staticmethod
-    def stem_weights(mat):
+    def stem_weights(mat, hilo=False):
         """[Np][9 taps x 8 padded channels (+ K padding)] -> [Np][10 taps][8 channels] fp16 (tap 9 and channels 4..7 zero):
         the generic kernels' K order, so the accumulation order (and every output bit) stays theirs."""
         npad = mat.shape[0]
@@ -620,7 +620,10 @@ class Compiler:
         assert not full[:, :, 4:].any(), "stem kernel: more than 4 real input channels"
         out = np.zeros((npad, 10, 8), np.float64)
         out[:, :9] = full
-        return out.reshape(-1).astype(np.float16)
+        hi = out.reshape(-1).astype(np.float16)
+        if not hilo:
+            return hi
+        return np.concatenate([hi, (out.reshape(-1) - hi.astype(np.float64)).astype(np.float16)])
 
     @staticmethod
     def gemm_eligible(kh, kw, ph, pw, cinp, inshift, flags):
@@ -844,12 +847,12 @@ class Compiler:
             w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"], ptaps),
                                      lambda: self.patch_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh, kw,
                                                                 inv.span, ptaps))
-        elif (STEM and not self.hilo and (kh, kw, ph, pw) == (3, 3, 1, 1) and (sh, sw) in ((1, 1), (2, 2)) and inv.span == 8 and cin <= 4
+        elif (STEM and (kh, kw, ph, pw) == (3, 3, 1, 1) and (sh, sw) in ((1, 1), (2, 2)) and inv.span == 8 and cin <= 4
               and coutp <= 64 and inv.parts is None and inv_main.up == 0 and dot is None and flags in (0, ir.F_RES)):
             # stem over an image-like input (conv_stem.hip)
-            flags |= ir.F_STEM
-            w_off = self.add_weights(("convs", wname, tuple(inv.segs), ep["out_name"]),
-                                     lambda: self.stem_weights(self.pack_conv_weights(w, ep["scale"], inv)[0]))
+            flags |= ir.F_STEM | (ir.F_HILO if self.hilo else 0)
+            w_off = self.add_weights(("convs", wname, tuple(inv.segs), ep["out_name"], self.hilo),
+                                     lambda: self.stem_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], self.hilo))
         else:
             wk32 = WK32 and dot is None and self.gemm_eligible(kh, kw, ph, pw, inv.span, inv_main.up, flags)
             if wk32:

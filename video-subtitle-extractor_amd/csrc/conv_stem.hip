@@ -38,6 +38,17 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
         for (int ks = 0; ks < 5; ++ks)
             wf[j][ks] = r < p.Np ? *reinterpret_cast<const half8*>(p.w + (long)r * 80 + ks * 16 + fj * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
     }
+    // F_HILO: the fp16 lo parts of the weights (second block of Np x 80 halfs), multiplied in a second pass
+    const bool hilo = p.flags & F_HILO;
+    half8 wl[2][5];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * 32 + conv_wrow(fx);
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks)
+            wl[j][ks] = (hilo && r < p.Np) ? *reinterpret_cast<const half8*>(p.w + ((long)p.Np + r) * 80 + ks * 16 + fj * 8)
+                                           : half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
     if (tid < 64) sbias[tid] = tid < p.Np ? p.bias[tid] : 0.f;
 
     // (one tile per block: a block that walks 8 consecutive tiles was measured 15 % slower — its tiles run back to back
@@ -80,6 +91,23 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
             const half8 xf = half8{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][ks], xf, acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if (hilo) {
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) {
+            int t0 = 2 * ks + fj;
+            t0 = t0 < 9 ? t0 : 0;
+            const int o0 = (t0 / 3) * PW_ + t0 % 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = ((2 * wave + i) * SH) * PW_ + fx * SW;
+                const half4 a = *reinterpret_cast<const half4*>(patch + (q + o0) * 4);
+                const half8 xf = half8{a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j][ks], xf, acc[i][j], 0, 0, 0);
+            }
         }
     }
 
