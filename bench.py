@@ -146,7 +146,7 @@ def main():
     rec = modelzoo.get_model(rec_id, seed=1)
     if not modelzoo.has_real_weights(det_id):
         det = (det[0], empty_det_head(det[0], det[1]))
-    charset = shim.charset_for(lang, shim._ncls(rec[0]))
+    charset = shim.standin_charset(lang, shim._ncls(rec[0]))      # stand-in weights: index-faithful placeholder table
     pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="bucketed", bucket=args.bucket,
                                 batch_round=args.batch_round)
 

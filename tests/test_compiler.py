@@ -173,3 +173,18 @@ def test_light_patch_variant_selection():
             ptaps = int(p[ir.P_KTOT]) // ((int(p[ir.P_CINP]) + 31) // 32 * 32)
             seen.add((taps, ptaps))
     assert (9, 10) in seen and (81, 84) in seen and (49, 52) in seen and (25, 28) in seen
+
+
+@pytest.mark.parametrize("optype,attr,value", [("conv2d", "dilations", [2, 2]), ("conv2d", "padding_algorithm", "SAME"),
+                                               ("hard_swish", "offset", 2.0), ("nearest_interp_v2", "align_corners", True),
+                                               ("depthwise_conv2d", "dilations", [1, 2])])
+def test_unsupported_attribute_values_fail_loudly(optype, attr, value):
+    """A descriptor converted from another export (SAME padding, dilated conv, ...) must not compile into a program that
+    silently computes different values: the lowering hard-codes these attributes, so it refuses anything else."""
+    import copy
+    desc, w = net_ref.get_weights("V4_ch_det_fast")
+    desc = copy.deepcopy(desc)
+    op = next(o for o in desc["ops"] if o["type"] == optype)
+    op["attrs"][attr] = value
+    with pytest.raises(compiler.UnsupportedGraph, match=attr):
+        compiler.compile_model(desc, w, 1, 64, 96)

@@ -193,3 +193,69 @@ def test_box_parity_rate_real_detector(ctx):
             same += int(np.array_equal(np.asarray(a), np.asarray(b)))
             low += int(_iou(np.asarray(a), np.asarray(b)) < 0.99)
     assert n >= 20 and same >= 0.95 * n and low <= 1, (n, same, low)
+
+
+@pytest.mark.parametrize("mode", ["bucketed", "reference"])
+def test_recognizer_side_streams_keep_results(ctx, mode):
+    """rec_streams > 1: width groups run on side streams.  Groups that share one plan key (n, h, w) — a bucket split into
+    max_rec_batch chunks, reference-mode chunks of equal shape — are in flight at the same time and must each own a
+    workspace slot: results equal the single-stream run."""
+    import torch
+    from vse_amd import pipeline, synth
+    det = net_ref.get_weights("V3_ch_det_fast")
+    rec = net_ref.get_weights("V4_en_rec_fast")
+    frames, truth = synth.make_frames(6, 720, 1280, seed=11, p_two_lines=1.0, return_truth=True)
+    quads = [[np.array([[x0 - 4, y0 - 4], [x1 + 4, y0 - 4], [x1 + 4, y1 + 4], [x0 - 4, y1 + 4]], np.float32)
+              for (x0, y0, x1, y1, _t) in tr] for tr in truth]
+    # every box three times: 36 crops, buckets of >= 8 crops split into chunks of 4 -> several groups per plan key
+    quads = [q + q + q for q in quads]
+    dev = torch.from_numpy(frames).cuda()
+    pipe = pipeline.OcrPipeline(ctx, det, rec, P.en_charset(), rec_mode=mode, bucket=256, max_rec_batch=4, rec_batch_num=2)
+    groups = pipe._groups(pipe._crop_specs(quads))
+    keys = [(len(idx), w) for idx, w in groups]
+    assert len(keys) > len(set(keys)), "the case must contain groups that share a plan key"
+    pipe.rec_streams = 1
+    want = pipe.recognize(dev, quads)
+    for streams in (2, 3):
+        pipe.rec_streams = streams
+        for _ in range(3):
+            assert pipe.recognize(dev, quads) == want
+    assert torch.cuda.current_stream(ctx.tdev) == torch.cuda.default_stream(ctx.tdev)
+
+
+def test_text_recognizer_call_site(ctx):
+    """paddleocr TextRecognizer(args)(img_list): ready-made crops of different sizes, grouped like the reference (sorted
+    by w/h, chunks of rec_batch_num, padded to the chunk's widest) — checked against the oracle recogniser."""
+    from types import SimpleNamespace
+    from vse_amd import shim, synth
+    shim.config.allow_standin_weights = True
+    frames, truth = synth.make_frames(3, 720, 1280, seed=21, p_two_lines=1.0, return_truth=True)
+    crops = []
+    for f, tr in enumerate(truth):
+        for (x0, y0, x1, y1, _t) in tr:
+            crops.append(np.ascontiguousarray(frames[f][y0 - 3:y1 + 3, x0 - 3:x1 + 3]))
+    crops.append(np.ascontiguousarray(crops[0][:, :40]))          # a short one: padded to the 320-px base width
+    tr = shim.TextRecognizer(SimpleNamespace(rec_model_dir="V4_en_rec_fast", rec_image_shape="3,48,320", lang="en",
+                                             rec_batch_num=3))
+    got, elapse = tr(crops)
+    assert len(got) == len(crops) and elapse > 0
+    rec = net_ref.get_weights("V4_en_rec_fast")
+    charset = P.en_charset()
+    exact = 0
+    for idx, img_w in P.rec_batches(crops, 3):
+        batch = np.stack([P.resize_norm_img(crops[i], img_w) for i in idx])
+        probs = net_ref.run_graph(rec[0], rec[1], batch)[0].numpy()
+        for k, i in enumerate(idx):
+            ids, conf = P.ctc_greedy(probs[k])
+            srt = np.sort(probs[k], -1)
+            shaky = int(((srt[:, -1] - srt[:, -2]) < 0.05 * srt[:, -1]).sum())
+            text, score = got[i]
+            if text == P.decode_text(ids, charset):
+                exact += 1
+            else:
+                import difflib
+                ops = [o for o in difflib.SequenceMatcher(None, text, P.decode_text(ids, charset)).get_opcodes() if o[0] != "equal"]
+                assert len(ops) <= shaky
+            assert abs(score - conf) < 2e-2
+    assert exact >= 1
+    assert tr([]) [0] == []

@@ -142,3 +142,29 @@ def test_ctc_collapse_matches_oracle(ctx):
         assert oi[r, :ol[r]].tolist() == ids
         assert abs(oc[r] - conf) < 1e-5
     assert ol[0] == 0 and oc[0] == 0.0 and ol[1] == 1
+
+
+def test_db_postprocess_noise_frame_degrades_alone(ctx):
+    """A frame whose probability map is noise-like (more run end-points than the device record buffer holds: TV static, a
+    detector gone wild) must not abort the batch: it alone takes the host pass, gives the oracle's boxes (up to
+    max_candidates, like the reference), and the other frames are untouched."""
+    import torch
+    from oracle import pipeline_ref as P
+    rng = np.random.default_rng(3)
+    h, w = 544, 960
+    clean = np.zeros((h, w), np.float32)
+    clean[400:440, 200:700] = 0.9
+    # ~4000 isolated 6x6 blobs = ~49k run end-points (> 32768 device records) and more components than max_candidates
+    cells = rng.random((h // 8, w // 8)) < 0.5
+    noise = np.zeros((h, w), np.float32)
+    for cy, cx in zip(*np.nonzero(cells)):
+        noise[cy * 8 + 1:cy * 8 + 7, cx * 8 + 1:cx * 8 + 7] = 0.9
+    prob = np.stack([clean, noise, clean])
+    res = ctx.db_postprocess(torch.from_numpy(prob).cuda(), 1080, 1920, max_boxes=8192)
+    for f in (0, 2):
+        rb, _ = P.db_postprocess(prob[f], 1080, 1920)
+        assert len(res[f][0]) == len(rb) == 1 and np.array_equal(res[f][0], np.asarray(rb, np.float32))
+    rb, rs = P.db_postprocess(prob[1], 1080, 1920)
+    assert len(res[1][0]) == len(rb) == 1000          # max_candidates, like the reference
+    key = lambda b: tuple(np.asarray(b).reshape(-1).tolist())
+    assert sorted(map(key, res[1][0])) == sorted(map(key, rb))

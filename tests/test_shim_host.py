@@ -1,0 +1,67 @@
+"""Host-side behaviour of the drop-in shim that needs no GPU: dictionaries, kwargs, error behaviour."""
+import os
+
+import pytest
+
+from vse_amd import shim
+
+
+@pytest.fixture(autouse=True)
+def _restore_config():
+    keep = dict(vars(shim.config))
+    yield
+    for k, v in keep.items():
+        setattr(shim.config, k, v)
+
+
+def test_en_charset_is_builtin():
+    cs = shim.charset_for("en", 97)
+    assert len(cs) == 97 and cs[0] == "blank" and cs[1] == "0" and cs[-1] == " " and cs[-2] == " "
+    assert "".join(cs[1:11]) == "0123456789" and cs[cs.index("~") + 1] == "!"
+
+
+def test_no_dictionary_is_an_error_not_invented_text():
+    """Real converted weights + no dictionary must not return plausible-looking wrong text."""
+    shim.config.allow_standin_weights = False
+    shim.config.dict_dir = None
+    with pytest.raises(FileNotFoundError, match="ppocr_keys_v1.txt"):
+        shim.charset_for("ch", 6625)
+    with pytest.raises(FileNotFoundError, match="korean_dict.txt"):
+        shim.charset_for("korean", 3690)
+    with pytest.raises(FileNotFoundError, match="latin_dict.txt"):
+        shim.charset_for("fr", 187)
+    shim.config.allow_standin_weights = True
+    assert len(shim.charset_for("ch", 6625)) == 6625          # placeholder table only on explicit request
+
+
+def test_dictionary_from_path_and_dict_dir(tmp_path):
+    chars = ["的", "一", "是", "A", "#"]
+    p = tmp_path / "ppocr_keys_v1.txt"
+    p.write_bytes("\n".join(chars).encode("utf-8") + b"\n")
+    want = ["blank"] + chars + [" "]
+    assert shim.charset_for("ch", 7, rec_char_dict_path=str(p)) == want
+    assert shim.charset_for("ch", 6, rec_char_dict_path=str(p), use_space_char=False) == want[:-1]
+    shim.config.dict_dir = str(tmp_path)
+    assert shim.charset_for("ch", 7) == want
+    with pytest.raises(ValueError, match="7 classes but the recogniser has 6625"):
+        shim.charset_for("ch", 6625)
+    # CRLF files and the dict/ sub-directory of paddleocr's layout
+    os.makedirs(tmp_path / "dict")
+    (tmp_path / "dict" / "korean_dict.txt").write_bytes("가\r\n나\r\n".encode("utf-8"))
+    assert shim.charset_for("korean", 4) == ["blank", "가", "나", " "]
+
+
+def test_paddleocr_kwargs_are_checked_before_any_model_is_loaded():
+    with pytest.raises(NotImplementedError):
+        shim.PaddleOCR(det_model_dir="V4_ch_det", rec_model_dir="V4_ch_rec", use_angle_cls=True)
+    with pytest.raises(NotImplementedError):
+        shim.PaddleOCR(det_model_dir="V4_ch_det", rec_model_dir="V4_ch_rec", det_algorithm="EAST")
+    with pytest.raises(TypeError, match="rec_char_dict"):
+        shim.PaddleOCR(det_model_dir="V4_ch_det", rec_model_dir="V4_ch_rec", rec_char_dict="typo.txt")
+    # the reference's own kwargs (backend/tools/ocr.py:91-113) pass the check and reach model loading
+    shim.config.allow_standin_weights = False
+    with pytest.raises(FileNotFoundError, match="weights for V4_ch_det"):
+        shim.PaddleOCR(use_gpu=True, gpu_mem=500, det_algorithm="DB", det_model_dir="V4_ch_det", rec_algorithm="CRNN",
+                       rec_batch_num=6, rec_model_dir="V4_ch_rec", max_batch_size=10, det=True, use_angle_cls=False,
+                       drop_score=0, lang="ch", ocr_version="PP-OCRv4", rec_image_shape="3,48,320", use_onnx=False,
+                       onnx_providers=[])

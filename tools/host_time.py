@@ -8,7 +8,7 @@ from vse_amd import engine, modelzoo, pipeline, shim, synth
 ctx = engine.Context(0)
 det = modelzoo.get_model("V4_ch_det", seed=0); rec = modelzoo.get_model("V4_ch_rec", seed=1)
 det = (det[0], bench.empty_det_head(det[0], det[1]))
-charset = shim.charset_for("ch", shim._ncls(rec[0]))
+charset = shim.standin_charset("ch", shim._ncls(rec[0]))
 pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="bucketed", bucket=256, batch_round=4)
 pipe.rec_streams = 2
 frames_np, truth = synth.make_frames(64, 1080, 1920, seed=100, return_truth=True)

@@ -144,12 +144,50 @@ WK32 = os.environ.get("VSE_WK32", "1") != "0"      # 32-deep weight tiles for co
 HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
 
 
+class UnsupportedGraph(NotImplementedError):
+    """A descriptor uses an attribute value the kernels hard-code differently (would compile and compute wrong values)."""
+
+
+# Attribute values the lowering hard-codes (every graph under backend/models/ satisfies them, SURVEY App. E).  A descriptor
+# converted from another export (SAME padding, dilated convs, align_corners resize ...) must fail here, loudly, instead of
+# compiling into something that silently computes different values.  A missing attribute means the Paddle default.
+_REQUIRED_ATTRS = {
+    "conv2d": {"dilations": [1, 1], "padding_algorithm": "EXPLICIT", "data_format": ("NCHW", "AnyLayout")},
+    "depthwise_conv2d": {"dilations": [1, 1], "padding_algorithm": "EXPLICIT", "data_format": ("NCHW", "AnyLayout")},
+    "conv2d_transpose": {"dilations": [1, 1], "padding_algorithm": "EXPLICIT", "data_format": ("NCHW", "AnyLayout"),
+                         "output_padding": [], "output_size": []},
+    "hard_swish": {"offset": 3.0, "scale": 6.0, "threshold": 6.0},
+    "swish": {"beta": 1.0},
+    "nearest_interp_v2": {"align_corners": False, "interp_method": "nearest", "data_layout": ("NCHW", "AnyLayout")},
+    "pool2d": {"padding_algorithm": "EXPLICIT", "global_pooling": False, "data_format": ("NCHW", "AnyLayout")},
+    "batch_norm": {"data_layout": ("NCHW", "AnyLayout")},
+    "matmul_v2": {"trans_x": False, "trans_y": False},
+}
+
+
+def check_attrs(ops):
+    for i, op in enumerate(ops):
+        want = _REQUIRED_ATTRS.get(op["type"])
+        if not want:
+            continue
+        a = op.get("attrs", {})
+        for k, v in want.items():
+            if k not in a:
+                continue
+            got = a[k]
+            ok = got in v if isinstance(v, tuple) else (abs(got - v) < 1e-6 if isinstance(v, float) else got == v)
+            if not ok:
+                raise UnsupportedGraph(f"op {i} ({op['type']}): attribute {k}={got!r} is not supported (the kernels "
+                                       f"implement {k}={v!r} only)")
+
+
 class Compiler:
     def __init__(self, desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True,
                  store=None, reuse=True):
         self.desc = desc
         self.W = dict(weights)
         self.ops = list(desc["ops"])
+        check_attrs(self.ops)
         self.merged_gmac_credit = {}          # merged conv weight name -> algorithmic MAC factor of the original branches
         self.hilo = False                     # fp16 hi + lo weight pairs (compile_model(hilo=True))
         self.pending_gate = {}                # SE output name -> gate view its depthwise consumer applies on load (F_GATE)

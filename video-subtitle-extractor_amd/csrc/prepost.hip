@@ -186,7 +186,23 @@ __global__ __launch_bounds__(256) void db_score_kernel(const float* __restrict__
     if (threadIdx.x == 0) out[blockIdx.x] = scnt[0] ? (float)(ssum[0] / scnt[0]) : 0.f;
 }
 
-#define DB_RUN_CAP 32768   // run end-point records per frame
+#define DB_RUN_CAP 32768   // run end-point records per frame kept on the device (more -> host pass for that frame)
+
+// Host twin of db_runs_kernel over one frame's label image (parent pointers, -1 = background).
+static void db_runs_host(const int* L, int h, int w, std::vector<int2>& out) {
+    out.clear();
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int p = y * w + x;
+            if (L[p] < 0) continue;
+            const bool left = (x == 0) || (L[p - 1] < 0);
+            const bool right = (x == w - 1) || (L[p + 1] < 0);
+            if (!(left || right)) continue;
+            int r = p;
+            while (L[r] != r) r = L[r];
+            out.push_back(make_int2(r, x | (y << 16)));
+        }
+}
 
 extern "C" size_t vse_db_workspace_bytes(int n, int h, int w) {
     size_t b = (size_t)n * h * w * sizeof(int);          // labels
@@ -225,11 +241,9 @@ extern "C" int vse_db_postprocess(vse_ctx*, const float* d_prob, int n, int h, i
     if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
     std::vector<std::vector<int2>> hrecs(n);
     int maxc = 0;
+    std::vector<int> over;                                // frames whose records did not fit (noise-like maps)
     for (int f = 0; f < n; ++f) {
-        if (hcnt[f] > DB_RUN_CAP) {
-            vse_set_error("vse_db_postprocess: run-record capacity exceeded (noise-like probability map)");
-            return VSE_E_NOMEM;
-        }
+        if (hcnt[f] > DB_RUN_CAP) { over.push_back(f); hcnt[f] = 0; }
         maxc = std::max(maxc, hcnt[f]);
     }
     if (maxc) {
@@ -240,6 +254,16 @@ extern "C" int vse_db_postprocess(vse_ctx*, const float* d_prob, int n, int h, i
             return VSE_E_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
         for (int f = 0; f < n; ++f) hrecs[f].assign(flat.begin() + (size_t)f * maxc, flat.begin() + (size_t)f * maxc + hcnt[f]);
+    }
+    // A frame with more run end-points than the device buffer holds (TV static, a detector gone wild) degrades alone:
+    // its label image is copied back and the same records are extracted on the host, so the other frames of the batch are
+    // unaffected and the frame itself still yields what the reference would (up to max_candidates boxes).
+    for (int f : over) {
+        std::vector<int> hl((size_t)h * w);
+        if (hipMemcpyAsync(hl.data(), L + (size_t)f * h * w, hl.size() * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess)
+            return VSE_E_HIP;
+        if (hipStreamSynchronize(st) != hipSuccess) return VSE_E_HIP;
+        db_runs_host(hl.data(), h, w, hrecs[f]);
     }
 
     // ---- host geometry, pass 1: components -> candidate quads ----------------------------------------

@@ -67,8 +67,12 @@ int vse_init(int device_id, vse_ctx** out) {
     vse_ctx* c = new vse_ctx();
     c->device = device_id;
     c->zero_page = nullptr;
-    HIP_TRY(hipMalloc(&c->zero_page, 4096));
-    HIP_TRY(hipMemset(c->zero_page, 0, 4096));
+    if (hipMalloc(&c->zero_page, 4096) != hipSuccess || hipMemset(c->zero_page, 0, 4096) != hipSuccess) {
+        set_err("vse_init: cannot allocate the zero page on device %d: %s", device_id, hipGetErrorString(hipGetLastError()));
+        if (c->zero_page) (void)hipFree(c->zero_page);
+        delete c;
+        return VSE_E_HIP;
+    }
     *out = c;
     return VSE_OK;
 }

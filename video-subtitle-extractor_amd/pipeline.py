@@ -140,7 +140,7 @@ class OcrPipeline:
         if self.rec_mode == "reference":
             by_frame = {}
             for i, s in enumerate(specs):
-                by_frame.setdefault(s["frame"], []).append(i)
+                by_frame.setdefault(s.get("gframe", s["frame"]), []).append(i)
             for f in sorted(by_frame):
                 idx = by_frame[f]
                 order = [idx[j] for j in np.argsort(np.array([specs[i]["ratio"] for i in idx]), kind="stable")]
@@ -164,14 +164,47 @@ class OcrPipeline:
     def recognize(self, frames, boxes_per_frame):
         """boxes_per_frame: list (len N) of sequences of 4x2 quads (already in the order results are wanted).
         -> list per frame of [(text, score)]."""
-        t = self.ctx.torch
         specs = self._crop_specs(boxes_per_frame)
         results = [[("", 0.0)] * len(b) for b in boxes_per_frame]
+        for s, r in zip(specs, self._recognize_specs(frames, specs)):
+            results[s["frame"]][s["slot"]] = r
+        return results
+
+    def recognize_crops(self, crops):
+        """paddleocr TextRecognizer.__call__(img_list): crops = list of uint8 BGR [h,w,3] arrays of any sizes ->
+        [(text, score)] in input order.  The whole list is ONE grouping unit (sorted by w/h, chunks of rec_batch_num, each
+        chunk padded to its own widest member), as the reference's recogniser treats the crops of one frame.  The crops ride
+        through the same device path as boxes cut from frames: they are placed on a common canvas and "cropped" with the
+        identity quad (bicubic weights at integer coordinates are exactly (0,1,0,0): a pixel copy)."""
+        t = self.ctx.torch
+        if not crops:
+            return []
+        mh = max(int(c.shape[0]) for c in crops)
+        mw = max(int(c.shape[1]) for c in crops)
+        canvas = np.zeros((len(crops), mh, mw, 3), np.uint8)
+        specs = []
+        for i, c in enumerate(crops):
+            c = np.asarray(c)
+            if c.dtype != np.uint8 or c.ndim != 3 or c.shape[2] != 3 or c.shape[0] < 1 or c.shape[1] < 1:
+                raise ValueError("expected uint8 BGR HxWx3 crops")
+            h, w = int(c.shape[0]), int(c.shape[1])
+            canvas[i, :h, :w] = c
+            quad = np.array([[0, 0], [w, 0], [w, h], [0, h]], np.float32)
+            specs.append(dict(frame=i, gframe=0, slot=0, quad=quad, crop_w=w, crop_h=h, rotate=0, ratio=w / float(h),
+                              iw=w, ih=h))
+        return self._recognize_specs(t.from_numpy(canvas).to(self.ctx.tdev), specs)
+
+    def _recognize_specs(self, frames, specs):
+        """-> [(text, score)] per spec."""
+        t = self.ctx.torch
+        out = [("", 0.0)] * len(specs)
         if not specs:
-            return results
+            return out
         pending = []
         groups = self._groups(specs)
-        # width groups are independent: run them on side streams so the latency-bound launches of small groups overlap
+        # width groups are independent: run them on side streams so the latency-bound launches of small groups overlap.
+        # Every stream owns a workspace slot of the recogniser: two groups with the same (n, h, w) plan key may be in flight
+        # at once (a bucket split into max_rec_batch chunks, reference-mode chunks of equal shape) and must not share one.
         nstreams = min(len(groups), getattr(self, "rec_streams", 1))
         main = t.cuda.current_stream(self.ctx.tdev)
         if nstreams > 1:
@@ -180,35 +213,34 @@ class OcrPipeline:
                                  for _ in range(nstreams)]
             for st in self._streams[:nstreams]:
                 st.wait_stream(main)
-        for gi, (idx, img_w) in enumerate(groups):
-            side = self._streams[gi % nstreams] if nstreams > 1 else None
-            if side is not None:
-                t.cuda.set_stream(side)
-            crops = []
-            for i in idx:
-                s = specs[i]
-                rw = min(img_w, int(math.ceil(self.rec_h * s["ratio"])))
-                crops.append(dict(quad=s["quad"], frame=s["frame"], crop_w=s["crop_w"], crop_h=s["crop_h"],
-                                  resized_w=max(rw, 1), rotate=s["rotate"]))
-            if self.rec_mode != "reference" and self.batch_round > 1:
-                while len(crops) % self.batch_round:
-                    crops.append(crops[-1])           # dummy rows; their results are never read
-            x = self.ctx.rec_preprocess(frames, crops, self.rec_h, img_w)
-            idx_maxp = self._run(self.rec, x)[-1]          # [B,1,T,2]
-            oi, ol, oc = self.ctx.ctc_collapse(idx_maxp)
-            pending.append((idx, oi, ol, oc))
-        if nstreams > 1:
-            t.cuda.set_stream(main)
-            for st in self._streams[:nstreams]:
-                main.wait_stream(st)
+        try:
+            for gi, (idx, img_w) in enumerate(groups):
+                if nstreams > 1:
+                    t.cuda.set_stream(self._streams[gi % nstreams])
+                crops = []
+                for i in idx:
+                    s = specs[i]
+                    rw = min(img_w, int(math.ceil(self.rec_h * s["ratio"])))
+                    crops.append(dict(quad=s["quad"], frame=s["frame"], crop_w=s["crop_w"], crop_h=s["crop_h"],
+                                      resized_w=max(rw, 1), rotate=s["rotate"]))
+                if self.rec_mode != "reference" and self.batch_round > 1:
+                    while len(crops) % self.batch_round:
+                        crops.append(crops[-1])           # dummy rows; their results are never read
+                x = self.ctx.rec_preprocess(frames, crops, self.rec_h, img_w)
+                idx_maxp = self._run(self.rec, x, slot=gi % nstreams if nstreams > 1 else 0)[-1]          # [B,1,T,2]
+                oi, ol, oc = self.ctx.ctc_collapse(idx_maxp)
+                pending.append((idx, oi, ol, oc))
+        finally:
+            if nstreams > 1:
+                t.cuda.set_stream(main)
+                for st in self._streams[:nstreams]:
+                    main.wait_stream(st)
         for idx, oi, ol, oc in pending:                      # one sync per group at the end
             oi, ol, oc = oi.cpu().numpy(), ol.cpu().numpy(), oc.cpu().numpy()
             for k, i in enumerate(idx):
-                s = specs[i]
                 ids = oi[k, :ol[k]]
-                text = "".join(self.charset[j] for j in ids)
-                results[s["frame"]][s["slot"]] = (text, float(oc[k]))
-        return results
+                out[i] = ("".join(self.charset[j] for j in ids), float(oc[k]))
+        return out
 
     # ---- TextSystem.__call__(img, cls=False) for a batch ------------------------------------------------
     def ocr(self, frames):
@@ -224,9 +256,12 @@ class OcrPipeline:
         if getattr(self, "_det_stream", None) is None:
             self._det_stream = t.cuda.Stream(device=self.ctx.tdev)
         main = t.cuda.current_stream(self.ctx.tdev)
-        self._det_stream.wait_stream(main)
         prev = None
         for k, frames in enumerate(batches):
+            # the iterator may have produced this batch asynchronously on the main stream (GPU decode, crop, non-blocking
+            # upload): order the detector stream after it for EVERY batch.  Nothing is lost: the previous _finish_maps has
+            # already drained the main stream when the next batch is requested.
+            self._det_stream.wait_stream(main)
             with t.cuda.stream(self._det_stream):
                 maps = self.det_maps(frames, slot=k & 1)
                 ev = t.cuda.Event()

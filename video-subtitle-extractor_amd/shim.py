@@ -21,7 +21,7 @@ from . import engine, modelzoo, pipeline
 
 config = SimpleNamespace(language="ch", mode="fast", recBatchNumber=6, maxBatchSize=10, dropScore=75,
                          subtitleAreaDeviationRate=0, hardwareAcceleration=True, device=0,
-                         allow_standin_weights=False, weights_dir=None)
+                         allow_standin_weights=False, weights_dir=None, dict_dir=None)
 
 LATIN_LANG = ['af', 'az', 'bs', 'cs', 'cy', 'da', 'de', 'es', 'et', 'fr', 'ga', 'hr', 'hu', 'id', 'is', 'it', 'ku',
               'la', 'lt', 'lv', 'mi', 'ms', 'mt', 'nl', 'no', 'oc', 'pi', 'pl', 'pt', 'ro', 'rs_latin', 'sk', 'sl',
@@ -127,13 +127,61 @@ class PaddleModelConfig:
         return model_dir
 
 
-def charset_for(lang, ncls):
-    """['blank'] + dictionary + [' '] (SURVEY App. C.6).  Only the 95-entry `en` dictionary order is known here;
-    other languages get a stand-in table (the dictionary files live inside the paddleocr wheel)."""
+# dictionary file of each recogniser language inside paddleocr 2.10 (ppocr/utils/...), relative to config.dict_dir
+_DICT_FILES = {"ch": "ppocr_keys_v1.txt", "en": "en_dict.txt"}
+
+
+def _dict_candidates(lang):
+    group = ("latin" if lang in LATIN_LANG else "arabic" if lang in ARABIC_LANG else "cyrillic" if lang in CYRILLIC_LANG
+             else "devanagari" if lang in DEVANAGARI_LANG else lang)
+    name = _DICT_FILES.get(group, f"{group}_dict.txt")
+    return [name, os.path.join("dict", name)]
+
+
+def read_dict_file(path):
+    """paddleocr BaseRecLabelDecode: one character per line (trailing newline / CR stripped, nothing else)."""
+    with open(path, "rb") as f:
+        return [ln.decode("utf-8").strip("\n").strip("\r\n") for ln in f.readlines()]
+
+
+def standin_charset(lang, ncls):
+    """Index-faithful placeholder table: ONLY for stand-in weights / index-level parity runs, never for real text."""
     if lang == "en" and ncls == 97:
-        chars = [chr(c) for c in range(0x30, 0x7F)] + [chr(c) for c in range(0x21, 0x30)] + [" "]
-        return ["blank"] + chars + [" "]
+        return en_charset()
     return ["blank"] + [chr(0x4E00 + i) for i in range(ncls - 2)] + [" "]
+
+
+def en_charset():
+    """paddleocr's 95-entry en_dict.txt order: digits .. '~', then '!' .. '/', then ' ' — plus CTC
+    blank in front and the use_space_char blank behind = the 97 classes of V4/en_rec_fast."""
+    chars = [chr(c) for c in range(0x30, 0x7F)] + [chr(c) for c in range(0x21, 0x30)] + [" "]
+    return ["blank"] + chars + [" "]
+
+
+def charset_for(lang, ncls, rec_char_dict_path=None, use_space_char=True):
+    """CTC label table ['blank'] + dictionary (+ [' '] when use_space_char) for a recogniser with `ncls` classes
+    (paddleocr CTCLabelDecode).  Resolution order: an explicit rec_char_dict_path (the PaddleOCR kwarg),
+    the language's file under config.dict_dir, the built-in `en` table.  The dictionaries live inside the paddleocr wheel,
+    not in the reference checkout: without one there is NO way to turn class indices into the right characters, so this
+    raises instead of inventing text — unless config.allow_standin_weights asks for the placeholder table (index-level
+    parity runs with stand-in weights)."""
+    path = rec_char_dict_path
+    if path is None and getattr(config, "dict_dir", None):
+        for cand in _dict_candidates(lang):
+            if os.path.exists(os.path.join(config.dict_dir, cand)):
+                path = os.path.join(config.dict_dir, cand)
+                break
+    if path is not None:
+        chars = ["blank"] + read_dict_file(path) + ([" "] if use_space_char else [])
+        if len(chars) != ncls:
+            raise ValueError(f"dictionary {path} gives {len(chars)} classes but the recogniser has {ncls}")
+        return chars
+    if lang == "en" and ncls == 97 and use_space_char:
+        return en_charset()
+    if config.allow_standin_weights:
+        return standin_charset(lang, ncls)
+    raise FileNotFoundError(f"no character dictionary for language {lang!r}: pass rec_char_dict_path=... or set "
+                            f"config.dict_dir to a directory holding {_dict_candidates(lang)[0]} (paddleocr ppocr/utils)")
 
 
 def _load_model(model_id):
@@ -211,19 +259,63 @@ class TextDetector:
         return self.pipe.detect(frames)
 
 
+class TextRecognizer:
+    """paddleocr TextRecognizer(args)(img_list) -> (list[(text, score)], elapse): CTC recognition of ready-made crops
+    (uint8 BGR arrays of any sizes), grouped like the reference (sorted by w/h, chunks of rec_batch_num)."""
+
+    def __init__(self, args):
+        model = _load_model(args.rec_model_dir)
+        shp = [int(v) for v in getattr(args, "rec_image_shape", "3,48,320").split(",")]
+        charset = charset_for(getattr(args, "lang", config.language), _ncls(model[0]),
+                              getattr(args, "rec_char_dict_path", None), getattr(args, "use_space_char", True))
+        ctx = _context()
+        self.pipe = pipeline.OcrPipeline.__new__(pipeline.OcrPipeline)
+        self.pipe.ctx = ctx
+        self.pipe.rec = engine.Net(ctx, model[0], model[1], want_probs=False)
+        self.pipe.charset = charset
+        self.pipe.rec_batch_num = getattr(args, "rec_batch_num", 6)
+        self.pipe.rec_h, self.pipe.rec_base_w = shp[1], shp[2]
+        self.pipe.rec_mode = "reference"
+        self.pipe.bucket, self.pipe.batch_round, self.pipe.max_rec_batch = 64, 1, 64
+        self.pipe.profile_sink = None
+        self.pipe.rec_streams = 1
+
+    def __call__(self, img_list):
+        t0 = time.time()
+        return self.pipe.recognize_crops(list(img_list)), time.time() - t0
+
+
 class PaddleOCR:
     """PaddleOCR(**kwargs)(img, cls=False) -> (boxes, rec_res, time_dict) as used at backend/tools/ocr.py:27,91-113."""
 
+    # kwargs of the reference's call (ocr.py:91-113) that select a backend / memory pool / algorithm label and have no
+    # meaning here; anything else unknown is an error, not silently dropped
+    _BACKEND_KWARGS = {"use_gpu", "gpu_mem", "gpu_id", "use_onnx", "onnx_providers", "max_batch_size", "det", "rec", "cls",
+                       "ocr_version", "show_log", "use_mp", "total_process_num", "enable_mkldnn", "cpu_threads",
+                       "use_tensorrt", "precision", "ir_optim", "cls_model_dir", "use_xpu", "use_npu", "use_mlu",
+                       "det_limit_type", "benchmark", "warmup"}
+
     def __init__(self, det_model_dir=None, rec_model_dir=None, rec_batch_num=6, drop_score=0.5, lang="ch",
-                 use_angle_cls=False, rec_image_shape="3,48,320", rec_mode="reference", **_ignored):
+                 use_angle_cls=False, rec_image_shape="3,48,320", rec_mode="reference", rec_char_dict_path=None,
+                 use_space_char=True, det_algorithm="DB", rec_algorithm="CRNN", det_limit_side_len=960,
+                 det_db_thresh=0.3, det_db_box_thresh=0.6, det_db_unclip_ratio=1.5, **backend):
         if use_angle_cls:
             raise NotImplementedError("angle classifier is never enabled by the reference (ocr.py:104)")
+        if det_algorithm != "DB":
+            raise NotImplementedError("only DB detection exists in the reference (SURVEY F9)")
+        if rec_algorithm not in ("CRNN", "SVTR_LCNet", "SVTR_HGNet"):
+            raise NotImplementedError(f"rec_algorithm={rec_algorithm!r}: only the CTC recognisers of the reference exist")
+        unknown = set(backend) - self._BACKEND_KWARGS
+        if unknown:
+            raise TypeError(f"PaddleOCR(): unsupported arguments {sorted(unknown)}")
         det = _load_model(det_model_dir)
         rec = _load_model(rec_model_dir)
         shp = [int(v) for v in rec_image_shape.split(",")]
-        self.pipe = pipeline.OcrPipeline(_context(), det, rec, charset_for(lang, _ncls(rec[0])),
-                                         rec_batch_num=rec_batch_num, rec_h=shp[1], rec_base_w=shp[2],
-                                         drop_score=drop_score, rec_mode=rec_mode)
+        charset = charset_for(lang, _ncls(rec[0]), rec_char_dict_path, use_space_char)
+        self.pipe = pipeline.OcrPipeline(_context(), det, rec, charset, rec_batch_num=rec_batch_num, rec_h=shp[1],
+                                         rec_base_w=shp[2], drop_score=drop_score, rec_mode=rec_mode,
+                                         limit_side_len=det_limit_side_len, db_thresh=det_db_thresh,
+                                         db_box_thresh=det_db_box_thresh, db_unclip_ratio=det_db_unclip_ratio)
 
     def __call__(self, img, cls=False):
         t0 = time.time()
@@ -249,9 +341,12 @@ class OcrRecogniser:
 
     def init_model(self):
         mc = PaddleModelConfig(self.hardware_accelerator)
-        return PaddleOCR(det_model_dir=mc.DET_MODEL_PATH, rec_model_dir=mc.REC_MODEL_PATH,
-                         rec_batch_num=config.recBatchNumber, drop_score=0, lang=mc.REC_CHAR_TYPE,
-                         use_angle_cls=False, rec_image_shape=mc.REC_IMAGE_SHAPE)
+        hw = self.hardware_accelerator
+        return PaddleOCR(use_gpu=hw.has_cuda(), gpu_mem=500, det_algorithm='DB', det_model_dir=mc.DET_MODEL_PATH,
+                         rec_algorithm='CRNN', rec_batch_num=config.recBatchNumber, rec_model_dir=mc.REC_MODEL_PATH,
+                         max_batch_size=config.maxBatchSize, det=True, use_angle_cls=False, drop_score=0,
+                         lang=mc.REC_CHAR_TYPE, ocr_version=f'PP-OCR{mc.MODEL_VERSION.lower()}',
+                         rec_image_shape=mc.REC_IMAGE_SHAPE, use_onnx=False, onnx_providers=hw.onnx_providers)
 
     def predict(self, image):
         if not self.recogniser:
