@@ -151,7 +151,12 @@ class Emulator:
             oc2 = int(r["out2"]["c"])
             self.write(r["out2"], z if oc2 == 1 else F.pad(z, (0, oc2 - 1)))
             return
-        if int(r["flags"]) & ir.F_PATCH:
+        if int(r["flags"]) & ir.F_COL:
+            assert cinp % 16 == 0 and Kp == kh * kw * cinp
+            wt = self.wread(int(r["w_off"]), Kp * Np + 3 * kh * Np * 16, np.float16).astype(np.float32)
+            assert not wt[Kp * Np:].any()                   # the three zero stages of the DMA look-ahead
+            wmat = np.ascontiguousarray(wt[:Kp * Np].reshape(cinp // 16, kw, kh, Np, 16).transpose(3, 2, 1, 0, 4)).reshape(Np, Kp)
+        elif int(r["flags"]) & ir.F_PATCH:
             taps = kh * kw
             c32 = (cinp + 31) // 32 * 32
             tp = Kp // c32                                  # taps padded to whole kernel steps by the compiler

@@ -162,17 +162,21 @@ def test_head_up2_folding_is_exact():
 
 def test_light_patch_variant_selection():
     """3x3 stride-1 convs with up to 128 couts on well-tiling maps take the LIGHT patch variant: taps are padded to 2
-    (two taps per step); 9x9 keeps two taps per step on 16-row tiles, and the same weights compile for both shapes."""
+    (two taps per step).  The tall filters of the large-kernel neck (9x9, and the 7x7 / 5x5 IntraCL merges) go to the
+    column-per-step kernel (F_COL): no tap padding, K = taps x channels exactly."""
     desc, w = net_ref.get_weights("V4_ch_det")
     prog = compiler.compile_model(desc, w, 1, 544, 960)
-    seen = set()
+    seen, col = set(), set()
     for o in prog.ops:
+        p = o["p"]
+        taps = int(p[ir.P_KH]) * int(p[ir.P_KW])
         if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_PATCH and not int(o["flags"]) & ir.F_UP2HEAD:
-            p = o["p"]
-            taps = int(p[ir.P_KH]) * int(p[ir.P_KW])
             ptaps = int(p[ir.P_KTOT]) // ((int(p[ir.P_CINP]) + 31) // 32 * 32)
             seen.add((taps, ptaps))
-    assert (9, 10) in seen and (81, 84) in seen and (49, 52) in seen and (25, 28) in seen
+        if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_COL:
+            assert not int(o["flags"]) & ir.F_PATCH and int(p[ir.P_KTOT]) == taps * int(p[ir.P_CINP])
+            col.add(taps)
+    assert seen == {(9, 10)} and col == {81, 49, 25}
 
 
 @pytest.mark.parametrize("optype,attr,value", [("conv2d", "dilations", [2, 2]), ("conv2d", "padding_algorithm", "SAME"),

@@ -89,6 +89,13 @@ CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (32, 32, (7, 7), (1, 1), (3, 3), 16, 96, 2),       # 49 taps (odd): last step has a single tap; <16,32,1>
     (64, 24, (5, 5), (1, 1), (2, 2), 32, 64, 1),       # <16,32,1> with a cout tail (24 of 32), two channel chunks
     (96, 40, (7, 1), (1, 1), (3, 0), 16, 64, 1), (96, 40, (1, 7), (1, 1), (0, 3), 16, 64, 1),
+    # conv_col_kernel (one filter column per step, 16-channel chunks; cin % 16 == 0, kh in 5/7/9, <= 64 couts) — the 9x9 / 7x7 /
+    # 5x5 cases above run on it as well
+    (256, 64, (9, 9), (1, 1), (4, 4), 24, 40, 1),      # 16 chunks: patch double buffer + 4-stage ring wrap many times
+    (48, 64, (9, 9), (1, 1), (4, 4), 19, 33, 2),       # odd chunk count; second tile row has 3 rows (idle waves), second column 1 px
+    (64, 40, (9, 5), (1, 1), (4, 2), 16, 40, 1),       # tall filter, 5 columns; cout tail (40 of 64)
+    (32, 64, (5, 9), (1, 1), (2, 4), 21, 64, 1),       # wide filter: 9 steps of 5 taps
+    (16, 16, (7, 7), (1, 1), (3, 3), 33, 31, 3),       # a single chunk; 16 couts of a 32-cout tile
     # scalar-addressed implicit GEMM (conv_gemm_kernel: cin % 32 == 0, <= 31 taps); VSE_CONV_GEMM=0 sends the same
     # cases through conv_mfma_kernel
     (64, 128, (3, 3), (1, 1), (1, 1), 20, 36, 2),      # masked, BN=128, image seam inside a tile

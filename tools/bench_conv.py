@@ -33,6 +33,11 @@ LAYERS = {  # name: cin, cout, k, stride, pad, h, w, n
     "det_3x3_768_192": (768, 192, (3, 3), (1, 1), (1, 1), 34, 60, 64),
     "det_9x9_256_64": (256, 64, (9, 9), (1, 1), (4, 4), 136, 240, 64),
     "det_9x9_64_64": (64, 64, (9, 9), (1, 1), (4, 4), 136, 240, 64),
+    "det_9x9_256_64_h68": (256, 64, (9, 9), (1, 1), (4, 4), 68, 120, 64),
+    "det_9x9_256_64_h34": (256, 64, (9, 9), (1, 1), (4, 4), 34, 60, 64),
+    "det_9x9_256_64_h17": (256, 64, (9, 9), (1, 1), (4, 4), 17, 30, 64),
+    "det_9x9_64_64_h68": (64, 64, (9, 9), (1, 1), (4, 4), 68, 120, 64),
+    "det_3x3_256_64_h68": (256, 64, (3, 3), (1, 1), (1, 1), 68, 120, 64),
     "det_7x7_32_32": (32, 32, (7, 7), (1, 1), (3, 3), 136, 240, 64),
     "det_5x5_32_32": (32, 32, (5, 5), (1, 1), (2, 2), 136, 240, 64),
     "rec_3x3_128_128": (128, 128, (3, 3), (1, 1), (1, 1), 12, 512, 32),

@@ -142,6 +142,9 @@ STEM = os.environ.get("VSE_STEM", "1") != "0"         # conv_stem_kernel for 3x3
 GATE_DW = os.environ.get("VSE_GATE_DW", "1") != "0"   # SE gate folded into a depthwise consumer
 WK32 = os.environ.get("VSE_WK32", "1") != "0"      # 32-deep weight tiles for conv_gemm_kernel (contiguous wave DMAs)
 HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
+COL = os.environ.get("VSE_COL", "1") != "0"           # conv_col_kernel (one filter column per step) for 9x9 / 7x7 / 5x5 layers
+# below this tile efficiency the 8-row tiles of conv_patch_kernel win (measured: 17x30 map 0.163 vs 0.203 ms, 34x60 0.50 vs 0.43)
+COL_MIN_TILE_EFF = float(os.environ.get("VSE_COL_MINEFF", "0.75"))
 
 
 class UnsupportedGraph(NotImplementedError):
@@ -728,6 +731,17 @@ class Compiler:
         return np.concatenate([m.reshape(-1), np.zeros(16 * npad * 32, np.float16)])
 
     @staticmethod
+    def col_weights(mat, kh, kw, cinp):
+        """[Np][Kp] (K order tap-major (dy, dx), channel-minor) -> [cinp/16][kw][kh][Np][16] fp16 for conv_col_kernel: one
+        ring stage = one filter column of one 16-channel chunk, contiguous; three zero stages follow the stream (the DMA
+        look-ahead of the last steps lands on readable zeros)."""
+        npad = mat.shape[0]
+        assert cinp % 16 == 0
+        full = mat[:, :kh * kw * cinp].reshape(npad, kh, kw, cinp // 16, 16)
+        m = np.ascontiguousarray(full.transpose(3, 2, 1, 0, 4)).astype(np.float16)
+        return np.concatenate([m.reshape(-1), np.zeros(3 * kh * npad * 16 + 512, np.float16)])
+
+    @staticmethod
     def head_up2_weights(mat, cinp):
         """3x3 conv over concat[u (8 physical channels, 1 real), up2(x) (64 channels)], matrix [Np][9*cinp] in
         (tap, channel) order -> the stream of conv_head_up2_kernel:
@@ -833,10 +847,22 @@ class Compiler:
         light_ok = ((sh, sw) == (1, 1) and kh * kw >= 5 and (8 + kh - 1) * (32 + kw - 1) <= 352 and tile_eff8 >= PATCH_MIN_TILE_EFF
                     and kh * kw * cin >= PATCH_MIN_K and self.use_patch and inv.parts is None
                     and (PATCH_LIGHT >= 2 if coutp <= 64 else (coutp <= 128 and PATCH_LIGHT >= 1)))
+        # column-per-step kernel (conv_col.hip, mirrors conv_col_ok): tall filters, <= 64 couts, 16-row tiles whose waves
+        # below the map idle (a partial tile row costs ~0.35 + 0.65 * live waves / 8 of a full one)
+        rem16 = oh % 16
+        rows16 = oh // 16 + ((0.35 + 0.65 * -(-rem16 // 2) / 8.0) if rem16 else 0.0)
+        tile_eff_col = (oh * ow) / float(rows16 * 16 * -(-ow // 32) * 32)
+        col = (COL and (sh, sw) == (1, 1) and kh in (5, 7, 9) and 3 <= kw <= 17 and inv.span % 16 == 0 and coutp <= 64
+               and inv.parts is None and self.use_patch and not self.hilo and kh * kw * cin >= PATCH_MIN_K
+               and tile_eff_col >= COL_MIN_TILE_EFF)
+        if col:
+            patch_std = light_ok = False
         patch = patch_std or light_ok
         self.env_dims_tmp = (inv.n, oh, ow)
         if patch:
             flags |= ir.F_PATCH
+        if col:
+            flags |= ir.F_COL
         in2shift = 0
         if inv.parts is not None:
             if patch:
@@ -861,7 +887,7 @@ class Compiler:
             while len(ins) < 2:
                 ins.append(None)
             ins.append(inv.parts[1])
-        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch_std and th == 16 and coutp <= 128) else None
+        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if ((patch_std and th == 16 and coutp <= 128) or col) else None
         if patch:
             # taps padded to whole kernel steps (2 taps in the LIGHT variant, else 4), channels to 32
             light = light_ok and dot is None
@@ -880,6 +906,10 @@ class Compiler:
             Kp = 2 * 4 * 4 * 32 + 32
             w_off = self.add_weights(("convh", wname, tuple(inv.segs), ep["out_name"]),
                                      lambda: self.head_up2_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], inv.span))
+        elif col:
+            Kp = kh * kw * inv.span
+            w_off = self.add_weights(("convc", wname, tuple(inv.segs), ep["out_name"]),
+                                     lambda: self.col_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh, kw, inv.span))
         elif patch:
             # (the tap padding depends on the kernel variant the map size selects: part of the cache key)
             w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"], ptaps),

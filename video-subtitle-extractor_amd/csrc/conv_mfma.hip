@@ -283,10 +283,11 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.dot_out = a.dot_out.ptr; p.dot_f32 = a.dot_out.esize == 4; p.dot_ld = a.dot_out.ld;
     p.in2 = reinterpret_cast<const half_t*>(a.in2.ptr); p.in2_ld = a.in2.ld; p.in2_shift = a.in2shift;
     p.in2_hs = a.in2.h; p.in2_ws = a.in2.w; p.nv0 = a.in.c >> 3;
-    if ((a.flags & (F_DOT1 | F_SRC2)) && !(a.flags & F_PATCH)) return VSE_E_UNSUPPORTED;
+    if ((a.flags & (F_DOT1 | F_SRC2)) && !(a.flags & (F_PATCH | F_COL))) return VSE_E_UNSUPPORTED;
     if (!a.zero) return VSE_E_INVAL;
     if (a.flags & F_UP2HEAD) return launch_conv_head_up2(p, a.in.n, st);
     if (a.flags & F_STEM) return launch_conv_stem(p, a.in.n, st);
+    if (a.flags & F_COL) return launch_conv_col(p, a.in.n, st);
     if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
     if (a.Kp % 64) return VSE_E_INVAL;
     static const bool use_gemm = [] { const char* e = getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();

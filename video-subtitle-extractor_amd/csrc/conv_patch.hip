@@ -40,11 +40,8 @@
 #ifndef VSE_PIPE128
 #define VSE_PIPE128 0     // ... also for the 128-cout LIGHT tile (spills: 68 bytes of scratch per lane)
 #endif
-#ifndef VSE_PIPE
-#define VSE_PIPE 1        // software-pipelined fast step (A/B on one box: tools/ab.sh conv_patch VSE_PIPE ...)
-#endif
-#ifndef VSE_PIPE128
-#define VSE_PIPE128 0     // ... also for the 128-cout LIGHT tile (spills: 68 bytes of scratch per lane)
+#ifndef VSE_EDGE_SKIP
+#define VSE_EDGE_SKIP 1   // waves whose output rows lie below the map skip their fragment reads and MFMAs (A/B: tools/ab.sh)
 #endif
 #define PTW 32
 #define PRING 4
@@ -182,6 +179,10 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
         woffb[j] = (unsigned)(r * 64 + ((fj ^ ((r >> 2) & 3)) << 4));
     }
     const int qb0 = (2 * wpx) * PW + fx, qb1 = qb0 + PW;
+    // ragged bottom edge: a wave whose two output rows both lie below the map only takes part in the DMA issue and the
+    // barriers; its partner on the SIMD gets the matrix pipe to itself, so a tile with half of its rows valid costs about
+    // half a tile (136 rows under 16-row tiles: 8.5 tiles' worth of time instead of 9)
+    const bool wave_live = VSE_EDGE_SKIP == 0 || (oy0 + 2 * wpx) < p.OH;
     const char* const ring_b = reinterpret_cast<const char*>(ring0);
 
     float16v acc[2][TN];
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
                     tapoff = wrap ? dx : tapoff + PW;
                     dy = wrap ? 0 : dy;
                 }
+                if (!wave_live) continue;
                 half8 x0s[2], wfb[2][TN], x1b[2];
                 {
                     const unsigned q0 = (unsigned)(qb0 + offstar);
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
                 const unsigned a0 = (q0 << 6) + ((fj ^ ((q0 >> 2) & 3)) << 4), a1 = (q1 << 6) + ((fj ^ ((q1 >> 2) & 3)) << 4);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
+                    if (!wave_live) break;
                     if (ks == 1 && klim1) break;           // channel tail <= 16: upper half of the chunk is all zeros
                     half8 wf[TN], xf[2];
 #if VSE_ABLATE == 2

@@ -206,6 +206,7 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if (o.kind != OP_CONV) return 0;
     if (o.flags & F_UP2HEAD) return 400000;   // conv_head_up2_kernel
     if (o.flags & F_STEM) return 500000;      // conv_stem_kernel
+    if (o.flags & F_COL) return 600000 + 100 * o.p[P_KH] + conv_col_bn(o.p[P_COUT]);   // conv_col_kernel<KH, BN>
     if (o.flags & F_PATCH) {   // conv_patch_kernel<TH, BN, BIGP> -> 100000*BIGP + 1000*TH + BN
         // conv_patch_kernel<TH, BN, MODE> -> 100000*MODE + 1000*TH + BN
         int th, bn, mode;
