@@ -90,14 +90,21 @@ def test_weight_store_is_shape_independent():
 
 
 def test_kernel_selection_and_head_fusion_at_full_size():
-    """At the reference's det size the k x k stride-1 convs with <= 64 couts go to the LDS-resident-patch kernel (wider
-    ones are faster on the 256-pixel implicit-GEMM tiles), the DB head's
+    """At the reference's det size the k x k stride-1 convs go to the LDS-resident-patch family (conv_patch_kernel, or the
+    column-per-step kernels conv_col_kernel / conv_c3_kernel = F_COL), the DB head's
     1x1->1-channel conv + sigmoid is folded into its producer (F_DOT1) and the upsample+concat in front of it is a
     virtual 2-source gather (F_SRC2): no 64-channel 544x960 tensor is written or copied."""
     desc, w = net_ref.get_weights("V4_ch_det")
     prog = compiler.compile_model(desc, w, 1, 544, 960)
     flags = [int(o["flags"]) for o in prog.ops if int(o["kind"]) == ir.OP_CONV]
-    assert sum(bool(f & ir.F_PATCH) for f in flags) >= 10
+    assert sum(bool(f & (ir.F_PATCH | ir.F_COL)) for f in flags) >= 30 and sum(bool(f & ir.F_COL) for f in flags) >= 20
+    # every column-kernel op obeys the kernels' preconditions (conv_col_ok / conv_c3_ok)
+    for o in prog.ops:
+        if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_COL:
+            p = o["p"]
+            assert not int(o["flags"]) & (ir.F_PATCH | ir.F_SRC2 | ir.F_DOT1 | ir.F_HILO | ir.F_PIXSHUF)
+            assert (p[ir.P_SH], p[ir.P_SW]) == (1, 1) and p[ir.P_CINP] % 16 == 0 and p[ir.P_KH] in (3, 5, 7, 9)
+            assert p[ir.P_COUT] <= (192 if p[ir.P_KH] == 3 else 64) and p[ir.P_KTOT] == p[ir.P_KH] * p[ir.P_KW] * p[ir.P_CINP]
     assert sum(bool(f & ir.F_DOT1) for f in flags) == 1 and sum(bool(f & ir.F_SRC2) for f in flags) == 1
     # ... and that last conv runs on the LOW-RES grid with folded 2x2 taps (conv_head.hip): same algorithmic MACs reported
     assert sum(bool(f & ir.F_UP2HEAD) for f in flags) == 1
@@ -177,7 +184,9 @@ def test_light_patch_variant_selection():
             assert not int(o["flags"]) & ir.F_PATCH and int(p[ir.P_KTOT]) == taps * int(p[ir.P_CINP])
             col.add(taps)
     # (the 17x30 maps of the coarsest pyramid level tile badly into 16-row tiles and stay on the 8-row patch variant)
-    assert (9, 10) in seen and col == {81, 49, 25}
+    # (... and the 3x3 layers with more than 64 couts over 64 input channels stay on LIGHT; the other 3x3 layers up to 192 couts
+    # run on conv_c3_kernel)
+    assert (9, 10) in seen and col == {81, 49, 25, 9}
 
 
 @pytest.mark.parametrize("optype,attr,value", [("conv2d", "dilations", [2, 2]), ("conv2d", "padding_algorithm", "SAME"),

@@ -96,6 +96,12 @@ CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (64, 40, (9, 5), (1, 1), (4, 2), 16, 40, 1),       # tall filter, 5 columns; cout tail (40 of 64)
     (32, 64, (5, 9), (1, 1), (2, 4), 21, 64, 1),       # wide filter: 9 steps of 5 taps
     (16, 16, (7, 7), (1, 1), (3, 3), 33, 31, 3),       # a single chunk; 16 couts of a 32-cout tile
+    # conv_c3_kernel (3x3, 16-channel chunks, two blocks per CU; tile shape per map) — the 128-cout 3x3 cases above run on it too
+    (64, 128, (3, 3), (1, 1), (1, 1), 12, 384, 2),     # recogniser-like map: 4 x 128 tiles, two cout tiles
+    (128, 64, (3, 3), (1, 1), (1, 1), 24, 130, 1),     # 8 x 64 tiles with a 2-pixel third column tile (idle waves)
+    (48, 64, (3, 3), (1, 1), (1, 1), 19, 70, 2),       # 3 chunks; ragged in both directions
+    (256, 96, (3, 3), (1, 1), (1, 1), 34, 60, 1),      # 16 chunks, cout tail (96 = 64 + 32)
+    (16, 16, (3, 3), (1, 1), (1, 1), 64, 64, 1),       # K = 144 < PATCH_MIN_K: stays on the implicit GEMM
     # scalar-addressed implicit GEMM (conv_gemm_kernel: cin % 32 == 0, <= 31 taps); VSE_CONV_GEMM=0 sends the same
     # cases through conv_mfma_kernel
     (64, 128, (3, 3), (1, 1), (1, 1), 20, 36, 2),      # masked, BN=128, image seam inside a tile

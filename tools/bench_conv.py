@@ -38,6 +38,12 @@ LAYERS = {  # name: cin, cout, k, stride, pad, h, w, n
     "det_9x9_256_64_h17": (256, 64, (9, 9), (1, 1), (4, 4), 17, 30, 64),
     "det_9x9_64_64_h68": (64, 64, (9, 9), (1, 1), (4, 4), 68, 120, 64),
     "det_3x3_256_64_h68": (256, 64, (3, 3), (1, 1), (1, 1), 68, 120, 64),
+    "det_3x3_224_224": (224, 224, (3, 3), (1, 1), (1, 1), 17, 30, 64),
+    "rec_3x3_128_128_w768": (128, 128, (3, 3), (1, 1), (1, 1), 12, 384, 28),
+    "rec_3x3_160_160_w768": (160, 160, (3, 3), (1, 1), (1, 1), 12, 192, 28),
+    "rec_3x3_192_192_w768": (192, 192, (3, 3), (1, 1), (1, 1), 6, 192, 28),
+    "rec_3x3_768_192_w768": (768, 192, (3, 3), (1, 1), (1, 1), 6, 192, 28),
+    "rec_3x3_224_224_w768": (224, 224, (3, 3), (1, 1), (1, 1), 3, 192, 28),
     "det_7x7_32_32": (32, 32, (7, 7), (1, 1), (3, 3), 136, 240, 64),
     "det_5x5_32_32": (32, 32, (5, 5), (1, 1), (2, 2), 136, 240, 64),
     "rec_3x3_128_128": (128, 128, (3, 3), (1, 1), (1, 1), 12, 512, 32),
@@ -76,7 +82,8 @@ def main():
         desc, wts = graph(cin, cout, k, s, p)
         from vse_amd import compiler
         nets = {}
-        for key, mink in (("g", 1 << 30), ("p", 500)):     # "p": conv_patch_kernel allowed; numeric cfgs: implicit GEMM only
+        # "p": conv_patch_kernel / conv_col_kernel allowed; "c": + conv_c3_kernel for any couts; numeric cfgs: implicit GEMM only
+        for key, mink in (("g", 1 << 30), ("p", 500), ("c", 500)):
             compiler.PATCH_MIN_K = mink
             nets[key] = engine.Net(ctx, desc, wts, want_probs=False)
         x = (torch.rand((n, h, w, 8), device="cuda") * 2 - 1).half()
@@ -87,16 +94,18 @@ def main():
         row = []
         ref = None
         for c in cfgs:
-            net = nets["p" if c == "p" else "g"]
-            compiler.PATCH_MIN_K = 500 if c == "p" else 1 << 30      # plans are compiled lazily on the first run
+            net = nets[c if c in ("p", "c") else "g"]
+            compiler.PATCH_MIN_K = 500 if c in ("p", "c") else 1 << 30      # plans are compiled lazily on the first run
             compiler.PATCH_MAX_COUT = 256 if c == "p" else 64       # "p": also try the patch kernel on wide layers (two+ cout tiles)
+            compiler.COL3 = c == "c"
+            compiler.COL3_MAX_COUT, compiler.COL3_MIN_TILE_EFF, compiler.COL3_WIDE_MIN_CIN = 4096, 0.0, 0
             os.environ["VSE_GEMM_CFG"] = "" if c in ("p", "d") else c      # "d": the launcher's own choice
             out = net.run(x)
             torch.cuda.synchronize()
             o = out[0].float()
             if ref is None:
                 ref = o.clone()
-            same = bool(torch.equal(o, ref)) or c == "p"
+            same = bool(torch.equal(o, ref)) or c in ("p", "c")
             best = 1e9
             for _ in range(3):
                 ms, prog, var = net.profile(x)

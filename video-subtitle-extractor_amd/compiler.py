@@ -145,6 +145,21 @@ HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
 COL = os.environ.get("VSE_COL", "1") != "0"           # conv_col_kernel (one filter column per step) for 9x9 / 7x7 / 5x5 layers
 # below this tile efficiency the 8-row tiles of conv_patch_kernel win (measured: 17x30 map 0.163 vs 0.203 ms, 34x60 0.50 vs 0.43)
 COL_MIN_TILE_EFF = float(os.environ.get("VSE_COL_MINEFF", "0.75"))
+# conv_c3_kernel (3x3, two blocks per CU): VSE_COL3=0 off; cout / tile-efficiency limits from per-layer A/B runs
+COL3 = os.environ.get("VSE_COL3", "1") != "0"
+COL3_MAX_COUT = int(os.environ.get("VSE_COL3_MAXCOUT", "192"))     # per-layer A/B (tools/bench_conv.py --cfgs d,p,c): 224-cout layers tie or lose
+COL3_WIDE_MIN_CIN = 128    # layers with more than 64 couts (two+ cout tiles refetch the patch) only from 128 input channels on
+COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
+
+
+def c3_tile_eff(oh, ow):
+    """Mirror of conv_c3_plan (csrc/conv_c3.hip): best tile efficiency over the 16x32 / 8x64 / 4x128 tile shapes when waves
+    outside the map idle."""
+    def axis(n, unit, waves):
+        tile = unit * waves
+        full, rem = divmod(n, tile)
+        return full + ((0.35 + 0.65 * -(-rem // unit) / waves) if rem else 0.0)
+    return max(oh * ow / (axis(oh, 2, rw) * axis(ow, 32, 8 // rw) * 512.0) for rw in (8, 4, 2))
 
 
 class UnsupportedGraph(NotImplementedError):
@@ -676,6 +691,16 @@ class Compiler:
             return False
         return cinp % 32 == 0 and kh * kw <= 31 and kh >= 2 * ph + 1 and kw >= 2 * pw
 
+    def _dot1_candidate(self, name, cout):
+        """Structural half of _try_fuse_dot1 without side effects: the only consumer is a 1x1 conv to ONE channel."""
+        cons = self._live_consumers(name)
+        if len(cons) != 1 or name in self.placement or self.ops[cons[0]]["type"] != "conv2d":
+            return False
+        op = self.ops[cons[0]]
+        a = op["attrs"]
+        return (tuple(self.W[op["in"]["Filter"][0]].shape) == (1, cout, 1, 1) and list(a["strides"]) == [1, 1]
+                and not any(a["paddings"]) and a.get("groups", 1) == 1)
+
     def _try_fuse_dot1(self, name, cout, coutp):
         """`name` (conv output after its epilogue) -> conv2d 1x1 to ONE channel (+bias, +sigmoid): fold it into the
         producing conv's epilogue as a per-pixel dot product; the wide tensor is then never written to HBM."""
@@ -855,6 +880,11 @@ class Compiler:
         col = (COL and (sh, sw) == (1, 1) and kh in (5, 7, 9) and 3 <= kw <= 17 and inv.span % 16 == 0 and coutp <= 64
                and inv.parts is None and self.use_patch and not self.hilo and kh * kw * cin >= PATCH_MIN_K
                and tile_eff_col >= COL_MIN_TILE_EFF)
+        c3 = (COL3 and (sh, sw) == (1, 1) and (kh, kw, ph, pw) == (3, 3, 1, 1) and inv.span % 16 == 0 and inv.parts is None
+              and self.use_patch and not self.hilo and kh * kw * cin >= PATCH_MIN_K and coutp <= COL3_MAX_COUT
+              and (coutp <= 64 or inv.span >= COL3_WIDE_MIN_CIN)
+              and c3_tile_eff(oh, ow) >= COL3_MIN_TILE_EFF and not self._dot1_candidate(ep["out_name"], cout))
+        col = col or c3
         if col:
             patch_std = light_ok = False
         patch = patch_std or light_ok

@@ -256,6 +256,10 @@ __device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const fl
 int launch_conv_patch(const ConvParams& p, int n_img, hipStream_t st);
 // one filter column per step over a 16-channel patch (conv_col.hip, F_COL): 9x9 / 7x7 / 5x5, <= 64 couts
 int launch_conv_col(const ConvParams& p, int n_img, hipStream_t st);
+// 3x3 sibling, two blocks per CU (conv_c3.hip, F_COL with kh = kw = 3)
+int launch_conv_c3(const ConvParams& p, int n_img, hipStream_t st);
+double conv_c3_plan(int OH, int OW, int* rw_out);
+bool conv_c3_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int flags);
 int conv_col_bn(int Np);
 bool conv_col_ok(int kh, int kw, int sh, int sw, int cinp, int Np, int flags);
 // DB head evaluated on the low-resolution grid (conv_head.hip, F_UP2HEAD)

@@ -206,6 +206,11 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if (o.kind != OP_CONV) return 0;
     if (o.flags & F_UP2HEAD) return 400000;   // conv_head_up2_kernel
     if (o.flags & F_STEM) return 500000;      // conv_stem_kernel
+    if ((o.flags & F_COL) && o.p[P_KH] == 3 && o.p[P_KW] == 3) {   // conv_c3_kernel<RW, 8 / RW>
+        int rw;
+        conv_c3_plan(o.out.h, o.out.w, &rw);
+        return 700000 + rw;
+    }
     if (o.flags & F_COL) return 600000 + 100 * o.p[P_KH] + conv_col_bn(o.p[P_COUT]);   // conv_col_kernel<KH, BN>
     if (o.flags & F_PATCH) {   // conv_patch_kernel<TH, BN, BIGP> -> 100000*BIGP + 1000*TH + BN
         // conv_patch_kernel<TH, BN, MODE> -> 100000*MODE + 1000*TH + BN
