@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--boxes", default="gt", choices=["gt", "db"])
     ap.add_argument("--bucket", type=int, default=256, help="rec width bucket (px)")
     ap.add_argument("--batch-round", type=int, default=4)
+    ap.add_argument("--min-rec-group", type=int, default=0, help="rec width buckets with fewer crops absorb the next narrower bucket")
     ap.add_argument("--rec-streams", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -148,7 +149,7 @@ def main():
         det = (det[0], empty_det_head(det[0], det[1]))
     charset = shim.standin_charset(lang, shim._ncls(rec[0]))      # stand-in weights: index-faithful placeholder table
     pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="bucketed", bucket=args.bucket,
-                                batch_round=args.batch_round)
+                                batch_round=args.batch_round, min_rec_group=args.min_rec_group)
 
     pipe.rec_streams = args.rec_streams
     frames_np, truth = synth.make_frames(args.batch, args.height, args.width, seed=100 + rank, return_truth=True)

@@ -1,0 +1,147 @@
+"""Frames -> raw.txt -> SRT driver (vse_amd.extractor) against tests/golden/extract.json: the reference's own fps sampler
+(backend/main.py:228-253) and OCR task producer / consumer (backend/tools/subtitle_ocr.py) executed on scripted inputs
+(tests/golden/make_extract_golden.py).  Host logic only: the recogniser is the same scripted fake."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from vse_amd import extractor
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "extract.json"), encoding="utf-8"))
+H, W, _ = G["frame_shape"]
+
+
+def frame_of(no):
+    f = np.zeros((H, W, 3), np.uint8)
+    f[:, :, 0] = no & 255
+    f[:, :, 1] = no >> 8
+    return f
+
+
+class ScriptedOcr:
+    def __init__(self, script, batched):
+        self.script, self.seen = script, []
+        if batched:
+            self.predict_batch = self._predict_batch
+
+    def predict(self, img):
+        no = int(img[0, 0, 0]) | (int(img[0, 0, 1]) << 8)
+        self.seen.append([no, list(img.shape)])
+        o = self.script.get(str(no), [])
+        return [q for q, _t, _s in o], [(t, s) for _q, t, s in o]
+
+    def _predict_batch(self, frames):
+        return [self.predict(np.asarray(f)) for f in frames]
+
+
+@pytest.mark.parametrize("fc", G["fps_cases"], ids=lambda c: f"{c['n_frames']}f@{c['fps']}/{c['extract_frequency']}")
+def test_fps_sampler_matches_reference(fc):
+    got = extractor.fps_tasks(fc["n_frames"], fc["fps"], fc["extract_frequency"], "AREA")
+    assert [[t[0], t[1], t[5]] for t in got] == fc["tasks"]
+    assert all(t[2] is None and t[3] is None and t[4] is None for t in got)
+
+
+@pytest.mark.parametrize("batched", [False, True])
+@pytest.mark.parametrize("k", range(len(G["ocr_cases"])))
+def test_ocr_tasks_match_reference_raw_txt(k, batched, monkeypatch):
+    c = G["ocr_cases"][k]
+    monkeypatch.setattr(extractor, "_stack", lambda frames: frames)           # scripted recogniser: no device
+    src = extractor.ArraySource([frame_of(i + 1) for i in range(c["n_frames"])], 25.0)
+    ocr = ScriptedOcr(c["ocr"], batched)
+    tasks = []
+    for no, cached, default_area in c["tasks"]:
+        o = c["ocr"].get(str(no), [])
+        dt, rr = ([q for q, _t, _s in o], [(t, s) for _q, t, s in o]) if cached else (None, None)
+        tasks.append((c["n_frames"], no, dt, rr, None, default_area))
+    tasks.append((c["n_frames"], -1, None, None, None, None))
+    area = None if c["area"] is None else extractor.SubtitleArea(**c["area"])
+    lines = extractor.run_ocr_tasks(src, tasks, ocr, area, c["lang"], c["drop_score"], c["deviation"], batch=3)
+    assert "".join(lines) == c["raw"]
+    assert sorted(ocr.seen) == sorted(c["seen"])              # same frames recognised, same (cropped) shapes
+
+
+def test_extractor_run_end_to_end_host():
+    """fps sampler -> OCR -> scene-text filter -> SRT, and the same with an area (no filters); SRT numbering / time codes from
+    srt.generate_subtitle_file (pinned separately by golden/srt.json)."""
+    script = {}
+    for no in range(1, 101):
+        items = [[[[10, 30], [50, 30], [50, 36], [10, 36]], "first" if no <= 40 else "second subtitle", 0.9]]
+        if no % 2:
+            items.append([[[5, 2], [30, 2], [30, 8], [5, 8]], "LOGO", 0.99])
+        script[str(no)] = items
+    src = extractor.ArraySource([frame_of(i + 1) for i in range(100)], 25.0)
+    ex = extractor.SubtitleExtractor(src, ScriptedOcr(script, False), extract_frequency=5)
+    text = ex.run()
+    assert text == "1\n00:00:00,001 --> 00:00:01,011\nfirst\n\n2\n00:00:01,016 --> 00:00:03,021\nsecond subtitle\n\n"
+    assert extractor.SubtitleExtractor.srt2txt(text) == "first\nsecond subtitle\n"
+    assert all("LOGO" not in ln for ln in ex.raw_lines)        # scene-text filter: most frequent vertical band only
+    area = extractor.SubtitleArea(ymin=28, ymax=38, xmin=0, xmax=64)
+    ex2 = extractor.SubtitleExtractor(src, ScriptedOcr(script, False), sub_area=area, extract_frequency=5)
+    assert ex2.run() == text
+
+
+def test_uncompressed_avi_roundtrip_and_refusals(tmp_path):
+    from vse_amd import ingest
+    rng = np.random.default_rng(2)
+    frames = rng.integers(0, 256, (7, 18, 37, 3), dtype=np.uint8)          # odd width: rows padded to 4 bytes
+    p = str(tmp_path / "clip.avi")
+    ingest.write_avi_bgr24(p, frames, 23.976)
+    src = ingest.open_source(p)
+    assert (src.frame_count, src.width, src.height) == (7, 37, 18) and abs(src.fps - 23.976) < 1e-9
+    assert all(np.array_equal(a, b) for a, b in zip(src.frames(), frames))
+    assert np.array_equal(src.read(5), frames[4]) and src.read(0) is None and src.read(8) is None
+    assert src.pos_msec(7) is None and src.pos_msec(0) == 0.0 and abs(src.pos_msec(3) - 3000 / 23.976) < 1e-9
+    src.close()
+    np.save(str(tmp_path / "clip.npy"), frames)
+    nsrc = ingest.open_source(str(tmp_path / "clip.npy"), fps=25)
+    assert nsrc.frame_count == 7 and np.array_equal(nsrc.read(7), frames[6])
+    with pytest.raises(ValueError, match="fps"):
+        ingest.open_source(str(tmp_path / "clip.npy"))
+    # a compressed stream is refused with a reason instead of decoded wrongly
+    raw = bytearray(open(p, "rb").read())
+    i = raw.index(b"vidsDIB ")
+    raw[i + 4:i + 8] = b"H264"
+    (tmp_path / "h264.avi").write_bytes(bytes(raw))
+    with pytest.raises(ValueError, match="needs a codec"):
+        ingest.AviBgr24Source(str(tmp_path / "h264.avi"))
+    (tmp_path / "junk.avi").write_bytes(b"not a video at all")
+    with pytest.raises(ValueError, match="RIFF"):
+        ingest.AviBgr24Source(str(tmp_path / "junk.avi"))
+
+
+def _shard_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = G["ocr_cases"][0]
+    extractor._stack = lambda frames: frames
+    src = extractor.ArraySource([frame_of(i + 1) for i in range(c["n_frames"])], 25.0)
+    ocr = ScriptedOcr(c["ocr"], True)
+    tasks = [(c["n_frames"], no, None, None, None, None) for no, _c, _a in c["tasks"]]
+    lines = extractor.run_ocr_tasks(src, tasks, ocr, extractor.SubtitleArea(**c["area"]), c["lang"], c["drop_score"],
+                                    c["deviation"], batch=2, shard=(rank, world), gather_device="cpu")
+    q.put((rank, "".join(lines), sorted(n for n, _s in ocr.seen)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_ocr_tasks_world2_gloo():
+    """N > 1: each rank recognises a contiguous slice of the tasks, one variable-length gather, every rank ends up with the
+    reference's raw.txt."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    c = G["ocr_cases"][0]
+    assert got[0][1] == got[1][1] == c["raw"]
+    assert got[0][2] == [1, 2, 3, 4, 5] and got[1][2] == [6, 7, 8, 9, 10]          # disjoint halves of the work

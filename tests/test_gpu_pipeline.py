@@ -277,3 +277,60 @@ def test_text_recognizer_call_site(ctx):
     gspecs = [dict(frame=i, gframe=0, ratio=c.shape[1] / float(c.shape[0])) for i, c in enumerate(crops)]
     assert [(list(idx), int(w)) for idx, w in tr.pipe._groups(gspecs)] == want_groups
     assert tr([])[0] == []
+
+
+def test_extractor_srt_matches_oracle_on_a_clip(ctx):
+    """BASELINE configs[0] as far as it can exist here: a short clip -> frame selection -> batched det + rec on the engine ->
+    raw.txt filters -> SRT, against the same driver fed by the CPU oracle frame by frame (the reference's order of work).
+    Accurate mode with a subtitle area (detector-driven frame selection, cached OCR results) and the fps sampler without an
+    area (scene-text filter) both give the oracle's raw.txt and SRT, byte for byte.  The stand-in recogniser's class
+    projection is scaled up so that its arg-max margins sit far above fp16 noise (a flat softmax makes strings a coin toss)."""
+    import torch
+    from vse_amd import extractor, pipeline, shim, synth
+    det = net_ref.get_weights("V3_ch_det_fast")
+    desc, w = net_ref.get_weights("V4_en_rec_fast")
+    last = [op for op in desc["ops"] if op["type"] in ("matmul_v2", "matmul")][-1]["in"]["Y"][0]
+    w = dict(w)
+    w[last] = w[last] * 12.0
+    rec = (desc, w)
+    cs = P.en_charset()
+    pipe = pipeline.OcrPipeline(ctx, det, rec, cs, rec_mode="reference")
+
+    class EngineOcr:
+        def predict(self, frame):
+            b, r = pipe.ocr(torch.from_numpy(np.ascontiguousarray(frame)).cuda()[None])[0]
+            return shim.OcrRecogniser.arrange(b, r)
+
+        def predict_batch(self, frames):
+            return [shim.OcrRecogniser.arrange(b, r) for b, r in pipe.ocr(frames)]
+
+    det_fn = lambda x: net_ref.run_graph(det[0], det[1], x)[0].numpy()[0, 0]
+    rec_fn = lambda b: net_ref.run_graph(rec[0], rec[1], b)[0].numpy()
+
+    class OracleOcr:
+        def predict(self, frame):
+            return P.ocr_predict_glue(*P.text_system(frame, det_fn, rec_fn, cs))
+
+    def oracle_detect(frames):
+        out = []
+        for f in frames:
+            x, _ = P.det_preprocess(f)
+            out.append(np.asarray(P.db_postprocess(det_fn(x), f.shape[0], f.shape[1])[0], np.float32).reshape(-1, 4, 2))
+        return out
+
+    def engine_detect(frames):
+        dev = torch.from_numpy(np.stack(frames)).cuda()
+        return [np.asarray(b, np.float32).reshape(-1, 4, 2) for b in pipe.detect(dev)]
+
+    h, wd = 360, 640
+    lit = synth.make_frames(3, h, wd, seed=4)
+    dark = np.full((h, wd, 3), 40, np.uint8)
+    clip = [dark, dark] + [lit[0]] * 5 + [dark] + [lit[1]] * 5 + [lit[2]] * 4 + [dark]
+    src = extractor.ArraySource(clip, 12.0)
+    area = extractor.SubtitleArea(ymin=int(0.7 * h), ymax=h, xmin=0, xmax=wd)
+    for kw in (dict(sub_area=area, mode="accurate"), dict(sub_area=None, mode="fast", extract_frequency=6)):
+        eng = extractor.SubtitleExtractor(src, EngineOcr(), detect_batch=engine_detect, drop_score=0.5, batch=8, **kw)
+        ora = extractor.SubtitleExtractor(src, OracleOcr(), detect_batch=oracle_detect, drop_score=0.5, batch=8, **kw)
+        got, want = eng.run(), ora.run()
+        assert eng.raw_lines == ora.raw_lines and len(ora.raw_lines) >= 3
+        assert got == want and got.count(" --> ") >= 1

@@ -65,3 +65,27 @@ def test_paddleocr_kwargs_are_checked_before_any_model_is_loaded():
                        rec_batch_num=6, rec_model_dir="V4_ch_rec", max_batch_size=10, det=True, use_angle_cls=False,
                        drop_score=0, lang="ch", ocr_version="PP-OCRv4", rec_image_shape="3,48,320", use_onnx=False,
                        onnx_providers=[])
+
+
+def test_bucketed_groups_fold_small_buckets_upwards():
+    """Bucketed recognition (throughput mode): a width bucket with fewer than min_rec_group crops absorbs the next narrower
+    bucket — widest first, because only a wider group can hold narrower crops; every crop stays in exactly one group whose
+    width covers it, and min_rec_group=0 keeps the plain buckets."""
+    from vse_amd import pipeline
+    p = pipeline.OcrPipeline.__new__(pipeline.OcrPipeline)
+    p.rec_mode, p.rec_h, p.rec_base_w, p.bucket, p.max_rec_batch = "bucketed", 48, 320, 256, 64
+    ratios = [10] * 28 + [15] * 28 + [20] * 22 + [26] * 4
+    specs = [dict(ratio=r) for r in ratios]
+    p.min_rec_group = 0
+    assert [(len(i), w) for i, w in p._groups(specs)] == [(28, 512), (28, 768), (22, 1024), (4, 1280)]
+    p.min_rec_group = 8
+    groups = p._groups(specs)
+    assert [(len(i), w) for i, w in groups] == [(28, 512), (28, 768), (26, 1280)]
+    seen = sorted(i for idx, _ in groups for i in idx)
+    assert seen == list(range(len(specs)))
+    assert all(48 * ratios[i] <= w for idx, w in groups for i in idx)
+    # cascades: every bucket too small -> one group at the widest width; more than max_rec_batch crops are chunked as before
+    p.min_rec_group = 8
+    assert [(len(i), w) for i, w in p._groups([dict(ratio=r) for r in [10] * 3 + [15] * 2 + [20] * 2 + [26]])] == [(8, 1280)]
+    p.max_rec_batch = 16
+    assert [len(i) for i, _ in p._groups([dict(ratio=10)] * 40)] == [16, 16, 8]

@@ -55,9 +55,9 @@ def unpack_records(buf):
     return recs
 
 
-def gather_records(records, device=None):
-    """All ranks call; rank 0 gets the concatenation ordered by frame number, other ranks get None.
-    Works without torch.distributed initialised (single process)."""
+def gather_records(records, device=None, to_all=False):
+    """All ranks call; rank 0 gets the concatenation ordered by frame number, other ranks get None (to_all=True: every
+    rank gets it — the exchange is an all_gather anyway).  Works without torch.distributed initialised (single process)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -73,7 +73,7 @@ def gather_records(records, device=None):
     buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
     bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
     dist.all_gather(bufs, buf)
-    if rank != 0:
+    if rank != 0 and not to_all:
         return None
     out = []
     for b, s in zip(bufs, sizes):

@@ -59,7 +59,7 @@ def resolve_det_weights(det_weights, weights):
 class OcrPipeline:
     def __init__(self, ctx, det_model, rec_model, charset, rec_batch_num=6, rec_h=48, rec_base_w=320,
                  limit_side_len=960, db_thresh=0.3, db_box_thresh=0.6, db_unclip_ratio=1.5, drop_score=0.0,
-                 rec_mode="reference", bucket=64, batch_round=1, max_rec_batch=64, det_weights="auto"):
+                 rec_mode="reference", bucket=64, batch_round=1, max_rec_batch=64, det_weights="auto", min_rec_group=0):
         """det_model / rec_model: (descriptor, weights dict).
         det_weights: "fp16" | "fp16x2" | "auto".  fp16x2 stores the detector's conv weights as fp16 hi + lo pairs (two K
         passes into the same fp32 accumulators): the rounding of BN-folded weights to fp16 is what moves box borders against
@@ -80,6 +80,7 @@ class OcrPipeline:
         self.bucket = bucket
         self.batch_round = batch_round        # bucketed mode: pad group sizes to a multiple (bounds the plan cache)
         self.max_rec_batch = max_rec_batch
+        self.min_rec_group = min_rec_group    # bucketed mode: buckets with fewer crops absorb the next narrower bucket
         self.profile_sink = None              # list: when set, every net run is profiled per op and appended here
         self.rec_streams = 1                  # >1: width groups of the recogniser run on that many side streams
 
@@ -155,6 +156,19 @@ class OcrPipeline:
             for i, s in enumerate(specs):
                 wb = (wneed(s) + self.bucket - 1) // self.bucket * self.bucket
                 buckets.setdefault(wb, []).append(i)
+            # a bucket with a handful of crops runs ~80 launches that fill a fraction of the chip (4 crops x 1280 px: 2.9 ms,
+            # 24 x 1024: 4.2 ms on MI355X): fold the next narrower bucket into it (its crops are padded further) until the
+            # group is worth its launches — from the widest bucket down, since only wider buckets can hold narrower crops
+            min_group = getattr(self, "min_rec_group", 0)
+            if min_group > 1:
+                widths = sorted(buckets, reverse=True)
+                k = 0
+                while k < len(widths) - 1:
+                    if len(buckets[widths[k]]) < min_group:
+                        buckets[widths[k]] += buckets.pop(widths[k + 1])
+                        del widths[k + 1]
+                    else:
+                        k += 1
             for wb in sorted(buckets):
                 idx = buckets[wb]
                 for b in range(0, len(idx), self.max_rec_batch):
