@@ -31,6 +31,10 @@
                           // conv_col_kernel); 0: plain look-ahead of three stages.  With two blocks per CU the partner block covers
                           // the barrier bubble, and a stage's DMA round trip (~5k cycles under load) needs the third step of slack.
 #endif
+// (Measured and removed: a PERSISTENT form — a block walking tiles lb, lb + 512, ... with the DMA ring running across tile
+// boundaries, so that only a block's first tile pays the prologue's DMA round trip.  Correct, but 9-25 % SLOWER on every
+// layer (128->128 0.687 -> 0.751 ms, 64->64 0.76 -> 0.96 ms): the epilogue's stores sit in the same in-order vmcnt queue as
+// the LDS-DMAs, so the first counted waits of the next tile also wait for the stores' HBM round trip.)
 #define C3RING 4
 #define C3BN 64
 
