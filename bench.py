@@ -334,7 +334,11 @@ def roofline(pipe, step, repeats=2):
             "algorithmic_gflop_per_launch": round(2 * gmac / cnt, 2),
             "share_of_conv_time": round(tms / all_ms, 3),
             "all_conv_tflops": round(2.0 * sum(v[1] for v in agg.values()) / all_ms, 2),
-            "conv_ms_per_step": round(all_ms / repeats, 3)}
+            "conv_ms_per_step": round(all_ms / repeats, 3),
+            # the other conv kernel instantiations by share of conv time (same definition of `achieved` for each)
+            "kernels": [{"kernel": variant_kernel_name(v), "share": round(t / all_ms, 3), "launches_per_step": c // repeats,
+                         "achieved": round(2.0 * g / t, 1), "frac": round(2.0 * g / t / MFMA_PEAK_TFLOPS, 3)}
+                        for v, (t, g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:6]]}
 
 
 if __name__ == "__main__":

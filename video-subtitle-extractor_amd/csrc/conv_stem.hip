@@ -18,36 +18,33 @@
 #define ST_ROWS 8
 #define ST_COLS 32
 
-template <int SH, int SW>
+// HILO is a template parameter: the lo table costs 40 VGPRs per lane (a resident block per CU less) and 40 KiB of loads per block,
+// which plain fp16 nets must not pay.  The weight tables are staged ONCE per block in LDS (<= 10 KiB each, 16 bytes per thread and
+// pass) and the fragments read from there: fetching the 20 fragments per lane straight from global memory moved 40-80 KiB through
+// the L1 / texture path per 256-pixel tile — more than the tile's input patch and output together.
+template <int SH, int SW, bool HILO>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
     constexpr int PH_ = (ST_ROWS - 1) * SH + 3, PW_ = (ST_COLS - 1) * SW + 3, NPIX = PH_ * PW_;
-    __shared__ __attribute__((aligned(16))) half_t patch[NPIX * 4 + 128];      // + 64 floats of bias
-    float* const sbias = reinterpret_cast<float*>(patch + NPIX * 4);
+    constexpr int NPIX4 = (NPIX * 4 + 7) & ~7;                                   // 16-byte aligned start of the weight tables
+    constexpr int WTAB = 64 * 80;
+    __shared__ __attribute__((aligned(16))) half_t patch[NPIX4 + (HILO ? 2 : 1) * WTAB + 128];      // + 64 floats of bias
+    half_t* const swt = patch + NPIX4;
+    float* const sbias = reinterpret_cast<float*>(swt + (HILO ? 2 : 1) * WTAB);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // ---- weights: lane (f = lane & 31, fj) supplies cout conv_wrow(f) of each 32-cout tile, k = 16 ks + 8 fj .. +7 ----------
     const int fx = lane & 31, fj = lane >> 5;
-    half8 wf[2][5];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = j * 32 + conv_wrow(fx);
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks)
-            wf[j][ks] = r < p.Np ? *reinterpret_cast<const half8*>(p.w + (long)r * 80 + ks * 16 + fj * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    // F_HILO: the fp16 lo parts of the weights (second block of Np x 80 halfs), multiplied in a second pass
-    const bool hilo = p.flags & F_HILO;
-    half8 wl[2][5];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = j * 32 + conv_wrow(fx);
-#pragma unroll
-        for (int ks = 0; ks < 5; ++ks)
-            wl[j][ks] = (hilo && r < p.Np) ? *reinterpret_cast<const half8*>(p.w + ((long)p.Np + r) * 80 + ks * 16 + fj * 8)
-                                           : half8{0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- weight tables [Np][80] (hi, then lo) -> LDS, rows >= Np zero ---------------------------------------------------------
+    {
+        const int nvec = p.Np * 10;                                             // 16-byte vectors per table
+        for (int v = tid; v < (HILO ? 2 : 1) * 640; v += 256) {
+            const int tab = v / 640, u = v - tab * 640;
+            half8 x = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (u < nvec) x = *reinterpret_cast<const half8*>(p.w + (long)tab * p.Np * 80 + u * 8);
+            *reinterpret_cast<half8*>(swt + tab * WTAB + u * 8) = x;
+        }
     }
     if (tid < 64) sbias[tid] = tid < p.Np ? p.bias[tid] : 0.f;
 
@@ -70,6 +67,15 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
         *reinterpret_cast<half4*>(patch + q * 4) = v;
     }
     __syncthreads();
+
+    // ---- weights: lane (f = lane & 31, fj) supplies cout conv_wrow(f) of each 32-cout tile, k = 16 ks + 8 fj .. +7 ----------
+    half8 wf[2][5];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = j * 32 + conv_wrow(fx);
+#pragma unroll
+        for (int ks = 0; ks < 5; ++ks) wf[j][ks] = *reinterpret_cast<const half8*>(swt + r * 80 + ks * 16 + fj * 8);
+    }
 
     // ---- 20 MFMAs per wave -------------------------------------------------------------------------------------------------------
     float16v acc[2][2];
@@ -94,7 +100,15 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
         }
     }
 
-    if (hilo) {
+    if constexpr (HILO) {
+        // F_HILO: the fp16 lo parts of the weights (second table), multiplied in a second pass into the same accumulators
+        half8 wl[2][5];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = j * 32 + conv_wrow(fx);
+#pragma unroll
+            for (int ks = 0; ks < 5; ++ks) wl[j][ks] = *reinterpret_cast<const half8*>(swt + WTAB + r * 80 + ks * 16 + fj * 8);
+        }
 #pragma unroll
         for (int ks = 0; ks < 5; ++ks) {
             int t0 = 2 * ks + fj;
@@ -136,7 +150,11 @@ int launch_conv_stem(const ConvParams& pin, int n_img, hipStream_t st) {
     p.tiles_w = (p.OW + ST_COLS - 1) / ST_COLS;
     const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w;
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
-    if (p.sh == 2) hipLaunchKernelGGL((conv_stem_kernel<2, 2>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_stem_kernel<1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)blocks), block(256);
+    const bool hilo = p.flags & F_HILO;
+    if (p.sh == 2 && hilo) hipLaunchKernelGGL((conv_stem_kernel<2, 2, true>), grid, block, 0, st, p);
+    else if (p.sh == 2) hipLaunchKernelGGL((conv_stem_kernel<2, 2, false>), grid, block, 0, st, p);
+    else if (hilo) hipLaunchKernelGGL((conv_stem_kernel<1, 1, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((conv_stem_kernel<1, 1, false>), grid, block, 0, st, p);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }
