@@ -177,3 +177,53 @@ def test_hilo_weights_on_gpu(ctx, mid):
     assert e_hi < (5e-2 if real else 1e-2) and e_hi <= e_lo + 1e-4, (e_lo, e_hi)
     if real:        # (stand-in nets put arbitrary pixels next to the threshold: flip counts mean nothing there)
         assert ((maps[True] > 0.3) != (ref > 0.3)).sum() <= ((maps[False] > 0.3) != (ref > 0.3)).sum()
+
+
+def _up_res_graph(cin, cout, k, rng):
+    """conv k x k over a nearest-x2-upsampled tensor (gathered on load: P_INSHIFT) + bias + residual add (F_RES) + relu."""
+    pad = [k[0] // 2, k[1] // 2]
+    desc = {"model": "unit", "ops": [
+        {"type": "feed", "in": {"X": ["feed"]}, "out": {"Out": ["x"]}, "attrs": {"col": 0}},
+        {"type": "conv2d", "in": {"Input": ["x"], "Filter": ["wr"]}, "out": {"Output": ["r"]},
+         "attrs": {"strides": [1, 1], "paddings": [0, 0], "groups": 1}},
+        {"type": "pool2d", "in": {"X": ["x"]}, "out": {"Out": ["p"]},
+         "attrs": {"pooling_type": "avg", "ksize": [2, 2], "strides": [2, 2], "paddings": [0, 0], "ceil_mode": False,
+                   "exclusive": True, "adaptive": False, "global_pooling": False, "padding_algorithm": "EXPLICIT"}},
+        {"type": "conv2d", "in": {"Input": ["p"], "Filter": ["w0"]}, "out": {"Output": ["t0"]},
+         "attrs": {"strides": [1, 1], "paddings": [0, 0], "groups": 1}},
+        {"type": "nearest_interp_v2", "in": {"X": ["t0"]}, "out": {"Out": ["u"]},
+         "attrs": {"scale": [2.0, 2.0], "align_corners": False, "interp_method": "nearest", "out_h": -1, "out_w": -1}},
+        {"type": "conv2d", "in": {"Input": ["u"], "Filter": ["w1"]}, "out": {"Output": ["t1"]},
+         "attrs": {"strides": [1, 1], "paddings": pad, "groups": 1}},
+        {"type": "elementwise_add", "in": {"X": ["t1"], "Y": ["b1"]}, "out": {"Out": ["t1b"]}, "attrs": {"axis": 1}},
+        {"type": "elementwise_add", "in": {"X": ["t1b"], "Y": ["r"]}, "out": {"Out": ["t2"]}, "attrs": {"axis": -1}},
+        {"type": "relu", "in": {"X": ["t2"]}, "out": {"Out": ["t3"]}, "attrs": {}},
+        {"type": "fetch", "in": {"X": ["t3"]}, "out": {"Out": ["fetch"]}, "attrs": {"col": 0}}],
+        "params": {"w0": {"dims": [cin, 3, 1, 1], "dtype": 5}, "w1": {"dims": [cout, cin, k[0], k[1]], "dtype": 5},
+                   "b1": {"dims": [cout], "dtype": 5}, "wr": {"dims": [cout, 3, 1, 1], "dtype": 5}},
+        "var_shapes": {"p": [-1, 3, -1, -1], "t0": [-1, cin, -1, -1], "u": [-1, cin, -1, -1], "t1": [-1, cout, -1, -1],
+                       "t1b": [-1, cout, -1, -1], "r": [-1, cout, -1, -1], "t2": [-1, cout, -1, -1]}}
+    wts = {"w0": rng.standard_normal((cin, 3, 1, 1)).astype(np.float32),
+           "w1": (rng.standard_normal((cout, cin, k[0], k[1])) / np.sqrt(cin * k[0] * k[1])).astype(np.float32),
+           "b1": rng.standard_normal(cout).astype(np.float32) * 0.1,
+           "wr": rng.standard_normal((cout, 3, 1, 1)).astype(np.float32) * 0.3}
+    return desc, wts
+
+
+@pytest.mark.parametrize("cin,cout,k,h,w", [(64, 64, (3, 3), 32, 64), (128, 96, (3, 3), 24, 128), (64, 64, (9, 9), 32, 64),
+                                            (32, 32, (5, 5), 48, 64), (96, 200, (3, 3), 16, 64)])
+def test_column_kernels_with_upsampled_input_and_residual(ctx, cin, cout, k, h, w):
+    """conv_c3_kernel / conv_col_kernel with the input gathered through a nearest x2 upsample (P_INSHIFT) and a residual add in
+    the epilogue (F_RES) — the FPN patterns; the last case (200 couts) takes the implicit GEMM and checks the same graph there."""
+    from vse_amd import compiler, ir
+    rng = np.random.default_rng(cin + cout)
+    desc, wts = _up_res_graph(cin, cout, k, rng)
+    prog = compiler.compile_model(desc, wts, 2, h, w)
+    big = [o for o in prog.ops if int(o["kind"]) == ir.OP_CONV and int(o["p"][ir.P_KH]) == k[0]][0]
+    assert int(big["p"][ir.P_INSHIFT]) == 1 and int(big["flags"]) & ir.F_RES
+    assert bool(int(big["flags"]) & ir.F_COL) == (cout <= 192)
+    x = rng.uniform(-1, 1, (2, 3, h, w)).astype(np.float16).astype(np.float32)
+    ref = net_ref.run_graph(desc, wts, x)[0].numpy()
+    got = np.transpose(run_hip(ctx, desc, wts, x)[0], (0, 3, 1, 2))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
