@@ -153,9 +153,11 @@ class Emulator:
             return
         if int(r["flags"]) & ir.F_COL:
             assert cinp % 16 == 0 and Kp == kh * kw * cinp
-            wt = self.wread(int(r["w_off"]), Kp * Np + 3 * kh * Np * 16, np.float16).astype(np.float32)
-            assert not wt[Kp * Np:].any()                   # the three zero stages of the DMA look-ahead
-            wmat = np.ascontiguousarray(wt[:Kp * Np].reshape(cinp // 16, kw, kh, Np, 16).transpose(3, 2, 1, 0, 4)).reshape(Np, Kp)
+            npass = 2 if int(r["flags"]) & ir.F_HILO else 1          # w = hi + lo (the lo stream follows the hi stream)
+            wt = self.wread(int(r["w_off"]), npass * Kp * Np + 3 * kh * Np * 16, np.float16).astype(np.float32)
+            assert not wt[npass * Kp * Np:].any()           # the three zero stages of the DMA look-ahead
+            ws = wt[:Kp * Np] + (wt[Kp * Np:2 * Kp * Np] if npass == 2 else 0.0)
+            wmat = np.ascontiguousarray(ws.reshape(cinp // 16, kw, kh, Np, 16).transpose(3, 2, 1, 0, 4)).reshape(Np, Kp)
         elif int(r["flags"]) & ir.F_PATCH:
             taps = kh * kw
             c32 = (cinp + 31) // 32 * 32

@@ -219,6 +219,7 @@ class Compiler:
         self.store = store if store is not None else WeightStore()
         self.reuse = reuse
         self.use_patch = True
+        self.use_col = True                   # conv_col_kernel / conv_c3_kernel (they walk hi + lo weights; the patch kernel does not)
         self.done = set()
         self.outputs = []
         self.gmacs = 0.0
@@ -756,15 +757,20 @@ class Compiler:
         return np.concatenate([m.reshape(-1), np.zeros(16 * npad * 32, np.float16)])
 
     @staticmethod
-    def col_weights(mat, kh, kw, cinp):
-        """[Np][Kp] (K order tap-major (dy, dx), channel-minor) -> [cinp/16][kw][kh][Np][16] fp16 for conv_col_kernel: one
-        ring stage = one filter column of one 16-channel chunk, contiguous; three zero stages follow the stream (the DMA
-        look-ahead of the last steps lands on readable zeros)."""
+    def col_weights(mat, kh, kw, cinp, hilo=False):
+        """[Np][Kp] (K order tap-major (dy, dx), channel-minor) -> [cinp/16][kw][kh][Np][16] fp16 for conv_col_kernel /
+        conv_c3_kernel: one ring stage = one filter column of one 16-channel chunk, contiguous; hilo: the stream of
+        lo = fp16(w - hi) follows the stream of hi = fp16(w) (second pass over the same chunks); three zero stages follow (the
+        DMA look-ahead of the last steps lands on readable zeros)."""
         npad = mat.shape[0]
         assert cinp % 16 == 0
         full = mat[:, :kh * kw * cinp].reshape(npad, kh, kw, cinp // 16, 16)
-        m = np.ascontiguousarray(full.transpose(3, 2, 1, 0, 4)).astype(np.float16)
-        return np.concatenate([m.reshape(-1), np.zeros(3 * kh * npad * 16 + 512, np.float16)])
+        m = np.ascontiguousarray(full.transpose(3, 2, 1, 0, 4))
+        hi = m.astype(np.float16)
+        parts = [hi.reshape(-1)]
+        if hilo:
+            parts.append((m - hi.astype(np.float64)).astype(np.float16).reshape(-1))
+        return np.concatenate(parts + [np.zeros(3 * kh * npad * 16 + 512, np.float16)])
 
     @staticmethod
     def head_up2_weights(mat, cinp):
@@ -878,10 +884,10 @@ class Compiler:
         rows16 = oh // 16 + ((0.35 + 0.65 * -(-rem16 // 2) / 8.0) if rem16 else 0.0)
         tile_eff_col = (oh * ow) / float(rows16 * 16 * -(-ow // 32) * 32)
         col = (COL and (sh, sw) == (1, 1) and kh in (5, 7, 9) and 3 <= kw <= 17 and inv.span % 16 == 0 and coutp <= 64
-               and inv.parts is None and self.use_patch and not self.hilo and kh * kw * cin >= PATCH_MIN_K
+               and inv.parts is None and self.use_col and kh * kw * cin >= PATCH_MIN_K
                and tile_eff_col >= COL_MIN_TILE_EFF)
         c3 = (COL3 and (sh, sw) == (1, 1) and (kh, kw, ph, pw) == (3, 3, 1, 1) and inv.span % 16 == 0 and inv.parts is None
-              and self.use_patch and not self.hilo and kh * kw * cin >= PATCH_MIN_K and coutp <= COL3_MAX_COUT
+              and self.use_col and kh * kw * cin >= PATCH_MIN_K and coutp <= COL3_MAX_COUT
               and (coutp <= 64 or inv.span >= COL3_WIDE_MIN_CIN)
               and c3_tile_eff(oh, ow) >= COL3_MIN_TILE_EFF and not self._dot1_candidate(ep["out_name"], cout))
         col = col or c3
@@ -938,8 +944,11 @@ class Compiler:
                                      lambda: self.head_up2_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], inv.span))
         elif col:
             Kp = kh * kw * inv.span
-            w_off = self.add_weights(("convc", wname, tuple(inv.segs), ep["out_name"]),
-                                     lambda: self.col_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh, kw, inv.span))
+            if self.hilo:
+                flags |= ir.F_HILO
+            w_off = self.add_weights(("convc", wname, tuple(inv.segs), ep["out_name"], self.hilo),
+                                     lambda: self.col_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], kh, kw, inv.span,
+                                                              self.hilo))
         elif patch:
             # (the tap padding depends on the kernel variant the map size selects: part of the cache key)
             w_off = self.add_weights(("convp", wname, tuple(inv.segs), ep["out_name"], ptaps),
@@ -1477,5 +1486,5 @@ def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_pro
     c = Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse)
     c.hilo = bool(hilo)
     if c.hilo:
-        c.use_patch = False          # the two-pass K walk lives in the implicit-GEMM kernels only
+        c.use_patch = False          # conv_patch_kernel has no two-pass K walk (the implicit-GEMM, stem and column kernels do)
     return c.compile()

@@ -77,7 +77,10 @@ __global__ __launch_bounds__(512, 4) void conv_c3_kernel(const ConvParams p) {
     const int ty = t % p.tiles_h;
     const long img = t / p.tiles_h;
     const int oy0 = ty * TH, ox0 = tx * TW, n0 = nt * BN;
-    const int nchunks = p.cinp >> 4;
+    const int nch1 = p.cinp >> 4;                        // 16-channel chunks of one pass over the input
+    // F_HILO: fp16 hi + lo weight pairs — the lo stream follows the hi stream, the patch chunks are walked a second time into
+    // the same accumulators (the implicit-GEMM kernels' two-pass K walk)
+    const int nchunks = (p.flags & F_HILO) ? 2 * nch1 : nch1;
 
     // ---- DMA source state: 32-bit element offsets from the tensor bases -----------------------------------------------
     int poff[PNPL];                                        // < 0: zero page
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(512, 4) void conv_c3_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < PNPL; ++j) {
             const int i = wave + 8 * j;
-            const half_t* src = (live && poff[j] >= 0) ? in_img + poff[j] + cc * 16 : p.zero;
+            const half_t* src = (live && poff[j] >= 0) ? in_img + poff[j] + (cc >= nch1 ? cc - nch1 : cc) * 16 : p.zero;
             half_t* dst = base + i * 512;
             if (i >= PINSTR) { src = p.zero; dst = dummy0; }
             glds16_asm(src, dst);
@@ -324,7 +327,7 @@ double conv_c3_plan(int OH, int OW, int* rw_out) {
 }
 bool conv_c3_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int flags) {
     return kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && (cinp & 15) == 0
-           && !(flags & (F_SRC2 | F_PIXSHUF | F_HILO | F_DOT1));
+           && !(flags & (F_SRC2 | F_PIXSHUF | F_DOT1));
 }
 
 int launch_conv_c3(const ConvParams& pin, int n_img, hipStream_t st) {

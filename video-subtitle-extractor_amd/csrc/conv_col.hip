@@ -74,7 +74,8 @@ __global__ __launch_bounds__(512, 2) void conv_col_kernel(const ConvParams p) {
     const int oy0 = ty * CTH, ox0 = tx * CTW, n0 = nt * BN;
 
     const int kw = p.kw;
-    const int nchunks = p.cinp >> 4;
+    const int nch1 = p.cinp >> 4;
+    const int nchunks = (p.flags & F_HILO) ? 2 * nch1 : nch1;      // F_HILO: second pass over the patch chunks with the lo weights
 
     // ---- DMA source state ---------------------------------------------------------------------------------------
     // patch: instruction i covers pixels 32i .. 32i+31; lane -> pixel 32i + (lane >> 1), LDS slot lane & 1
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv_col_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < PNPL; ++j) {
             const int i = wave + 8 * j;
-            const half_t* src = (live && pok[j]) ? p.in + poff[j] + cc * 16 : p.zero;
+            const half_t* src = (live && pok[j]) ? p.in + poff[j] + (cc >= nch1 ? cc - nch1 : cc) * 16 : p.zero;
             half_t* dst = base + i * 512;
             if (i >= PINSTR) { src = p.zero; dst = dummy0; }
             glds16_asm(src, dst);
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void conv_col_kernel(const ConvParams p) {
 int conv_col_bn(int Np) { return Np > 32 ? 64 : 32; }
 bool conv_col_ok(int kh, int kw, int sh, int sw, int cinp, int Np, int flags) {
     return sh == 1 && sw == 1 && (kh == 9 || kh == 7 || kh == 5) && kw >= 3 && CTW + kw - 1 <= CPW && (cinp & 15) == 0 && Np <= 64
-           && !(flags & (F_SRC2 | F_PIXSHUF | F_HILO));
+           && !(flags & (F_SRC2 | F_PIXSHUF));
 }
 
 int launch_conv_col(const ConvParams& pin, int n_img, hipStream_t st) {
