@@ -885,7 +885,7 @@ class Compiler:
         tile_eff_col = (oh * ow) / float(rows16 * 16 * -(-ow // 32) * 32)
         col = (COL and (sh, sw) == (1, 1) and kh in (5, 7, 9) and 3 <= kw <= 17 and inv.span % 16 == 0 and coutp <= 64
                and inv.parts is None and self.use_col and kh * kw * cin >= PATCH_MIN_K
-               and tile_eff_col >= COL_MIN_TILE_EFF)
+               and tile_eff_col >= COL_MIN_TILE_EFF and not self._dot1_candidate(ep["out_name"], cout))
         c3 = (COL3 and (sh, sw) == (1, 1) and (kh, kw, ph, pw) == (3, 3, 1, 1) and inv.span % 16 == 0 and inv.parts is None
               and self.use_col and kh * kw * cin >= PATCH_MIN_K and coutp <= COL3_MAX_COUT
               and (coutp <= 64 or inv.span >= COL3_WIDE_MIN_CIN)
@@ -923,7 +923,7 @@ class Compiler:
             while len(ins) < 2:
                 ins.append(None)
             ins.append(inv.parts[1])
-        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if ((patch_std and th == 16 and coutp <= 128) or col) else None
+        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch_std and th == 16 and coutp <= 128) else None
         if patch:
             # taps padded to whole kernel steps (2 taps in the LIGHT variant, else 4), channels to 32
             light = light_ok and dot is None

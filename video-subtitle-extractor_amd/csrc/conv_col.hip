@@ -57,7 +57,6 @@ __global__ __launch_bounds__(512, 2) void conv_col_kernel(const ConvParams p) {
     half_t* const ring0 = lds + 2 * PATCH_HALFS;
     half_t* const dummy0 = ring0 + CRING * WSTAGE_HALFS;             // 1 KiB landing zone of the surplus DMAs (zeros)
     float* const sbias = reinterpret_cast<float*>(dummy0 + 512);
-    float* const sdotw = sbias + BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -150,7 +149,6 @@ __global__ __launch_bounds__(512, 2) void conv_col_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     conv_stage_consts<true>(sbias, p.bias, p.zero, n0, BN, p.Np, wave, lane);                             // wave 0
-    if (p.flags & F_DOT1) conv_stage_consts<true>(sdotw, p.dotw, p.zero, n0, BN, p.Np, wave - 4, lane);   // wave 4
     issue_patch(0);
     issue_w(0);
     issue_w(1);
@@ -249,29 +247,7 @@ __global__ __launch_bounds__(512, 2) void conv_col_kernel(const ConvParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // drain the look-ahead / dummy DMAs before LDS is released
 
-    // ---- epilogue (as conv_patch_kernel, one wave = all couts of its 64 pixels) --------------------------------------
-    if (p.flags & F_DOT1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float part = 0.f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                float dbias[16], dw[16];
-                conv_epilogue_consts(sbias, j * 32, lane, dbias);
-                conv_epilogue_consts(sdotw, j * 32, lane, dw);
-                part += conv_epilogue_dot(p, acc[i][j], dbias, dw);
-            }
-            part += __shfl_xor(part, 32);
-            const int oy = oy0 + 2 * wave + i, ox = ox0 + fx;
-            if (fj == 0 && oy < p.OH && ox < p.OW) {
-                const long m = (img * p.OH + oy) * p.OW + ox;
-                const float z = vse_act(part + p.dotb, p.dotact, 0.f, 0.f);
-                if (p.dot_f32) reinterpret_cast<float*>(p.dot_out)[m * p.dot_ld] = z;
-                else reinterpret_cast<half_t*>(p.dot_out)[m * p.dot_ld] = (half_t)z;
-            }
-        }
-        return;
-    }
+    // ---- epilogue (one wave = all couts of its 64 pixels) -----------------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int oy = oy0 + 2 * wave + i, ox = ox0 + fx;
@@ -290,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void conv_col_kernel(const ConvParams p) {
 int conv_col_bn(int Np) { return Np > 32 ? 64 : 32; }
 bool conv_col_ok(int kh, int kw, int sh, int sw, int cinp, int Np, int flags) {
     return sh == 1 && sw == 1 && (kh == 9 || kh == 7 || kh == 5) && kw >= 3 && CTW + kw - 1 <= CPW && (cinp & 15) == 0 && Np <= 64
-           && !(flags & (F_SRC2 | F_PIXSHUF));
+           && !(flags & (F_SRC2 | F_PIXSHUF | F_DOT1));
 }
 
 int launch_conv_col(const ConvParams& pin, int n_img, hipStream_t st) {
@@ -298,7 +274,6 @@ int launch_conv_col(const ConvParams& pin, int n_img, hipStream_t st) {
     if (!conv_col_ok(p.kh, p.kw, p.sh, p.sw, p.cinp, p.Np, p.flags)) return VSE_E_UNSUPPORTED;
     const int bn = conv_col_bn(p.Np);
     p.ntn = (unsigned)((p.Np + bn - 1) / bn);
-    if ((p.flags & F_DOT1) && (p.ntn != 1 || (p.flags & F_RES) || !p.dotw || !p.dot_out)) return VSE_E_UNSUPPORTED;
     p.tiles_h = (p.OH + CTH - 1) / CTH;
     p.tiles_w = (p.OW + CTW - 1) / CTW;
     const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w * p.ntn;
