@@ -307,9 +307,37 @@ def _cubic_w(x):
     return np.stack([c0, c1, c2, c3], -1).astype(np.float32)
 
 
+def _bicubic_itab(wy, wx):
+    """cv2's fixed-point bicubic table entry (imgwarp.cpp initInterTab2D, as recalled): the 4 x 4 products of the float32 1-D
+    coefficients scaled by INTER_REMAP_COEF_SCALE = 32768 and rounded to short (cvRound: half to even); when they do not sum
+    to 32768 the difference goes to the largest (sum too small) or smallest (too large) of the entries [2..3] x [2..3] — the
+    loop bounds `ksize/2 .. ksize/2 + 2` of the original, scanned with its strict-less / else-strict-greater updates.
+    wy, wx: float32 [..., 4] -> int32 [..., 4, 4]."""
+    v = (wy[..., :, None] * wx[..., None, :]).astype(np.float32) * np.float32(32768.0)
+    it = np.clip(np.rint(v), -32768, 32767).astype(np.int32)
+    diff = it.reshape(it.shape[:-2] + (16,)).sum(-1) - 32768
+    flat = it.reshape(it.shape[:-2] + (16,))
+    mk = np.full(diff.shape, 10, np.int64)                # flat index of (2, 2)
+    Mk = mk.copy()
+    for pos in (10, 11, 14, 15):
+        val = flat[..., pos]
+        cur_m = np.take_along_axis(flat, mk[..., None], -1)[..., 0]
+        cur_M = np.take_along_axis(flat, Mk[..., None], -1)[..., 0]
+        less = val < cur_m
+        more = (~less) & (val > cur_M)
+        mk = np.where(less, pos, mk)
+        Mk = np.where(more, pos, Mk)
+    tgt = np.where(diff < 0, Mk, mk)
+    fix = np.where(diff != 0, diff, 0)
+    cur = np.take_along_axis(flat, tgt[..., None], -1)[..., 0]
+    new = ((cur - fix + 32768) % 65536) - 32768            # (short) cast of the corrected entry
+    np.put_along_axis(flat, tgt[..., None], new[..., None], -1)
+    return flat.reshape(it.shape)
+
+
 def get_rotate_crop_image(img, pts):
     """paddleocr get_rotate_crop_image: warpPerspective(INTER_CUBIC, BORDER_REPLICATE) with coordinates quantised
-    to 1/32 px, float bicubic (A=-0.75), then np.rot90 when tall."""
+    to 1/32 px and cv2's FIXED-POINT bicubic (A = -0.75; 15-bit weight table, (sum + 2^14) >> 15), then np.rot90 when tall."""
     cw, ch, rotate = crop_geometry(pts)
     sh, sw = img.shape[:2]
     try:
@@ -326,14 +354,15 @@ def get_rotate_crop_image(img, pts):
     sx, sy = (X >> 5) - 1, (Y >> 5) - 1
     wx = _cubic_w((X & 31).astype(np.float32) * np.float32(1 / 32))
     wy = _cubic_w((Y & 31).astype(np.float32) * np.float32(1 / 32))
-    acc = np.zeros((ch, cw, 3), np.float32)
-    I = img.astype(np.float32)
+    itab = _bicubic_itab(wy, wx)
+    acc = np.zeros((ch, cw, 3), np.int64)
+    I = img.astype(np.int64)
     for r in range(4):
         yy = np.clip(sy + r, 0, sh - 1)
         for q in range(4):
             xx = np.clip(sx + q, 0, sw - 1)
-            acc += (wy[..., r] * wx[..., q])[..., None] * I[yy, xx]
-    out = np.clip(np.rint(acc), 0, 255).astype(np.uint8)
+            acc += itab[..., r, q][..., None] * I[yy, xx]
+    out = np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
     if rotate:
         out = np.rot90(out)
     return np.ascontiguousarray(out)

@@ -447,7 +447,34 @@ __global__ __launch_bounds__(256) void crop_warp_kernel(const uint8_t* __restric
         float wx[4], wy[4];
         cubic_w((float)(X & 31) * (1.f / 32.f), wx);
         cubic_w((float)(Y & 31) * (1.f / 32.f), wy);
-        float acc[3] = {0.f, 0.f, 0.f};
+        // cv2's fixed-point table entry for this (fy, fx) (imgwarp.cpp initInterTab2D, restated in oracle/pipeline_ref.py
+        // _bicubic_itab): products scaled by 2^15 and rounded to short, the rounding residue moved into the largest / smallest
+        // of the entries [2..3] x [2..3]
+        int it[16], isum = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = (wy[r] * wx[q]) * 32768.f;
+                it[r * 4 + q] = min(max((int)rintf(v), -32768), 32767);
+                isum += it[r * 4 + q];
+            }
+        if (isum != 32768) {
+            const int diff = isum - 32768;
+            int mk = 10, Mk = 10;
+            const int order[4] = {10, 11, 14, 15};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pos = order[k];
+                if (it[pos] < it[mk]) mk = pos;
+                else if (it[pos] > it[Mk]) Mk = pos;
+            }
+            const int tgt = diff < 0 ? Mk : mk;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k == tgt) it[k] = (int)(short)(it[k] - diff);
+        }
+        int acc[3] = {0, 0, 0};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int yy = min(max(sy + r, 0), sh - 1);
@@ -455,17 +482,17 @@ __global__ __launch_bounds__(256) void crop_warp_kernel(const uint8_t* __restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int xx = min(max(sx + q, 0), sw - 1);
-                const float wgt = wy[r] * wx[q];
-                acc[0] += wgt * (float)row[xx * 3 + 0];
-                acc[1] += wgt * (float)row[xx * 3 + 1];
-                acc[2] += wgt * (float)row[xx * 3 + 2];
+                const int wgt = it[r * 4 + q];
+                acc[0] += wgt * (int)row[xx * 3 + 0];
+                acc[1] += wgt * (int)row[xx * 3 + 1];
+                acc[2] += wgt * (int)row[xx * 3 + 2];
             }
         }
         int ox = x, oy = y;
         if (c.rotate) { oy = c.cw - 1 - x; ox = y; }
         uint8_t* o = scratch + c.scratch_off + ((long)oy * c.iw + ox) * 3;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) o[k] = (uint8_t)min(max((int)rintf(acc[k]), 0), 255);
+        for (int k = 0; k < 3; ++k) o[k] = (uint8_t)min(max((acc[k] + (1 << 14)) >> 15, 0), 255);      // FixedPtCast<int, uchar, 15>
     }
 }
 
