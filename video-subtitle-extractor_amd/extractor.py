@@ -9,8 +9,8 @@ logic on the host.  Frames are independent, so the tasks of one video can also b
 and the per-frame records gathered on rank 0 (parallel.gather_records) before the sequential text logic runs.
 
 Pinned by tests/golden/extract.json (the reference's own producer / consumer / fps sampler executed on scripted inputs),
-frame_loop.json, srt.json and raw_filters.json.  Not rebuilt: VideoSubFinder frame selection (closed binary), reformat.execute
-(needs the absent `wordsegment` corpus), GUI progress plumbing.
+frame_loop.json, srt.json, raw_filters.json and text_cleanup.json.  Not rebuilt: VideoSubFinder frame selection (closed binary), GUI
+progress plumbing; reformat.execute is text_cleanup.py with the word segmenter as a parameter (its corpus is not installed here).
 
 Frame sources: anything with `frame_count`, `fps`, `read(frame_no) -> uint8 BGR [H,W,3] | None` (1-based, like
 cap.set(CAP_PROP_POS_FRAMES, frame_no - 1); cap.read()) and `frames()` (decode order).  `ArraySource` wraps decoded frames;
@@ -21,7 +21,7 @@ from types import SimpleNamespace
 
 import numpy as np
 
-from . import frame_select, parallel, raw_filters, shim, srt
+from . import frame_select, parallel, raw_filters, shim, srt, text_cleanup
 
 # backend/tools/constant.py:5-13 — default subtitle position used by the fps sampler's half-frame crop
 LOWER_PART, UPPER_PART, UNKNOWN = "LOWER_PART", "UPPER_PART", "UNKNOWN"
@@ -156,13 +156,15 @@ class SubtitleExtractor:
 
     def __init__(self, source, ocr, detect_batch=None, sub_area=None, mode="fast", language="ch", extract_frequency=3,
                  default_subtitle_area=None, drop_score=0.75, deviation_rate=0.0, threshold=80, batch=64,
-                 watermark_decide=None, scene_text_decide=lambda band: True, shard=None, gather_device=None):
+                 watermark_decide=None, scene_text_decide=lambda band: True, shard=None, gather_device=None,
+                 word_segmentation=False, segment=None):
         self.source, self.ocr, self.detect_batch = source, ocr, detect_batch
         self.sub_area, self.mode, self.language = sub_area, mode, language
         self.extract_frequency, self.default_subtitle_area = extract_frequency, default_subtitle_area
         self.drop_score, self.deviation_rate, self.threshold, self.batch = drop_score, deviation_rate, threshold, batch
         self.watermark_decide, self.scene_text_decide = watermark_decide, scene_text_decide
         self.shard, self.gather_device = shard, gather_device
+        self.word_segmentation, self.segment = word_segmentation, segment      # config.wordSegmentation (main.py:181-182)
         self.raw_lines = None
         self.short_lines = None
 
@@ -189,6 +191,8 @@ class SubtitleExtractor:
             lines = raw_filters.filter_scene_text(lines, self.scene_text_decide) if lines else lines
         text, self.short_lines, self.raw_lines = srt.generate_subtitle_file(lines, self.source.fps, self.threshold,
                                                                               getattr(self.source, "pos_msec", None))
+        if self.word_segmentation:
+            text, _ = text_cleanup.cleanup_srt(text, self.language, self.segment or text_cleanup.default_segmenter())
         return text
 
     @staticmethod
