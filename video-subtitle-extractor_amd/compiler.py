@@ -889,6 +889,7 @@ class Compiler:
         c3 = (COL3 and (sh, sw) == (1, 1) and (kh, kw, ph, pw) == (3, 3, 1, 1) and inv.span % 16 == 0 and inv.parts is None
               and self.use_col and kh * kw * cin >= PATCH_MIN_K and coutp <= COL3_MAX_COUT
               and (coutp <= 64 or inv.span >= COL3_WIDE_MIN_CIN)
+              and inv.src_h * inv.src_w * inv.buf.ld < 2_000_000_000      # 32-bit in-image offsets (launch_conv_c3 checks the same)
               and c3_tile_eff(oh, ow) >= COL3_MIN_TILE_EFF and not self._dot1_candidate(ep["out_name"], cout))
         col = col or c3
         if col:
