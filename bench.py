@@ -42,7 +42,9 @@ def parse():
     ap.add_argument("--boxes", default="gt", choices=["gt", "db"])
     ap.add_argument("--bucket", type=int, default=256, help="rec width bucket (px)")
     ap.add_argument("--batch-round", type=int, default=4)
-    ap.add_argument("--min-rec-group", type=int, default=0, help="rec width buckets with fewer crops absorb the next narrower bucket")
+    ap.add_argument("--min-rec-group", type=int, default=8,
+                    help="rec width buckets with fewer crops absorb the next narrower bucket (0 = off); 8: the 4-crop 1280-px bucket of "
+                         "the default workload joins the 1024-px one - 6 %% less GPU time in conv kernels at the same frames/s")
     ap.add_argument("--rec-streams", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -242,7 +244,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.batch}x{args.height}p frames/GPU/step, precise mode: {det_id} @544x960 + "
-                                   f"{rec_id}, {n_lines} text lines/batch, rec boxes={args.boxes}, rec batching=bucketed({args.bucket}px)",
+                                   f"{rec_id}, {n_lines} text lines/batch, rec boxes={args.boxes}, rec batching=bucketed({args.bucket}px, min group {args.min_rec_group})",
                        "streaming": "sequential batches" if args.no_overlap else
                                     "detector of batch k+1 overlapped with post-processing + recognition of batch k (2 HIP streams); "
                                     "all K batches start and finish inside the timed region",
