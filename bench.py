@@ -278,6 +278,8 @@ def variant_kernel_name(code):
         return "conv_stem_kernel"
     if code >= 400000:
         return "conv_head_up2_kernel"
+    if 1000 <= code < 300000 and code % 1000 in (32, 64, 128) and (code // 1000) % 100 in (8, 16):      # before the gemm range: mode 2 = 2xxxxx
+        return f"conv_patch_kernel<{(code // 1000) % 100}, {code % 1000}, {code // 100000}>"
     if code >= 200000:
         cfg = {0: "128, 128, 2, 2, 32, 3", 1: "256, 64, 4, 1, 32, 3", 2: "256, 32, 4, 1, 32, 3", 6: "256, 128, 4, 2, 32, 3",
                16: "256, 256, 4, 4, 32, 3", 17: "256, 192, 8, 2, 32, 3", 18: "256, 256, 4, 4, 64, 2",
