@@ -227,3 +227,39 @@ def test_column_kernels_with_upsampled_input_and_residual(ctx, cin, cout, k, h, 
     got = np.transpose(run_hip(ctx, desc, wts, x)[0], (0, 3, 1, 2))
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cin,cout,k,h,w,n", [(256, 64, (9, 9), 136, 240, 4), (128, 128, (3, 3), 136, 240, 4), (160, 160, (3, 3), 68, 120, 8),
+                                              (32, 32, (7, 7), 136, 240, 4)])
+def test_column_kernels_race_screen(ctx, cin, cout, k, h, w, n):
+    """The column kernels order their LDS-DMA ring with counted vmcnt waits + one barrier per step; a miscounted wait shows up as
+    a rare stale fragment that a tolerance test can miss.  Screen: the same launch repeated under a competing stream (timing
+    varies from run to run) must give bit-identical outputs every time, at full detector map sizes (many rounds of blocks)."""
+    import torch
+    from vse_amd import engine
+    rng = np.random.default_rng(7)
+    desc = {"model": "unit", "ops": [
+        {"type": "feed", "in": {"X": ["feed"]}, "out": {"Out": ["x"]}, "attrs": {"col": 0}},
+        {"type": "conv2d", "in": {"Input": ["x"], "Filter": ["w0"]}, "out": {"Output": ["t0"]},
+         "attrs": {"strides": [1, 1], "paddings": [0, 0], "groups": 1}},
+        {"type": "conv2d", "in": {"Input": ["t0"], "Filter": ["w1"]}, "out": {"Output": ["t1"]},
+         "attrs": {"strides": [1, 1], "paddings": [k[0] // 2, k[1] // 2], "groups": 1}},
+        {"type": "relu", "in": {"X": ["t1"]}, "out": {"Out": ["t2"]}, "attrs": {}},
+        {"type": "fetch", "in": {"X": ["t2"]}, "out": {"Out": ["fetch"]}, "attrs": {"col": 0}}],
+        "params": {"w0": {"dims": [cin, 3, 1, 1], "dtype": 5}, "w1": {"dims": [cout, cin, k[0], k[1]], "dtype": 5}},
+        "var_shapes": {"t0": [-1, cin, -1, -1], "t1": [-1, cout, -1, -1]}}
+    wts = {"w0": rng.standard_normal((cin, 3, 1, 1)).astype(np.float32),
+           "w1": (rng.standard_normal((cout, cin, k[0], k[1])) / np.sqrt(cin * k[0] * k[1])).astype(np.float32)}
+    net = engine.Net(ctx, desc, wts)
+    x = (torch.rand((n, h, w, 8), device="cuda") * 2 - 1).half()
+    x[..., 3:] = 0
+    first = net.run(x)[0].clone()
+    side = torch.cuda.Stream()
+    junk = torch.rand((4096, 4096), device="cuda")
+    for rep in range(12):
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 3):
+                junk = junk @ junk * 1e-4           # competing load on another stream
+        out = net.run(x)[0]
+        assert torch.equal(out, first), rep
+    torch.cuda.synchronize()
