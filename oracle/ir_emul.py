@@ -151,7 +151,10 @@ class Emulator:
             oc2 = int(r["out2"]["c"])
             self.write(r["out2"], z if oc2 == 1 else F.pad(z, (0, oc2 - 1)))
             return
-        if int(r["flags"]) & ir.F_COL:
+        if int(r["flags"]) & ir.F_PW:
+            assert (kh, kw) == (1, 1) and Kp == cinp
+            wmat = self.wread(int(r["w_off"]), Np * Kp, np.float16).astype(np.float32).reshape(Np, Kp)
+        elif int(r["flags"]) & ir.F_COL:
             assert cinp % 16 == 0 and Kp == kh * kw * cinp
             npass = 2 if int(r["flags"]) & ir.F_HILO else 1          # w = hi + lo (the lo stream follows the hi stream)
             wt = self.wread(int(r["w_off"]), npass * Kp * Np + 3 * kh * Np * 16, np.float16).astype(np.float32)

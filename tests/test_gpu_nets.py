@@ -102,6 +102,11 @@ CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (48, 64, (3, 3), (1, 1), (1, 1), 19, 70, 2),       # 3 chunks; ragged in both directions
     (256, 96, (3, 3), (1, 1), (1, 1), 34, 60, 1),      # 16 chunks, cout tail (96 = 64 + 32)
     (16, 16, (3, 3), (1, 1), (1, 1), 64, 64, 1),       # K = 144 < PATCH_MIN_K: stays on the implicit GEMM
+    # conv_pw_kernel (1x1, <= 64 channels in and out, fragments straight from global memory); (16, 40, 1x1) above runs on it too
+    (32, 64, (1, 1), (1, 1), (0, 0), 17, 31, 3),       # M tail inside the last block (1581 pixels)
+    (64, 32, (1, 1), (1, 1), (0, 0), 16, 16, 1),       # exactly one block, one cout tile
+    (48, 24, (1, 1), (1, 1), (0, 0), 9, 50, 2),        # three K slices, cout tail (24 of 32)
+    (64, 64, (1, 1), (1, 1), (0, 0), 33, 40, 2),
     # scalar-addressed implicit GEMM (conv_gemm_kernel: cin % 32 == 0, <= 31 taps); VSE_CONV_GEMM=0 sends the same
     # cases through conv_mfma_kernel
     (64, 128, (3, 3), (1, 1), (1, 1), 20, 36, 2),      # masked, BN=128, image seam inside a tile

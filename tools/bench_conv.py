@@ -39,6 +39,10 @@ LAYERS = {  # name: cin, cout, k, stride, pad, h, w, n
     "det_9x9_64_64_h68": (64, 64, (9, 9), (1, 1), (4, 4), 68, 120, 64),
     "det_3x3_256_64_h68": (256, 64, (3, 3), (1, 1), (1, 1), 68, 120, 64),
     "det_3x3_224_224": (224, 224, (3, 3), (1, 1), (1, 1), 17, 30, 64),
+    "det_3x3_32_32": (32, 32, (3, 3), (1, 1), (1, 1), 136, 240, 64),
+    "det_3x3_32_32_h68": (32, 32, (3, 3), (1, 1), (1, 1), 68, 120, 64),
+    "det_1x1_32_64": (32, 64, (1, 1), (1, 1), (0, 0), 136, 240, 64),
+    "det_1x1_64_32": (64, 32, (1, 1), (1, 1), (0, 0), 136, 240, 64),
     "rec_3x3_128_128_w768": (128, 128, (3, 3), (1, 1), (1, 1), 12, 384, 28),
     "rec_3x3_160_160_w768": (160, 160, (3, 3), (1, 1), (1, 1), 12, 192, 28),
     "rec_3x3_192_192_w768": (192, 192, (3, 3), (1, 1), (1, 1), 6, 192, 28),
@@ -83,7 +87,7 @@ def main():
         from vse_amd import compiler
         nets = {}
         # "p": conv_patch_kernel / conv_col_kernel allowed; "c": + conv_c3_kernel for any couts; numeric cfgs: implicit GEMM only
-        for key, mink in (("g", 1 << 30), ("p", 500), ("c", 500)):
+        for key, mink in (("g", 1 << 30), ("p", 500), ("c", 100)):
             compiler.PATCH_MIN_K = mink
             nets[key] = engine.Net(ctx, desc, wts, want_probs=False)
         x = (torch.rand((n, h, w, 8), device="cuda") * 2 - 1).half()
@@ -95,10 +99,11 @@ def main():
         ref = None
         for c in cfgs:
             net = nets[c if c in ("p", "c") else "g"]
-            compiler.PATCH_MIN_K = 500 if c in ("p", "c") else 1 << 30      # plans are compiled lazily on the first run
+            compiler.PATCH_MIN_K = (100 if c == "c" else 500) if c in ("p", "c") else 1 << 30      # plans are compiled lazily on the first run
             compiler.PATCH_MAX_COUT = 256 if c == "p" else 64       # "p": also try the patch kernel on wide layers (two+ cout tiles)
             compiler.COL3 = c == "c"
             compiler.COL3_MAX_COUT, compiler.COL3_MIN_TILE_EFF, compiler.COL3_WIDE_MIN_CIN = 4096, 0.0, 0
+            compiler.COL3_MIN_K = 100
             os.environ["VSE_GEMM_CFG"] = "" if c in ("p", "d") else c      # "d": the launcher's own choice
             out = net.run(x)
             torch.cuda.synchronize()

@@ -148,6 +148,8 @@ COL_MIN_TILE_EFF = float(os.environ.get("VSE_COL_MINEFF", "0.75"))
 # conv_c3_kernel (3x3, two blocks per CU): VSE_COL3=0 off; cout / tile-efficiency limits from per-layer A/B runs
 COL3 = os.environ.get("VSE_COL3", "1") != "0"
 COL3_MAX_COUT = int(os.environ.get("VSE_COL3_MAXCOUT", "192"))     # per-layer A/B (tools/bench_conv.py --cfgs d,p,c): 224-cout layers tie or lose
+PW = os.environ.get("VSE_PW", "1") != "0"             # conv_pw_kernel for 1x1 convs over <= 64 channels in and out
+COL3_MIN_K = int(os.environ.get("VSE_COL3_MINK", "250"))   # 3x3 32->32 @136x240 (K = 288): 0.180 ms on the implicit GEMM, 0.115 ms here
 COL3_WIDE_MIN_CIN = 128    # layers with more than 64 couts (two+ cout tiles refetch the patch) only from 128 input channels on
 COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
 
@@ -887,7 +889,7 @@ class Compiler:
                and inv.parts is None and self.use_col and kh * kw * cin >= PATCH_MIN_K
                and tile_eff_col >= COL_MIN_TILE_EFF and not self._dot1_candidate(ep["out_name"], cout))
         c3 = (COL3 and (sh, sw) == (1, 1) and (kh, kw, ph, pw) == (3, 3, 1, 1) and inv.span % 16 == 0 and inv.parts is None
-              and self.use_col and kh * kw * cin >= PATCH_MIN_K and coutp <= COL3_MAX_COUT
+              and self.use_col and kh * kw * cin >= min(PATCH_MIN_K, COL3_MIN_K) and coutp <= COL3_MAX_COUT
               and (coutp <= 64 or inv.span >= COL3_WIDE_MIN_CIN)
               and inv.src_h * inv.src_w * inv.buf.ld < 2_000_000_000      # 32-bit in-image offsets (launch_conv_c3 checks the same)
               and c3_tile_eff(oh, ow) >= COL3_MIN_TILE_EFF and not self._dot1_candidate(ep["out_name"], cout))
@@ -943,6 +945,12 @@ class Compiler:
             Kp = 2 * 4 * 4 * 32 + 32
             w_off = self.add_weights(("convh", wname, tuple(inv.segs), ep["out_name"]),
                                      lambda: self.head_up2_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], inv.span))
+        elif (PW and (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and inv.parts is None and inv_main.up == 0 and dot is None
+              and inv.span % 16 == 0 and inv.span <= 64 and coutp <= 64 and not self.hilo and flags in (0, ir.F_RES)):
+            flags |= ir.F_PW
+            Kp = inv.span
+            w_off = self.add_weights(("convpw", wname, tuple(inv.segs), ep["out_name"]),
+                                     lambda: self.pack_conv_weights(w, ep["scale"], inv)[0][:, :inv.span].astype(np.float16).reshape(-1))
         elif col:
             Kp = kh * kw * inv.span
             if self.hilo:

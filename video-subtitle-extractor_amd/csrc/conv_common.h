@@ -260,6 +260,9 @@ int launch_conv_col(const ConvParams& p, int n_img, hipStream_t st);
 int launch_conv_c3(const ConvParams& p, int n_img, hipStream_t st);
 double conv_c3_plan(int OH, int OW, int* rw_out);
 bool conv_c3_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int flags);
+// pointwise conv over <= 64 input channels and <= 64 couts, no LDS staging (conv_pw.hip, F_PW)
+int launch_conv_pw(const ConvParams& p, hipStream_t st);
+bool conv_pw_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int Np, int inshift, int flags);
 int conv_col_bn(int Np);
 bool conv_col_ok(int kh, int kw, int sh, int sw, int cinp, int Np, int flags);
 // DB head evaluated on the low-resolution grid (conv_head.hip, F_UP2HEAD)

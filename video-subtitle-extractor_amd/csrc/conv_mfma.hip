@@ -287,6 +287,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     if (!a.zero) return VSE_E_INVAL;
     if (a.flags & F_UP2HEAD) return launch_conv_head_up2(p, a.in.n, st);
     if (a.flags & F_STEM) return launch_conv_stem(p, a.in.n, st);
+    if (a.flags & F_PW) return launch_conv_pw(p, st);
     if (a.flags & F_COL) return (p.kh == 3 && p.kw == 3) ? launch_conv_c3(p, a.in.n, st) : launch_conv_col(p, a.in.n, st);
     if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
     if (a.Kp % 64) return VSE_E_INVAL;

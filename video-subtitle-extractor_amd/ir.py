@@ -70,6 +70,7 @@ F_STEM = 512        # 3x3 conv over an image-like input (<= 4 real channels): co
 F_GATE = 256        # OP_DWCONV: in1 = SE gate [N,1,1,C]; the input is multiplied by it (rounded to fp16) on load — the
                     # separate OP_SCALE pass of an SE block whose only consumer is this depthwise conv disappears
 F_WK32 = 128        # weights tiled [Kp/32][Np][32] (one wave DMA = 1 KiB contiguous) for conv_gemm_kernel; else [Kp/64][Np][64]
+F_PW = 4096         # pointwise conv over <= 64 input channels / <= 64 couts (conv_pw.hip): weights plain [Np][cinp] fp16
 F_COL = 2048        # column-per-step LDS-patch kernel (conv_col.hip): weights packed [cinp/16][kw][kh][Np][16] + 3 zero stages
 F_UP2HEAD = 64      # F_SRC2 | F_DOT1 3x3 conv over [1-channel full-res map, x2-upsampled 64-channel map] evaluated on the LOW-RES
                     # grid: weights packed [chunk][parity][2x2 tap][Np][32] + [Np][32] for the 1-channel source (conv_head.hip)
