@@ -271,7 +271,7 @@ def variant_kernel_name(code):
     code = int(code)
     tiles = {128: "128, 128, 2, 2", 64: "256, 64, 4, 1", 32: "256, 32, 4, 1"}
     if code >= 800000:
-        return f"conv_pw_kernel<{code % 10}, {(code - 800000) // 10}>"
+        return f"conv_pw_kernel<{code - 800000}>"
     if code >= 700000:
         return f"conv_c3_kernel<{code - 700000}, {8 // (code - 700000)}>"
     if code >= 600000:

@@ -148,7 +148,8 @@ COL_MIN_TILE_EFF = float(os.environ.get("VSE_COL_MINEFF", "0.75"))
 # conv_c3_kernel (3x3, two blocks per CU): VSE_COL3=0 off; cout / tile-efficiency limits from per-layer A/B runs
 COL3 = os.environ.get("VSE_COL3", "1") != "0"
 COL3_MAX_COUT = int(os.environ.get("VSE_COL3_MAXCOUT", "192"))     # per-layer A/B (tools/bench_conv.py --cfgs d,p,c): 224-cout layers tie or lose
-PW = os.environ.get("VSE_PW", "1") != "0"             # conv_pw_kernel for 1x1 convs over <= 64 channels in and out
+PW = os.environ.get("VSE_PW", "1") != "0"             # conv_pw_kernel for 1x1 convs (and 2x2 s2 transposed convs) over <= 64 input channels
+PW_MAX_COUT = int(os.environ.get("VSE_PW_MAXCOUT", "64"))
 COL3_MIN_K = int(os.environ.get("VSE_COL3_MINK", "250"))   # 3x3 32->32 @136x240 (K = 288): 0.180 ms on the implicit GEMM, 0.115 ms here
 COL3_WIDE_MIN_CIN = 128    # layers with more than 64 couts (two+ cout tiles refetch the patch) only from 128 input channels on
 COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
@@ -843,10 +844,17 @@ class Compiler:
                 bias[q * coutp:q * coutp + cout] = ep["shift"]
             oh, ow = inv.h * 2, inv.w * 2
             out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
-            w_off = self.add_weights(("convT", wname, tuple(inv.segs), ep["out_name"], self.hilo),
-                                     self.tile_weights(mat, hilo=self.hilo))
+            tflags = ir.F_PIXSHUF | (ir.F_HILO if self.hilo else 0)
+            if PW and inv.span % 16 == 0 and inv.span <= 64 and 4 * coutp <= 256 and inv.up == 0 and not self.hilo:
+                # few input channels: conv_pw_kernel streams the pixels straight from global memory (pixel-shuffle store as ever)
+                tflags |= ir.F_PW
+                Kp = inv.span
+                w_off = self.add_weights(("convTpw", wname, tuple(inv.segs), ep["out_name"]), w2.astype(np.float16).reshape(-1))
+            else:
+                w_off = self.add_weights(("convT", wname, tuple(inv.segs), ep["out_name"], self.hilo),
+                                         self.tile_weights(mat, hilo=self.hilo))
             b_off = self.add_weights(("convTb", wname, ep["out_name"]), bias)
-            self.emit(ir.OP_CONV, ep["out_name"], [inv], out, flags=ir.F_PIXSHUF | (ir.F_HILO if self.hilo else 0),
+            self.emit(ir.OP_CONV, ep["out_name"], [inv], out, flags=tflags,
                       p={ir.P_KH: 1, ir.P_KW: 1, ir.P_SH: 1, ir.P_SW: 1, ir.P_PH: 0, ir.P_PW: 0,
                          ir.P_ACT: ep["act"], ir.P_ACT2: 0, ir.P_COUT: 4 * coutp, ir.P_KTOT: Kp,
                          ir.P_INSHIFT: 0, ir.P_RESSHIFT: 0, ir.P_CINP: inv.span},
@@ -946,7 +954,7 @@ class Compiler:
             w_off = self.add_weights(("convh", wname, tuple(inv.segs), ep["out_name"]),
                                      lambda: self.head_up2_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], inv.span))
         elif (PW and (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and inv.parts is None and inv_main.up == 0 and dot is None
-              and inv.span % 16 == 0 and inv.span <= 64 and coutp <= 64 and not self.hilo and flags in (0, ir.F_RES)):
+              and inv.span % 16 == 0 and inv.span <= 64 and coutp <= PW_MAX_COUT and not self.hilo and flags in (0, ir.F_RES)):
             flags |= ir.F_PW
             Kp = inv.span
             w_off = self.add_weights(("convpw", wname, tuple(inv.segs), ep["out_name"]),
