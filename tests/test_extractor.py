@@ -145,3 +145,74 @@ def test_sharded_ocr_tasks_world2_gloo():
     c = G["ocr_cases"][0]
     assert got[0][1] == got[1][1] == c["raw"]
     assert got[0][2] == [1, 2, 3, 4, 5] and got[1][2] == [6, 7, 8, 9, 10]          # disjoint halves of the work
+
+
+def test_prefetch_keeps_order_and_propagates_errors():
+    """staging.prefetch with a stand-in uploader: batches arrive in order, staged by the producer thread; a failing source
+    raises in the consumer; an abandoned iteration does not leave the producer blocked."""
+    import threading
+    from vse_amd import staging
+
+    class FakeUploader:
+        def __init__(self):
+            self.threads = set()
+
+        def bind_thread(self):
+            self.threads.add(threading.get_ident())
+
+        def stage(self, frames):
+            return ("staged", [int(f.sum()) for f in frames])
+
+    def batches(n, fail_at=None):
+        for b in range(n):
+            if b == fail_at:
+                raise IOError("decoder died")
+            yield [(10 * b + i, np.full((2, 2, 3), b + i, np.uint8)) for i in range(3)]
+
+    up = FakeUploader()
+    got = list(staging.prefetch(batches(5), up))
+    assert [[k for k, _ in items] for items, _ in got] == [[10 * b + i for i in range(3)] for b in range(5)]
+    assert got[3][1] == ("staged", [12 * (3 + i) for i in range(3)])
+    assert up.threads and threading.get_ident() not in up.threads
+    with pytest.raises(IOError):
+        list(staging.prefetch(batches(5, fail_at=2), up))
+    it = staging.prefetch(batches(50), up, ahead=1)
+    next(it)
+    it.close()                                  # consumer gives up: the producer must terminate
+    assert threading.active_count() < 8
+
+
+def test_run_ocr_tasks_with_uploader_equals_host_stacking():
+    """The staged route (producer thread + uploader) gives the same lines as the host-stacking route."""
+    from vse_amd import extractor
+
+    class Staged:
+        def __init__(self, frames):
+            self.frames = frames
+
+        def tensor(self):
+            return np.stack(self.frames)
+
+    class FakeUploader:
+        def bind_thread(self):
+            pass
+
+        def stage(self, frames):
+            return Staged([np.array(f) for f in frames])
+
+    class Ocr:
+        def predict(self, frame):
+            v = int(frame[0, 0, 0])
+            return [[(v, v), (v + 30, v), (v + 30, v + 10), (v, v + 10)]], [(f"t{v}", 0.9)]
+
+    class OcrBatched(Ocr):
+        def predict_batch(self, frames):
+            assert isinstance(frames, np.ndarray) and frames.ndim == 4        # what the uploader staged, not a list
+            return [self.predict(f) for f in frames]
+
+    frames = [np.full((8 + 2 * (i // 5), 40, 3), i, np.uint8) for i in range(13)]
+    src = extractor.ArraySource(frames, 10.0)
+    tasks = extractor.fps_tasks(13, 10.0, 10)
+    a = extractor.run_ocr_tasks(src, tasks, Ocr(), batch=4)
+    b = extractor.run_ocr_tasks(src, tasks, OcrBatched(), batch=4, uploader=FakeUploader())
+    assert a == b and len(a) == 13

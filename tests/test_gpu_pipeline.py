@@ -289,7 +289,7 @@ def test_extractor_on_a_clip_engine_vs_oracle(ctx):
         equal the engine run frame by frame (the reference's order of work) byte for byte — raw.txt and SRT, in the fps mode
         and in the accurate mode (detector-driven selection, cached OCR results)."""
     import torch
-    from vse_amd import extractor, pipeline, shim, synth
+    from vse_amd import extractor, pipeline, shim, staging, synth
     det = net_ref.get_weights("V3_ch_det_fast")
     rec = net_ref.get_weights("V4_en_rec_fast")
     cs = P.en_charset()
@@ -312,7 +312,7 @@ def test_extractor_on_a_clip_engine_vs_oracle(ctx):
             return P.ocr_predict_glue(*P.text_system(frame, det_fn, rec_fn, cs))
 
     def engine_detect(frames):
-        dev = torch.from_numpy(np.stack(frames)).cuda()
+        dev = frames if torch.is_tensor(frames) else torch.from_numpy(np.stack(frames)).cuda()
         return [np.asarray(b, np.float32).reshape(-1, 4, 2) for b in pipe.detect(dev)]
 
     h, wd = 360, 640
@@ -331,5 +331,9 @@ def test_extractor_on_a_clip_engine_vs_oracle(ctx):
         a, b = one.run(), many.run()
         assert many.raw_lines == one.raw_lines and len(one.raw_lines) >= 3
         assert a == b and a.count(" --> ") >= 1
+        # the same through pinned staging + producer thread (device tensors reach detect_batch / predict_batch)
+        staged = extractor.SubtitleExtractor(src, EngineOcrBatched(), detect_batch=engine_detect,
+                                             uploader=staging.Uploader(ctx.tdev), **kw)
+        assert staged.run() == a and staged.raw_lines == one.raw_lines
         if kw is fps_kw:
             assert geo(many.raw_lines) == geo(ora.raw_lines)

@@ -21,7 +21,7 @@ from types import SimpleNamespace
 
 import numpy as np
 
-from . import frame_select, parallel, raw_filters, shim, srt, text_cleanup
+from . import frame_select, parallel, raw_filters, shim, srt, staging, text_cleanup
 
 # backend/tools/constant.py:5-13 — default subtitle position used by the fps sampler's half-frame crop
 LOWER_PART, UPPER_PART, UNKNOWN = "LOWER_PART", "UPPER_PART", "UNKNOWN"
@@ -81,43 +81,50 @@ def frame_lines(frame_no, dt_box, rec_res, sub_area, rec_char_type, drop_score, 
 
 
 def run_ocr_tasks(source, tasks, ocr, sub_area=None, rec_char_type="ch", drop_score=0.75, deviation_rate=0.0, batch=64,
-                  shard=None, gather_device=None):
+                  shard=None, gather_device=None, uploader=None):
     """Producer + consumer of subtitle_ocr.py over a task list.  `ocr` has predict(frame) and optionally
-    predict_batch(list of equal-shaped frames).  Tasks whose frame cannot be read are skipped like the reference's failed
+    predict_batch(batch of equal-shaped frames).  Tasks whose frame cannot be read are skipped like the reference's failed
     cap.read(); tasks that carry a cached (dt_box, rec_res) — accurate mode — are not recognised again.
+    uploader (staging.Uploader): batches are assembled in pinned memory and uploaded by a producer thread while the previous
+    batch is recognised — the reference's producer / consumer pair at batch granularity; predict_batch then receives a
+    device uint8 tensor [n,H,W,3].  Without one the frames are stacked on the host.
     shard=(rank, world): this rank recognises a contiguous slice of the tasks; every rank gets the records of all tasks back
     (one variable-length gather) and therefore returns the same lines.  -> list of raw.txt lines in task order."""
     tasks = [t for t in tasks if t[1] != -1]
     lo, hi = (0, len(tasks)) if shard is None else parallel.shard_range(len(tasks), *shard)
     results = {}                        # task index -> (dt_box, rec_res)
-    pend = []                           # (task index, frame) waiting for a batch of their shape
+    batched = hasattr(ocr, "predict_batch")
 
-    def flush(items):
-        if not items:
-            return
-        frames = [f for _, f in items]
-        if hasattr(ocr, "predict_batch") and len(frames) > 1:
-            out = ocr.predict_batch(_stack(frames))
-        else:
-            out = [ocr.predict(f) for f in frames]
-        for (k, _), r in zip(items, out):
-            results[k] = r
+    def batches():
+        """lists of (task index, frame): consecutive readable tasks of one frame shape, at most `batch` of them"""
+        pend = []
+        for k in range(lo, hi):
+            _total, no, dt_box, rec_res, _ms, default_area = tasks[k]
+            frame = source.read(no)
+            if frame is None:
+                continue
+            if dt_box is not None and rec_res is not None:
+                results[k] = (dt_box, rec_res)
+                continue
+            if default_area is not None:
+                frame = frame_preprocess(default_area, frame)
+            if pend and (pend[0][1].shape != frame.shape or len(pend) >= batch):
+                yield pend
+                pend = []
+            pend.append((k, frame))
+        if pend:
+            yield pend
 
-    for k in range(lo, hi):
-        _total, no, dt_box, rec_res, _ms, default_area = tasks[k]
-        frame = source.read(no)
-        if frame is None:
-            continue
-        if dt_box is not None and rec_res is not None:
-            results[k] = (dt_box, rec_res)
-            continue
-        if default_area is not None:
-            frame = frame_preprocess(default_area, frame)
-        if pend and (pend[0][1].shape != frame.shape or len(pend) >= batch):
-            flush(pend)
-            pend = []
-        pend.append((k, frame))
-    flush(pend)
+    if batched and uploader is not None:
+        for items, staged in staging.prefetch(batches(), uploader):
+            for (k, _), r in zip(items, ocr.predict_batch(staged.tensor())):
+                results[k] = r
+    else:
+        for items in batches():
+            frames = [f for _, f in items]
+            out = ocr.predict_batch(_stack(frames)) if batched and len(frames) > 1 else [ocr.predict(f) for f in frames]
+            for (k, _), r in zip(items, out):
+                results[k] = r
     if shard is not None and shard[1] > 1:
         recs = [(k, _boxes_array(results[k][0]), list(results[k][1])) for k in sorted(results)]
         results = {k: (_boxes_list(b), r) for k, b, r in parallel.gather_records(recs, device=gather_device, to_all=True)}
@@ -157,34 +164,43 @@ class SubtitleExtractor:
     def __init__(self, source, ocr, detect_batch=None, sub_area=None, mode="fast", language="ch", extract_frequency=3,
                  default_subtitle_area=None, drop_score=0.75, deviation_rate=0.0, threshold=80, batch=64,
                  watermark_decide=None, scene_text_decide=lambda band: True, shard=None, gather_device=None,
-                 word_segmentation=False, segment=None):
+                 word_segmentation=False, segment=None, uploader=None):
         self.source, self.ocr, self.detect_batch = source, ocr, detect_batch
         self.sub_area, self.mode, self.language = sub_area, mode, language
         self.extract_frequency, self.default_subtitle_area = extract_frequency, default_subtitle_area
         self.drop_score, self.deviation_rate, self.threshold, self.batch = drop_score, deviation_rate, threshold, batch
         self.watermark_decide, self.scene_text_decide = watermark_decide, scene_text_decide
         self.shard, self.gather_device = shard, gather_device
+        # staging.Uploader (or "auto": one on the shim's device when there is a GPU): detect_batch / predict_batch then receive
+        # device uint8 tensors [n,H,W,3] staged through pinned memory by a producer thread instead of lists of host frames
+        self.uploader = uploader
         self.word_segmentation, self.segment = word_segmentation, segment      # config.wordSegmentation (main.py:181-182)
         self.raw_lines = None
         self.short_lines = None
 
+    def _uploader(self):
+        if self.uploader == "auto":
+            self.uploader = staging.default_uploader() if hasattr(self.ocr, "predict_batch") else None
+        return self.uploader
+
     def select_tasks(self):
         s = self.source
         if self.sub_area is not None and self.mode == "accurate" and self.detect_batch is not None:
+            up = self._uploader()
             sel = frame_select.AccurateFrameSelector(self.detect_batch, self.ocr.predict, self.sub_area, s.frame_count,
                                                      self.threshold, chunk=self.batch,
                                                      predict_batch=getattr(self.ocr, "predict_batch", None) and self._predict_list)
-            return [(t[0], t[1], t[2], t[3], None, None) for t in sel.run(s.frames())]
+            return [(t[0], t[1], t[2], t[3], None, None) for t in sel.run(s.frames(), uploader=up)]
         return fps_tasks(s.frame_count, s.fps, self.extract_frequency, self.default_subtitle_area)
 
     def _predict_list(self, frames):
-        return self.ocr.predict_batch(_stack(frames))
+        return self.ocr.predict_batch(frames if not isinstance(frames, list) else _stack(frames))
 
     def run(self):
         """-> SRT text.  raw_lines (normalised, as the reference rewrites raw.txt) and short_lines are kept on the object."""
         tasks = self.select_tasks()
         lines = run_ocr_tasks(self.source, tasks, self.ocr, self.sub_area, self.language, self.drop_score,
-                              self.deviation_rate, self.batch, self.shard, self.gather_device)
+                              self.deviation_rate, self.batch, self.shard, self.gather_device, self._uploader())
         if self.sub_area is None:
             if self.watermark_decide is not None:               # the reference asks on stdin (main.py:164-170)
                 lines = raw_filters.filter_watermark(lines, self.watermark_decide)

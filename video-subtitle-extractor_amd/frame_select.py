@@ -124,26 +124,37 @@ class AccurateFrameSelector:
             self._pending.append(self._no - 1)
         self._flush(1)
 
-    def run(self, frames):
+    def run(self, frames, uploader=None):
         """frames: iterable of frames in decode order.  Returns the task list
-        [(frame_count, frame_no, dt_box | None, rec_res | None)] in the reference's queue order."""
-        buf = []
-        for f in frames:
-            buf.append(f)
-            if len(buf) == self.chunk:
-                self._consume(buf)
-                buf = []
-        if buf:
-            self._consume(buf)
+        [(frame_count, frame_no, dt_box | None, rec_res | None)] in the reference's queue order.
+        uploader (staging.Uploader): chunks are staged through pinned memory by a producer thread; detect_batch and
+        predict_batch then receive device uint8 tensors [n,H,W,3] (one upload per chunk serves both)."""
+        def chunks():
+            buf = []
+            for f in frames:
+                if buf and (len(buf) == self.chunk or getattr(buf[0][1], "shape", None) != getattr(f, "shape", None)):
+                    yield buf
+                    buf = []
+                buf.append((None, f))
+            if buf:
+                yield buf
+        if uploader is not None:
+            from . import staging
+            for items, staged in staging.prefetch(chunks(), uploader):
+                self._consume([f for _, f in items], staged.tensor())
+        else:
+            for items in chunks():
+                self._consume([f for _, f in items])
         self._flush(0)
         return self.tasks
 
-    def _consume(self, frames):
-        dets = self.detect_batch(frames)
+    def _consume(self, frames, dev=None):
+        dets = self.detect_batch(frames if dev is None else dev)
         if self.predict_batch is not None:
             want = [i for i, b in enumerate(dets) if self._has_subtitle(b)]
             if want:
-                for i, r in zip(want, self.predict_batch([frames[i] for i in want])):
+                sub = [frames[i] for i in want] if dev is None else dev[want]
+                for i, r in zip(want, self.predict_batch(sub)):
                     self._prefetched[self._no + 1 + i] = r
         for f, b in zip(frames, dets):
             self._step(f, b)
