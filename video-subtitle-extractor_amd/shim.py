@@ -17,11 +17,11 @@ from types import SimpleNamespace
 
 import numpy as np
 
-from . import engine, modelzoo, pipeline
+from . import engine, modelzoo, paddle_io, pipeline
 
 config = SimpleNamespace(language="ch", mode="fast", recBatchNumber=6, maxBatchSize=10, dropScore=75,
                          subtitleAreaDeviationRate=0, hardwareAcceleration=True, device=0,
-                         allow_standin_weights=False, weights_dir=None, dict_dir=None)
+                         allow_standin_weights=False, weights_dir=None, dict_dir=None, models_root=None)
 
 LATIN_LANG = ['af', 'az', 'bs', 'cs', 'cy', 'da', 'de', 'es', 'et', 'fr', 'ga', 'hr', 'hu', 'id', 'is', 'it', 'ku',
               'la', 'lt', 'lv', 'mi', 'ms', 'mt', 'nl', 'no', 'oc', 'pi', 'pl', 'pt', 'ro', 'rs_latin', 'sk', 'sl',
@@ -121,6 +121,9 @@ class PaddleModelConfig:
 
     @staticmethod
     def _exists(ver, name):
+        # the reference tests for the model DIRECTORY (paddle_model_config.py:66-79); config.models_root is that tree
+        if config.models_root and os.path.exists(os.path.join(config.models_root, ver, name, "inference.pdmodel")):
+            return True
         return os.path.exists(os.path.join(modelzoo.MODELS_DIR, f'{ver}_{name}.json'))
 
     def convertToOnnxModelIfNeeded(self, model_dir, *a, **k):   # identity: no ONNX path here
@@ -184,16 +187,43 @@ def charset_for(lang, ncls, rec_char_dict_path=None, use_space_char=True):
                             f"config.dict_dir to a directory holding {_dict_candidates(lang)[0]} (paddleocr ppocr/utils)")
 
 
-def _load_model(model_id):
-    desc = modelzoo.load_descriptor(model_id)
+def _paddle_dir(model):
+    """A Paddle inference model directory for `model`: the argument itself when it is one (det_model_dir / rec_model_dir as the
+    reference passes them, ocr.py:93-99), else <config.models_root>/<version>/<name> for an id like 'V4_ch_det' (the layout
+    of the reference's backend/models)."""
+    if os.path.isdir(model) and os.path.exists(os.path.join(model, "inference.pdmodel")):
+        return model
+    if config.models_root and "_" in os.path.basename(model):
+        ver, name = os.path.basename(model).split("_", 1)
+        d = os.path.join(config.models_root, ver, name)
+        if os.path.exists(os.path.join(d, "inference.pdmodel")):
+            return d
+    return None
+
+
+def _load_model(model):
+    """-> (descriptor, weights).  `model` is a model id under models/ ('V4_ch_det') or a Paddle inference model directory.
+    Weights come, in this order, from inference.pdiparams of the Paddle directory (read directly, paddle_io), from
+    <id>.npz under config.weights_dir or models/, or — only when config.allow_standin_weights — from the seeded stand-ins."""
+    pdir = _paddle_dir(model)
+    if pdir is not None:
+        mid = os.path.basename(model) if pdir != model else "_".join(os.path.normpath(pdir).split(os.sep)[-2:])
+        desc, weights = paddle_io.load_model_dir(pdir, mid)
+        if weights is not None:
+            return desc, weights
+        model_id = mid
+    else:
+        model_id = os.path.basename(model)
+        desc = modelzoo.load_descriptor(model_id)
     cands = [os.path.join(d, model_id + ".npz") for d in (config.weights_dir, modelzoo.MODELS_DIR) if d]
     for p in cands:
         if os.path.exists(p):
             return desc, modelzoo.load_weights_npz(p)
     if config.allow_standin_weights:
         return desc, modelzoo.random_weights(desc)
-    raise FileNotFoundError(f"weights for {model_id} not found ({cands}); the reference checkout ships them only for "
-                            "V3_ch_det_fast — convert inference.pdiparams with tools/pdmodel_convert.py")
+    raise FileNotFoundError(f"weights for {model_id} not found (no inference.pdiparams in {pdir or config.models_root}, none of "
+                            f"{cands}); the reference checkout ships them only for V3_ch_det_fast — point config.models_root at "
+                            "a backend/models tree that holds the .pdiparams blobs, or pass the model directory itself")
 
 
 def _ncls(desc):
