@@ -205,11 +205,35 @@ def order_points_clockwise(pts):
     return rect
 
 
+def _hole_contours(mask):
+    """Hole borders of cv2.findContours(RETR_LIST): 4-connected background regions that do not reach the image frame; the
+    border of one = the foreground pixels 4-adjacent to it (Suzuki-Abe border points of the 8-connected case).
+    -> [(raster index of the hole's first pixel, xs, ys)]"""
+    h, w = mask.shape
+    lab, k = ndimage.label(~mask)                       # default structure: 4-connectivity
+    if k == 0:
+        return []
+    outside = np.unique(np.concatenate([lab[0], lab[-1], lab[:, 0], lab[:, -1]]))
+    cross = ndimage.generate_binary_structure(2, 1)
+    out = []
+    for li, sl in enumerate(ndimage.find_objects(lab), 1):
+        if li in outside or sl is None:
+            continue
+        y0, y1, x0, x1 = sl[0].start - 1, sl[0].stop + 1, sl[1].start - 1, sl[1].stop + 1      # a hole never touches the frame
+        region = lab[y0:y1, x0:x1] == li
+        ring = ndimage.binary_dilation(region, cross) & mask[y0:y1, x0:x1]
+        ys, xs = np.nonzero(ring)
+        fy, fx = np.nonzero(region)
+        out.append(((int(fy[0]) + y0) * w + int(fx[0]) + x0, xs + x0, ys + y0))
+    return out
+
+
 def db_postprocess(prob, src_h, src_w, thresh=0.3, box_thresh=0.6, unclip_ratio=1.5, max_candidates=1000, min_size=3):
     """prob: float32 [h,w] -> (boxes float32 [k,4,2] in source pixels, scores float32 [k]).
-    Restates DBPostProcess.boxes_from_bitmap + TextDetector.filter_tag_det_res (App. C.2) with: outer contours
-    only (hole contours of RETR_LIST are not reproduced), components visited in reverse raster order of their
-    first pixel, convex hull of run end-points in place of the traced contour."""
+    Restates DBPostProcess.boxes_from_bitmap + TextDetector.filter_tag_det_res (App. C.2): outer borders of the 8-connected
+    components AND hole borders (cv2.findContours with RETR_LIST returns both), visited in reverse raster order of the pixel
+    at which the scan finds them (a component's first pixel / a hole's first pixel), convex hull of the border points in
+    place of the traced contour (the minimum-area rectangle only sees the hull)."""
     h, w = prob.shape
     mask = prob > np.float32(thresh)
     lab, k = ndimage.label(mask, structure=np.ones((3, 3), int))
@@ -223,13 +247,14 @@ def db_postprocess(prob, src_h, src_w, thresh=0.3, box_thresh=0.6, unclip_ratio=
     order = np.argsort(labs, kind="stable")
     ys, xs, labs = ys[order], xs[order], labs[order]
     starts = np.searchsorted(labs, np.arange(1, k + 2))
-    used = 0
-    for ci in range(k, 0, -1):
-        if used >= max_candidates:
-            break
-        used += 1
+    contours = []                                        # (raster index where the scan meets the border, xs, ys)
+    for ci in range(1, k + 1):
         sl = slice(starts[ci - 1], starts[ci])
-        hull = _convex_hull(zip(xs[sl].tolist(), ys[sl].tolist()))
+        contours.append((int((ys[sl] * w + xs[sl]).min()), xs[sl], ys[sl]))
+    contours += _hole_contours(mask)
+    contours.sort(key=lambda c: -c[0])
+    for _key, cx, cy in contours[:max_candidates]:
+        hull = _convex_hull(zip(cx.tolist(), cy.tolist()))
         corners, rw_, rh_ = _min_area_rect(hull)
         box, sside = _mini_box(corners, rw_, rh_)
         if sside < min_size:

@@ -165,3 +165,49 @@ def test_db_postprocess_noise_frame_degrades_alone(ctx):
     assert len(res[1][0]) == len(rb) == 1000          # max_candidates, like the reference
     key = lambda b: tuple(np.asarray(b).reshape(-1).tolist())
     assert sorted(map(key, res[1][0])) == sorted(map(key, rb))
+
+
+def _holey_maps(seed, n=4, h=96, w=160):
+    """High-probability blobs with dips below the threshold: enclosed holes of several sizes and depths (some pass the
+    0.6 box score, some do not), islands inside holes, notches open to the background, diagonally touching holes, blobs on
+    the frame."""
+    rng = np.random.default_rng(seed)
+    maps = rng.uniform(0, 0.2, (n, h, w)).astype(np.float32)
+    for f in range(n):
+        for _ in range(int(rng.integers(2, 6))):
+            bw, bh = int(rng.integers(20, 70)), int(rng.integers(10, 30))
+            x0, y0 = int(rng.integers(-5, w - bw + 5)), int(rng.integers(-3, h - bh + 3))
+            xa, ya, xb, yb = max(x0, 0), max(y0, 0), min(x0 + bw, w), min(y0 + bh, h)
+            maps[f, ya:yb, xa:xb] = rng.uniform(0.7, 0.99)
+            for _ in range(int(rng.integers(1, 5))):
+                dw, dh = int(rng.integers(1, 7)), int(rng.integers(1, 6))
+                dx, dy = int(rng.integers(xa - 2, max(xa - 1, xb - dw + 2))), int(rng.integers(ya - 2, max(ya - 1, yb - dh + 2)))
+                dxa, dya = max(dx, 0), max(dy, 0)
+                maps[f, dya:max(dya, dy + dh), dxa:max(dxa, dx + dw)] = rng.choice([0.0, 0.2, 0.29, 0.3])
+                if dw >= 3 and dh >= 3 and rng.random() < 0.5:
+                    maps[f, dy + 1:dy + 2, dx + 1:dx + 2] = 0.95            # an island inside the hole
+                if rng.random() < 0.4:                                     # a second dip touching the first one diagonally
+                    maps[f, max(dy + dh, 0):max(dy + dh, 0) + 2, max(dx + dw, 0):max(dx + dw, 0) + 2] = 0.1
+    return maps
+
+
+@pytest.mark.parametrize("seed", [10, 11, 12])
+def test_db_postprocess_hole_contours_match_oracle(ctx, seed):
+    """RETR_LIST semantics: hole borders are contours too.  The engine finds them from the run records on the host
+    (db_geometry.h hole_borders: union of background runs), the oracle by labelling the inverted mask with scipy."""
+    import torch
+    maps = _holey_maps(seed)
+    n, h, w = maps.shape
+    got = ctx.db_postprocess(torch.from_numpy(maps).cuda(), 2 * h, 2 * w)
+    from_holes = 0
+    for f in range(n):
+        rb, rs = P.db_postprocess(maps[f], 2 * h, 2 * w)
+        gb, gs = got[f]
+        assert gb.shape == rb.shape and np.array_equal(gb, rb), (f, gb, rb)
+        assert np.abs(gs - rs).max() < 1e-6 if len(rs) else True
+        keep, P._hole_contours = P._hole_contours, lambda m: []
+        try:
+            from_holes += len(rb) - len(P.db_postprocess(maps[f], 2 * h, 2 * w)[0])
+        finally:
+            P._hole_contours = keep
+    assert from_holes >= 3                  # the maps do exercise the hole path (3 / 8 / 7 boxes for the three seeds)

@@ -89,3 +89,35 @@ def test_rec_batches_reference_grouping():
     assert groups[0][1] == int(48 * (700 / 48)) and groups[1][1] == 900
     x = P.resize_norm_img(crops[0], 320)
     assert x.shape == (3, 48, 320) and np.all(x[:, :, 100:] == 0) and np.all(x[:, :, :100] == -1.0)
+
+
+def test_db_postprocess_hole_contours_known_answers():
+    """cv2.findContours(RETR_LIST) also returns hole borders, and boxes_from_bitmap treats them like any contour.
+    A 3x3 dip inside a 0.9 blob: border points = the 12 foreground pixels 4-adjacent to it (hull: an octagon inside
+    [19,23]x[9,13]), min-area rectangle 4x4, score over its 25 lattice points (16 x 0.9 + 9 x dip) / 25."""
+    prob = np.zeros((32, 64), np.float32)
+    prob[4:21, 5:41] = 0.9
+    prob[10:13, 20:23] = 0.25                       # score 0.666 >= 0.6: the hole yields a box of its own
+    boxes, scores = P.db_postprocess(prob, 32, 64)
+    assert len(boxes) == 2
+    small = boxes[np.argmin([np.ptp(b[:, 0]) for b in boxes])]
+    # 4x4 box grown by area * 1.5 / perimeter = 1.5 on every side: [17.5, 24.5] x [7.5, 14.5] -> integer corners
+    assert small[:, 0].min() in (17, 18) and small[:, 0].max() in (24, 25)
+    assert small[:, 1].min() in (7, 8) and small[:, 1].max() in (14, 15)
+    assert abs(float(scores[np.argmin([np.ptp(b[:, 0]) for b in boxes])]) - (16 * 0.9 + 9 * 0.25) / 25) < 1e-6
+    prob[10:13, 20:23] = 0.0                        # score 0.576 < 0.6: rejected
+    assert len(P.db_postprocess(prob, 32, 64)[0]) == 1
+    prob[10:13, 20:23] = 0.25
+    prob[10:13, 5:20] = 0.25                        # the dip now reaches ... still enclosed by column 5? no: opens to x < 5
+    assert len(P.db_postprocess(prob, 32, 64)[0]) == 1          # a notch open to the background is not a hole
+    # a hole whose border pixels lie on the frame is still a hole (the frame itself is background for the scan)
+    prob = np.zeros((16, 16), np.float32)
+    prob[0:9, 0:9] = 0.9
+    prob[3:6, 3:6] = 0.25
+    assert len(P.db_postprocess(prob, 16, 16)[0]) == 2
+    # two dips joined only diagonally are two holes (background is 4-connected)
+    prob = np.zeros((32, 64), np.float32)
+    prob[2:30, 2:60] = 0.95
+    prob[10:13, 20:23] = 0.29
+    prob[13:16, 23:26] = 0.29
+    assert len(P.db_postprocess(prob, 32, 64)[0]) == 3

@@ -166,4 +166,76 @@ inline void order_clockwise(const Pt in[4], Pt out[4]) {
     out[3] = (d1 > d0) ? rest[1] : rest[0];
 }
 
+
+// ---- hole borders (cv2.findContours with RETR_LIST returns them beside the outer borders) -------------------------------
+// Input: the foreground runs of one frame, per row, sorted by column.  A hole = a 4-connected background region that does
+// not reach the image frame; its border = the foreground pixels 4-adjacent to it (Suzuki-Abe border points of the
+// 8-connected case).  Only hull-relevant border points are emitted (run neighbours left / right, and the first / last
+// foreground pixel above and below each hole run inside every foreground run that overlaps it).
+struct Run { int a, b; };                     // columns [a, b] inclusive
+struct HoleBorder { long key; std::vector<IPt> pts; };    // key = raster index of the hole's first pixel
+
+inline std::vector<HoleBorder> hole_borders(const std::vector<std::vector<Run>>& fg, int y_first, int h, int w) {
+    // fg[i] = runs of row y_first + i (rows outside [y_first, y_first + fg.size()) hold no foreground)
+    struct Bg { int y, a, b, parent; bool frame; };
+    std::vector<Bg> bg;
+    std::vector<int> row_begin(fg.size() + 1, 0);
+    for (size_t i = 0; i < fg.size(); ++i) {
+        const int y = y_first + (int)i;
+        row_begin[i] = (int)bg.size();
+        const auto& r = fg[i];
+        const bool edge_row = (y == 0) || (y == h - 1);
+        if (r.empty()) { bg.push_back({y, 0, w - 1, 0, true}); continue; }
+        if (r[0].a > 0) bg.push_back({y, 0, r[0].a - 1, 0, true});
+        for (size_t k = 0; k + 1 < r.size(); ++k) bg.push_back({y, r[k].b + 1, r[k + 1].a - 1, 0, edge_row});
+        if (r.back().b < w - 1) bg.push_back({y, r.back().b + 1, w - 1, 0, true});
+    }
+    row_begin[fg.size()] = (int)bg.size();
+    for (size_t i = 0; i < bg.size(); ++i) bg[i].parent = (int)i;
+    auto find = [&](int a) { while (bg[a].parent != a) { bg[a].parent = bg[bg[a].parent].parent; a = bg[a].parent; } return a; };
+    auto unite = [&](int a, int b) {
+        a = find(a); b = find(b);
+        if (a == b) return;
+        if (a > b) std::swap(a, b);
+        bg[b].parent = a;                       // the smaller index (earlier in raster order) stays the root
+        bg[a].frame = bg[a].frame || bg[b].frame;
+    };
+    // the rows just outside the band are all background and reach the frame
+    auto touch_frame = [&](size_t i) { for (int k = row_begin[i]; k < row_begin[i + 1]; ++k) bg[find(k)].frame = true; };
+    if (!fg.empty()) { touch_frame(0); touch_frame(fg.size() - 1); }
+    for (size_t i = 1; i < fg.size(); ++i) {
+        int p = row_begin[i - 1], q = row_begin[i];
+        const int pe = row_begin[i], qe = row_begin[i + 1];
+        while (p < pe && q < qe) {
+            if (bg[p].a <= bg[q].b && bg[q].a <= bg[p].b) unite(p, q);
+            if (bg[p].b < bg[q].b) ++p; else ++q;
+        }
+    }
+    std::vector<HoleBorder> out;
+    std::vector<int> slot(bg.size(), -1);
+    for (size_t k = 0; k < bg.size(); ++k) {
+        const int root = find((int)k);
+        if (bg[root].frame) continue;
+        if (slot[root] < 0) {
+            slot[root] = (int)out.size();
+            out.push_back({(long)bg[root].y * w + bg[root].a, {}});    // root = first run in raster order
+        }
+        auto& pts = out[slot[root]].pts;
+        const Bg& g = bg[k];
+        pts.push_back({g.a - 1, g.y});
+        pts.push_back({g.b + 1, g.y});
+        for (int dy = -1; dy <= 1; dy += 2) {
+            const int i = g.y + dy - y_first;
+            if (i < 0 || i >= (int)fg.size()) continue;               // cannot happen for a hole; kept for safety
+            for (const Run& r : fg[i]) {
+                if (r.b < g.a) continue;
+                if (r.a > g.b) break;
+                pts.push_back({std::max(r.a, g.a), g.y + dy});
+                pts.push_back({std::min(r.b, g.b), g.y + dy});
+            }
+        }
+    }
+    return out;
+}
+
 }  // namespace dbgeo

@@ -129,7 +129,10 @@ __global__ __launch_bounds__(256) void db_merge_kernel(int* __restrict__ Lall, i
         }
     }
 }
-// Emits one record per horizontal run END-POINT: {root, x | y << 16}.  cnt[f] counts records of frame f.
+// Emits one record per horizontal run END-POINT: {root | end flags, x | y << 16}.  cnt[f] counts records of frame f.
+#define DB_LEFT (1 << 28)
+#define DB_RIGHT (1 << 29)
+#define DB_ROOT_MASK ((1 << 28) - 1)
 __global__ __launch_bounds__(256) void db_runs_kernel(int* __restrict__ Lall, int n, int h, int w, int2* __restrict__ recs,
                                                       int* __restrict__ cnt, int cap) {
     const long hw = (long)h * w;
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256) void db_runs_kernel(int* __restrict__ Lall, in
         if (!(left || right)) continue;
         const int root = uf_find(L, p);
         const int slot = atomicAdd(&cnt[f], 1);
-        if (slot < cap) recs[f * cap + slot] = make_int2(root, x | (y << 16));
+        if (slot < cap) recs[f * cap + slot] = make_int2(root | (left ? DB_LEFT : 0) | (right ? DB_RIGHT : 0), x | (y << 16));
     }
 }
 
@@ -200,7 +203,7 @@ static void db_runs_host(const int* L, int h, int w, std::vector<int2>& out) {
             if (!(left || right)) continue;
             int r = p;
             while (L[r] != r) r = L[r];
-            out.push_back(make_int2(r, x | (y << 16)));
+            out.push_back(make_int2(r | (left ? DB_LEFT : 0) | (right ? DB_RIGHT : 0), x | (y << 16)));
         }
 }
 
@@ -217,7 +220,7 @@ extern "C" int vse_db_postprocess(vse_ctx*, const float* d_prob, int n, int h, i
                                   int* n_boxes, void* stream) {
     if (!d_prob || !prm || !d_ws || !boxes || !n_boxes || n <= 0) return VSE_E_INVAL;
     if (ws_bytes < vse_db_workspace_bytes(n, h, w)) return VSE_E_NOMEM;
-    if (w >= 65536 || h >= 32768) return VSE_E_UNSUPPORTED;
+    if (w >= 65536 || h >= 32768 || (long)h * w > DB_ROOT_MASK) return VSE_E_UNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     char* ws = reinterpret_cast<char*>(d_ws);
     int* L = reinterpret_cast<int*>(ws);
@@ -272,23 +275,45 @@ extern "C" int vse_db_postprocess(vse_ctx*, const float* d_prob, int n, int h, i
     std::vector<ScoreBox> sb;
     for (int f = 0; f < n; ++f) {
         auto& r = hrecs[f];
+        // contours in cv2.findContours(RETR_LIST) order: outer borders of the 8-connected components and hole borders, most
+        // recently found first = descending raster index of the pixel at which the scan meets them (a component's first
+        // pixel = its union-find root; a hole's first pixel)
+        struct Contour { long key; std::vector<dbgeo::IPt> pts; };
+        std::vector<Contour> contours;
+        {
+            // foreground runs per row (for the holes): records sorted by (y, x); a LEFT record opens a run, a RIGHT one closes it
+            std::vector<int2> byrow(r);
+            std::sort(byrow.begin(), byrow.end(), [](const int2& a, const int2& b) {
+                const int ya = a.y >> 16, yb = b.y >> 16;
+                return ya < yb || (ya == yb && (a.y & 0xffff) < (b.y & 0xffff));
+            });
+            if (!byrow.empty()) {
+                const int y_first = byrow.front().y >> 16, y_last = byrow.back().y >> 16;
+                std::vector<std::vector<dbgeo::Run>> fg(y_last - y_first + 1);
+                for (const int2& e : byrow) {
+                    auto& row = fg[(e.y >> 16) - y_first];
+                    const int x = e.y & 0xffff;
+                    if (e.x & DB_LEFT) row.push_back({x, x});
+                    if (e.x & DB_RIGHT) row.back().b = x;
+                }
+                for (auto& hb : dbgeo::hole_borders(fg, y_first, h, w)) contours.push_back({hb.key, std::move(hb.pts)});
+            }
+        }
+        for (auto& e : r) e.x &= DB_ROOT_MASK;
         std::sort(r.begin(), r.end(), [](const int2& a, const int2& b) { return a.x < b.x || (a.x == b.x && a.y < b.y); });
-        // components ordered by descending root = reverse raster order of their first pixel (cv2.findContours
-        // returns the most recently found contour first)
-        std::vector<std::pair<int, int>> comps;   // [begin,end) over r
         for (size_t i = 0; i < r.size();) {
             size_t j = i;
-            while (j < r.size() && r[j].x == r[i].x) ++j;
-            comps.emplace_back((int)i, (int)j);
+            Contour c;
+            c.key = r[i].x;
+            while (j < r.size() && r[j].x == r[i].x) { c.pts.push_back({r[j].y & 0xffff, r[j].y >> 16}); ++j; }
+            contours.push_back(std::move(c));
             i = j;
         }
-        std::reverse(comps.begin(), comps.end());
+        std::sort(contours.begin(), contours.end(), [](const Contour& a, const Contour& b) { return a.key > b.key; });
         int used = 0;
-        for (auto& ce : comps) {
+        for (auto& ct : contours) {
             if (used++ >= prm->max_candidates) break;
-            std::vector<dbgeo::IPt> pts;
-            pts.reserve(ce.second - ce.first);
-            for (int i = ce.first; i < ce.second; ++i) pts.push_back({r[i].y & 0xffff, r[i].y >> 16});
+            const auto& pts = ct.pts;
             const auto hull = dbgeo::convex_hull(pts);
             const auto mr = dbgeo::min_area_rect(hull);
             Cand c;
