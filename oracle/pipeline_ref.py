@@ -309,17 +309,52 @@ def crop_geometry(pts):
 
 
 def _perspective_inverse(src, cw, ch):
-    dst = np.array([[0, 0], [cw, 0], [cw, ch], [0, ch]], dtype=np.float64)
-    A = np.zeros((8, 8))
-    b = np.zeros(8)
+    """cv2.getPerspectiveTransform + the inversion warpPerspective applies (no WARP_INVERSE_MAP), in cv2's own arithmetic as
+    recalled: the 8x8 system solved by OpenCV's LU (partial pivoting on |a|, row updates a[j][k] += (a[j][i] * (-1 / a[i][i])) *
+    a[i][k], back substitution s / a[i][i]), then the closed-form 3x3 inverse (cofactors times 1 / det3).  Plain float64
+    scalar operations in that order: the engine's host code (prepost.hip perspective_inverse) performs the same sequence, so
+    the two agree to the last bit — which matters because integer-cornered quads put many 1/32-pixel coordinates exactly on a
+    rounding tie."""
+    dst = [(0.0, 0.0), (float(cw), 0.0), (float(cw), float(ch)), (0.0, float(ch))]
+    A = [[0.0] * 8 for _ in range(8)]
+    b = [0.0] * 8
     for i in range(4):
         x, y = float(src[i][0]), float(src[i][1])
         X, Y = dst[i]
-        A[i] = [x, y, 1, 0, 0, 0, -x * X, -y * X]
-        A[i + 4] = [0, 0, 0, x, y, 1, -x * Y, -y * Y]
+        A[i] = [x, y, 1.0, 0.0, 0.0, 0.0, -x * X, -y * X]
+        A[i + 4] = [0.0, 0.0, 0.0, x, y, 1.0, -x * Y, -y * Y]
         b[i], b[i + 4] = X, Y
-    m = np.append(np.linalg.solve(A, b), 1.0).reshape(3, 3)
-    return np.linalg.inv(m)
+    eps = 2.220446049250313e-16 * 100
+    for i in range(8):
+        k = i
+        for j in range(i + 1, 8):
+            if abs(A[j][i]) > abs(A[k][i]):
+                k = j
+        if abs(A[k][i]) < eps:
+            raise np.linalg.LinAlgError("singular")
+        if k != i:
+            A[i], A[k] = A[k], A[i]
+            b[i], b[k] = b[k], b[i]
+        d = -1.0 / A[i][i]
+        for j in range(i + 1, 8):
+            alpha = A[j][i] * d
+            for c in range(i + 1, 8):
+                A[j][c] += alpha * A[i][c]
+            b[j] += alpha * b[i]
+    for i in range(7, -1, -1):
+        sacc = b[i]
+        for c in range(i + 1, 8):
+            sacc -= A[i][c] * b[c]
+        b[i] = sacc / A[i][i]
+    m = b + [1.0]
+    det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6])
+    if det == 0.0:
+        raise np.linalg.LinAlgError("singular")
+    d = 1.0 / det
+    inv = [(m[4] * m[8] - m[5] * m[7]) * d, (m[2] * m[7] - m[1] * m[8]) * d, (m[1] * m[5] - m[2] * m[4]) * d,
+           (m[5] * m[6] - m[3] * m[8]) * d, (m[0] * m[8] - m[2] * m[6]) * d, (m[2] * m[3] - m[0] * m[5]) * d,
+           (m[3] * m[7] - m[4] * m[6]) * d, (m[1] * m[6] - m[0] * m[7]) * d, (m[0] * m[4] - m[1] * m[3]) * d]
+    return np.array(inv, np.float64).reshape(3, 3)
 
 
 def _cubic_w(x):
@@ -369,13 +404,20 @@ def get_rotate_crop_image(img, pts):
         minv = _perspective_inverse(np.asarray(pts, np.float32), cw, ch)
     except np.linalg.LinAlgError:
         minv = np.array([[1, 0, pts[0][0]], [0, 1, pts[0][1]], [0, 0, 1]], dtype=np.float64)
-    ys, xs = np.mgrid[0:ch, 0:cw].astype(np.float64)
-    X0 = minv[0, 0] * xs + minv[0, 1] * ys + minv[0, 2]
-    Y0 = minv[1, 0] * xs + minv[1, 1] * ys + minv[1, 2]
-    W = minv[2, 0] * xs + minv[2, 1] * ys + minv[2, 2]
+    # WarpPerspectiveInvoker walks the destination in blocks (BLOCK_SZ = 32: bh0 = min(16, h), bw0 = min(1024 / bh0, w)) and
+    # evaluates the homography from the block's left edge bx: X0 = M0 bx + M1 y + M2, then (X0 + M0 x1) * (32 / (W0 + M6 x1))
+    ys, xs = np.mgrid[0:ch, 0:cw]
+    bw0 = min(1024 // min(16, ch), cw)
+    bx = ((xs // bw0) * bw0).astype(np.float64)
+    x1 = (xs % bw0).astype(np.float64)
+    ys = ys.astype(np.float64)
+    X0 = minv[0, 0] * bx + minv[0, 1] * ys + minv[0, 2]
+    Y0 = minv[1, 0] * bx + minv[1, 1] * ys + minv[1, 2]
+    W0 = minv[2, 0] * bx + minv[2, 1] * ys + minv[2, 2]
+    W = W0 + minv[2, 0] * x1
     W = np.where(W != 0, 32.0 / np.where(W != 0, W, 1), 0.0)
-    X = np.rint(np.clip(X0 * W, -2147483648.0, 2147483647.0)).astype(np.int64)
-    Y = np.rint(np.clip(Y0 * W, -2147483648.0, 2147483647.0)).astype(np.int64)
+    X = np.rint(np.clip((X0 + minv[0, 0] * x1) * W, -2147483648.0, 2147483647.0)).astype(np.int64)
+    Y = np.rint(np.clip((Y0 + minv[1, 0] * x1) * W, -2147483648.0, 2147483647.0)).astype(np.int64)
     sx, sy = (X >> 5) - 1, (Y >> 5) - 1
     wx = _cubic_w((X & 31).astype(np.float32) * np.float32(1 / 32))
     wy = _cubic_w((Y & 31).astype(np.float32) * np.float32(1 / 32))

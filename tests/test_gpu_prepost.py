@@ -211,3 +211,22 @@ def test_db_postprocess_hole_contours_match_oracle(ctx, seed):
         finally:
             P._hole_contours = keep
     assert from_holes >= 3                  # the maps do exercise the hole path (3 / 8 / 7 boxes for the three seeds)
+
+
+def test_prepost_fuzz_sample(ctx, capsys):
+    """A fixed-seed sample of tools/fuzz_prepost.py: det pre-process at odd frame sizes and the perspective crop + resize on
+    random quads (rotated, skewed, partly outside the frame, 1-3 pixel sides, tall, very wide), all bit-exact.  The tool found
+    the rounding ties of integer-cornered quads (homography solved / evaluated in a different operation order); since then the
+    engine and the oracle both follow cv2's LU + blocked evaluation, and 2900 crops / 290 frame sizes compare equal."""
+    import importlib.util
+    import os
+    import sys
+    spec = importlib.util.spec_from_file_location("fuzz_prepost", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_prepost.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    argv, sys.argv = sys.argv, ["fuzz_prepost", "--cases", "150", "--seed", "77"]
+    try:
+        rc = fz.main()
+    finally:
+        sys.argv = argv
+    assert rc == 0, capsys.readouterr().out

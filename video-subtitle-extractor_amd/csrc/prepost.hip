@@ -403,25 +403,33 @@ static bool perspective_inverse(const float src[4][2], int cw, int ch, double mi
         memcpy(a[i], r0, sizeof r0);
         memcpy(a[i + 4], r1, sizeof r1);
     }
-    for (int c = 0; c < 8; ++c) {
-        int piv = c;
-        for (int r = c + 1; r < 8; ++r)
-            if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
-        if (std::fabs(a[piv][c]) < 1e-12) return false;
-        if (piv != c)
-            for (int k = 0; k < 9; ++k) std::swap(a[piv][k], a[c][k]);
-        for (int r = 0; r < 8; ++r) {
-            if (r == c) continue;
-            const double f = a[r][c] / a[c][c];
-            for (int k = c; k < 9; ++k) a[r][k] -= f * a[c][k];
+    // OpenCV's LU (hal::LU64f as recalled): partial pivoting, a[j][k] += (a[j][i] * (-1 / a[i][i])) * a[i][k], back
+    // substitution s / a[i][i] — the same operation sequence as oracle/pipeline_ref.py _perspective_inverse
+    const double eps = 2.220446049250313e-16 * 100;
+    for (int i = 0; i < 8; ++i) {
+        int k = i;
+        for (int j = i + 1; j < 8; ++j)
+            if (std::fabs(a[j][i]) > std::fabs(a[k][i])) k = j;
+        if (std::fabs(a[k][i]) < eps) return false;
+        if (k != i)
+            for (int c = 0; c < 9; ++c) std::swap(a[i][c], a[k][c]);
+        const double d = -1.0 / a[i][i];
+        for (int j = i + 1; j < 8; ++j) {
+            const double alpha = a[j][i] * d;
+            for (int c = i + 1; c < 8; ++c) a[j][c] += alpha * a[i][c];
+            a[j][8] += alpha * a[i][8];
         }
     }
     double m[9];
-    for (int i = 0; i < 8; ++i) m[i] = a[i][8] / a[i][i];
+    for (int i = 7; i >= 0; --i) {
+        double sacc = a[i][8];
+        for (int c = i + 1; c < 8; ++c) sacc -= a[i][c] * m[c];
+        m[i] = sacc / a[i][i];
+    }
     m[8] = 1.0;
     // invert 3x3
     const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-    if (std::fabs(det) < 1e-300) return false;
+    if (det == 0.0) return false;
     const double id = 1.0 / det;
     minv[0] = (m[4] * m[8] - m[5] * m[7]) * id;
     minv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
@@ -461,12 +469,17 @@ __global__ __launch_bounds__(256) void crop_warp_kernel(const uint8_t* __restric
     const uint8_t* S = src + c.frame * fstride;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
         const int x = i % c.cw, y = i / c.cw;
-        const double X0 = c.minv[0] * x + c.minv[1] * y + c.minv[2];
-        const double Y0 = c.minv[3] * x + c.minv[4] * y + c.minv[5];
-        double W = c.minv[6] * x + c.minv[7] * y + c.minv[8];
+        // WarpPerspectiveInvoker's blocked evaluation (BLOCK_SZ = 32): the homography is taken at the block's left edge bx
+        // and advanced by x1 inside the block — the same operation order as the oracle, ties at 1/32 pixel included
+        const int bw0 = min(1024 / min(16, c.ch), c.cw);
+        const double bx = (double)((x / bw0) * bw0), x1 = (double)(x % bw0), yd = (double)y;
+        const double X0 = c.minv[0] * bx + c.minv[1] * yd + c.minv[2];
+        const double Y0 = c.minv[3] * bx + c.minv[4] * yd + c.minv[5];
+        const double W0 = c.minv[6] * bx + c.minv[7] * yd + c.minv[8];
+        double W = W0 + c.minv[6] * x1;
         W = W != 0.0 ? 32.0 / W : 0.0;                       // INTER_TAB_SIZE = 32
-        const double fX = fmax(-2147483648.0, fmin(2147483647.0, X0 * W));
-        const double fY = fmax(-2147483648.0, fmin(2147483647.0, Y0 * W));
+        const double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + c.minv[0] * x1) * W));
+        const double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + c.minv[3] * x1) * W));
         const int X = (int)rint(fX), Y = (int)rint(fY);      // cv::saturate_cast<int>(double) = lrint
         const int sx = (X >> 5) - 1, sy = (Y >> 5) - 1;
         float wx[4], wy[4];
