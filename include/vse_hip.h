@@ -100,9 +100,9 @@ int vse_det_preprocess(vse_ctx* ctx, const void* d_bgr, int n, int src_h, int sr
  * hull vertices).  Host finishing (hull, min-area rect, score, unclip) is vse_db_boxes().
  * Replaces cv2.findContours / minAreaRect / fillPoly+mean inside paddleocr DBPostProcess (App. C.2). */
 typedef struct vse_db_params {
-    float thresh;          /* 0.3 */
-    float box_thresh;      /* 0.6 */
-    float unclip_ratio;    /* 1.5 */
+    double box_thresh;     /* 0.6: compared with the box score as Python floats (doubles) in the reference */
+    double unclip_ratio;   /* 1.5: distance = area * unclip_ratio / perimeter is double arithmetic in the reference */
+    float thresh;          /* 0.3: compared with the float32 map in float32 */
     int max_candidates;    /* 1000 */
     int min_size;          /* 3 */
 } vse_db_params;

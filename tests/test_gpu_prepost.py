@@ -230,3 +230,22 @@ def test_prepost_fuzz_sample(ctx, capsys):
     finally:
         sys.argv = argv
     assert rc == 0, capsys.readouterr().out
+
+
+def test_db_fuzz_sample(ctx, capsys):
+    """A fixed-seed sample of tools/fuzz_db.py (rotated rectangles, ellipses, thin strokes, frame-touching blobs, dips, noise;
+    random map / source sizes, thresholds and unclip ratios): identical integer boxes, scores within 1e-6.  The tool found that
+    a float32 unclip_ratio in the C ABI moves `area * ratio / perimeter` off the reference's double value for ratios like 1.2
+    (a .5 corner then rounds the other way); box_thresh and unclip_ratio are doubles in vse_db_params since."""
+    import importlib.util
+    import os
+    import sys
+    spec = importlib.util.spec_from_file_location("fuzz_db", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_db.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    argv, sys.argv = sys.argv, ["fuzz_db", "--cases", "120", "--seed", "31"]
+    try:
+        rc = fz.main()
+    finally:
+        sys.argv = argv
+    assert rc == 0, capsys.readouterr().out

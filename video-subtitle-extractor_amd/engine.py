@@ -26,7 +26,7 @@ class VseError(RuntimeError):
 
 
 class DbParams(C.Structure):
-    _fields_ = [("thresh", C.c_float), ("box_thresh", C.c_float), ("unclip_ratio", C.c_float),
+    _fields_ = [("box_thresh", C.c_double), ("unclip_ratio", C.c_double), ("thresh", C.c_float),
                 ("max_candidates", C.c_int), ("min_size", C.c_int)]
 
 
@@ -162,7 +162,7 @@ class Context:
             self._db_boxes_cap = max_boxes
         boxes = self._db_boxes
         nb = C.c_int(0)
-        prm = DbParams(thresh, box_thresh, unclip_ratio, max_candidates, min_size)
+        prm = DbParams(box_thresh, unclip_ratio, thresh, max_candidates, min_size)
         _check(self.lib.vse_db_postprocess(self.handle, C.c_void_p(prob.data_ptr()), n, h, w, src_h, src_w,
                                            C.byref(prm), C.c_void_p(self._db_ws.data_ptr()), nbytes, boxes,
                                            max_boxes, C.byref(nb), self.stream()), "vse_db_postprocess")
