@@ -549,8 +549,11 @@ def subtitle_area_keep(coordinate, prob, area, deviation_rate=0.0, drop_score=0.
     """backend/tools/subtitle_ocr.py:42-67 with shapely rectangles restated: keep iff the box intersects the area with
     positive area... (shapely `is_empty` is False for touching rectangles too) and overflow <= rate and prob > drop.
     coordinate = (xmin,xmax,ymin,ymax); area = (ymin,ymax,xmin,xmax)."""
-    xmin, xmax, ymin, ymax = coordinate
-    aymin, aymax, axmin, axmax = area
+    # shapely polygons do not care about the corner order: an "inverted" box (xmin > xmax from a skewed quad) covers the
+    # rectangle between its smaller and larger values
+    xmin, xmax = min(coordinate[0], coordinate[1]), max(coordinate[0], coordinate[1])
+    ymin, ymax = min(coordinate[2], coordinate[3]), max(coordinate[2], coordinate[3])
+    aymin, aymax, axmin, axmax = min(area[0], area[1]), max(area[0], area[1]), min(area[2], area[3]), max(area[2], area[3])
     ix0, ix1 = max(xmin, axmin), min(xmax, axmax)
     iy0, iy1 = max(ymin, aymin), min(ymax, aymax)
     if ix0 > ix1 or iy0 > iy1:

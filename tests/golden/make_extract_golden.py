@@ -207,6 +207,12 @@ def make_cases():
     C.append(dict(n_frames=8, lang="ch", drop_score=0.75, deviation=0.0, area=None, tasks=lower, ocr=base_ocr))
     cached = [[1, True, None], [2, False, None], [4, True, None], [9, False, None], [12, False, None], [7, True, None]]   # 12: past the end
     C.append(dict(n_frames=10, lang="ch", drop_score=0.5, deviation=0.0, area=area, tasks=cached, ocr=base_ocr))
+    # skewed quads whose box comes out "inverted" (xmin > xmax or ymin > ymax: max of one side's corners vs min of the other's,
+    # ocr.py:118-129): the polygon's region does not depend on the corner order (found by tests/golden/fuzz_vs_reference.py)
+    inv = {1: [[[[47.3, 26.0], [46.2, 26.2], [46.1, 34.0], [47.4, 34.3]], "x inverted", 0.9]],
+           2: [[[[20.0, 33.8], [32.0, 33.6], [31.9, 32.8], [19.2, 33.6]], "y inverted", 0.9]],
+           3: [[[[2.3, 26.0], [1.2, 26.2], [1.1, 34.0], [2.4, 34.3]], "inverted outside", 0.9]]}
+    C.append(dict(n_frames=3, lang="ch", drop_score=0.75, deviation=0.0, area=area, tasks=[[no, False, None] for no in (1, 2, 3)], ocr=inv))
     # random boxes against the area filter (touching / containing / partial overlaps; integer and .5 coordinates)
     for k in range(6):
         ocr = {}

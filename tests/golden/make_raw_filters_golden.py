@@ -71,6 +71,13 @@ def make_scenarios():
         y = rnd.choice([100, 140, 180, 900, 940]) + rnd.randint(-15, 15)
         lines.append(raw(n, f"w{n % 7}", (x, x + rnd.choice([200, 290, 400]), y, y + rnd.choice([40, 80]))))
     S.append(dict(lines=lines, answers=["y", "n", "y", "n", "y", "y"]))
+    # 8: a text with a tab in the MIDDLE of the file: the rewrite drops its tail and its newline, so the row shares a line
+    # with the next one, and the merged line goes when EITHER of its two areas is deleted (found by tests/golden/fuzz_vs_reference.py)
+    lines = [raw(1, "logo", (1700, 1850, 40, 90)), raw(2, "keep\tlost", (300, 900, 600, 650)), raw(3, "logo", (1700, 1850, 40, 90)),
+             raw(4, "sub", (300, 900, 600, 650)), raw(5, "x\ty", (100, 200, 900, 950)), raw(6, "sub", (300, 900, 600, 650)),
+             raw(7, "logo", (1700, 1850, 40, 90)), raw(8, "sub", (300, 900, 600, 650))]
+    S.append(dict(lines=lines, answers=["n", "y", "n", "y"]))
+    S.append(dict(lines=lines, answers=["y", "n", "y", "y"]))
     return S
 
 

@@ -16,6 +16,7 @@ watermark detector rewrites the file, a watermark line is dropped when the area'
 scene-text band is abs(ymin - dev) .. ymax + dev, ties in the frequency counts keep first-seen order.
 tolerantPixelX / tolerantPixelY are compared as plain numbers (backend/config.py:66-67: 100 / 50).
 """
+import io
 from collections import Counter
 
 import numpy as np
@@ -68,7 +69,9 @@ def detect_watermark_area(lines, num=WATERMARK_AREA_NUM, tol_x=TOLERANT_PIXEL_X,
     """raw lines -> ([(area, count), ...] most frequent first, at most `num`; the rewritten raw lines)."""
     rows = [_parse(ln) for ln in lines]
     coords = unite_coordinates([r[1] for r in rows], tol_x, tol_y)
-    out = [f'{r[0]}\t{c}\t{r[2]}' for r, c in zip(rows, coords)]
+    # the reference rewrites raw.txt here and every later step reads the FILE back: a text that contained a tab has lost its
+    # tail and its newline, so it now shares one line with the row that follows it (found by fuzzing against the reference)
+    out = io.StringIO("".join(f'{r[0]}\t{c}\t{r[2]}' for r, c in zip(rows, coords))).readlines()
     common = Counter(coords).most_common()
     return (common[:num] if len(common) > num else common), out
 

@@ -441,13 +441,19 @@ def subtitle_area_keep(coordinate, prob, sub_area, deviation_rate=None, drop_sco
     coordinate = (xmin,xmax,ymin,ymax); sub_area has .xmin .xmax .ymin .ymax."""
     deviation_rate = config.subtitleAreaDeviationRate if deviation_rate is None else deviation_rate
     drop_score = config.dropScore / 100.0 if drop_score is None else drop_score
-    xmin, xmax, ymin, ymax = coordinate
-    ix0, ix1 = max(xmin, sub_area.xmin), min(xmax, sub_area.xmax)
-    iy0, iy1 = max(ymin, sub_area.ymin), min(ymax, sub_area.ymax)
+    # a skewed quad can give xmin > xmax or ymin > ymax (max of the left corners vs min of the right ones, ocr.py:118-129); the
+    # reference builds a shapely Polygon from the four corners, whose region does not depend on the corner order — so the
+    # rectangle is taken between the smaller and the larger value (found by fuzzing against the reference's own code)
+    xmin, xmax = min(coordinate[0], coordinate[1]), max(coordinate[0], coordinate[1])
+    ymin, ymax = min(coordinate[2], coordinate[3]), max(coordinate[2], coordinate[3])
+    ax0, ax1 = min(sub_area.xmin, sub_area.xmax), max(sub_area.xmin, sub_area.xmax)
+    ay0, ay1 = min(sub_area.ymin, sub_area.ymax), max(sub_area.ymin, sub_area.ymax)
+    ix0, ix1 = max(xmin, ax0), min(xmax, ax1)
+    iy0, iy1 = max(ymin, ay0), min(ymax, ay1)
     if ix0 > ix1 or iy0 > iy1:
         return False
     inter = max(0, ix1 - ix0) * max(0, iy1 - iy0)
-    a_area = (sub_area.xmax - sub_area.xmin) * (sub_area.ymax - sub_area.ymin)
+    a_area = (ax1 - ax0) * (ay1 - ay0)
     b_area = (xmax - xmin) * (ymax - ymin)
     return (a_area + b_area - inter) / a_area - 1 <= deviation_rate and prob > drop_score
 
