@@ -415,6 +415,62 @@ def fuzz_extract(n, seed):
     return bad
 
 
+def fuzz_fps(n, seed):
+    """extract_frame_by_fps (backend/main.py:228-253) over random (frame count, fps, extract frequency)."""
+    import make_frame_loop_golden as G
+    from vse_amd import extractor
+    main = G.install_stubs(80)
+    rnd = random.Random(seed)
+    bad = 0
+    for i in range(n):
+        n_frames = rnd.choice([0, 1, 2, 3, 7, 30, 31, 100, 257, rnd.randrange(0, 400)])
+        fps = rnd.choice([23.976, 24.0, 25.0, 29.97, 30.0, 50.0, 59.94, 60.0, 12.0, 5.0, 1.0, 0.5, rnd.uniform(1, 120)])
+        freq = rnd.choice([1, 2, 3, 3, 3, 5, 10, 24, 30, 60, 100])
+        ext = object.__new__(main.SubtitleExtractor)
+        ext.frame_count, ext.fps = n_frames, fps
+        tasks = []
+
+        class Cap:
+            def __init__(self):
+                self.i, self.open = 0, True
+
+            def isOpened(self):
+                return self.open
+
+            def read(self):
+                if self.i >= n_frames:
+                    return False, None
+                self.i += 1
+                return True, self.i
+
+            def release(self):
+                self.open = False
+
+        class Q:
+            def put(self, task):
+                tasks.append([task[0], task[1], task[5]])
+        main.config.extractFrequency = G._Val(freq)
+        main.config.subtitleArea = G._Val("AREA")
+        ext.video_cap = Cap()
+        ext.subtitle_ocr_task_queue = Q()
+        ext.update_progress = lambda **k: None
+        try:
+            ext.extract_frame_by_fps()
+            ref = tasks
+        except Exception as e:                                      # noqa: BLE001
+            ref = "EXC " + type(e).__name__
+        try:
+            mine = [[t[0], t[1], t[5]] for t in extractor.fps_tasks(n_frames, fps, freq, "AREA")]
+        except Exception as e:                                      # noqa: BLE001
+            mine = "EXC " + type(e).__name__
+        if ref != mine:
+            bad += 1
+            if bad <= 5:
+                print("FPS DIFF", n_frames, fps, freq, "ref", str(ref)[:200], "mine", str(mine)[:200])
+    print(f"fps sampler: {n} cases, {bad} differences")
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
@@ -430,6 +486,8 @@ def main():
         bad += fuzz_cleanup(a.cases, a.seed)
     if a.only in ("", "loop"):
         bad += fuzz_frame_loop(a.cases, a.seed)
+    if a.only in ("", "fps"):
+        bad += fuzz_fps(a.cases, a.seed)
     # the two below install their own stub sets for the same module names: run them in separate invocations
     if a.only == "glue":
         bad += fuzz_glue(a.cases, a.seed)
