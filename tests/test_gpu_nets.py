@@ -285,3 +285,30 @@ def test_conv_fuzz_sample(ctx):
         seen.add(str(fam))
         test_conv_shapes(ctx, *c)
     assert {"c3", "col", "pw", "gemm", "gemm1x1", "stem"} <= seen
+
+
+def test_graph_fuzz_sample(ctx):
+    """A fixed-seed sample of tools/fuzz_graph.py on the engine: random graphs over the reference models' operator set match
+    the fp32 interpreter or are refused by the compiler (UnsupportedGraph); 600 graphs ran clean with the tool."""
+    import importlib.util
+    from vse_amd import compiler
+    spec = importlib.util.spec_from_file_location("fuzz_graph", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_graph.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(99)
+    ok = 0
+    for _ in range(60):
+        h, w = int(rng.integers(2, 9)) * 16, int(rng.integers(2, 11)) * 16
+        n = int(rng.integers(1, 4))
+        desc, wts, cout = fz.random_graph(rng, h, w)
+        x = rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float16).astype(np.float32)
+        ref = net_ref.run_graph(desc, wts, x)[0].numpy()
+        try:
+            got = run_hip(ctx, desc, wts, x)[0]
+        except compiler.UnsupportedGraph:
+            continue
+        got = np.transpose(got[..., :cout], (0, 3, 1, 2))
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
+        ok += 1
+    assert ok >= 45

@@ -86,6 +86,17 @@ class View:
         return self.w >> self.up
 
 
+def merge_segs(segs):
+    """Adjacent channel segments that are physically contiguous are one segment (a concat of 8-multiples is dense)."""
+    out = []
+    for st, cnt in segs:
+        if out and out[-1][0] + out[-1][1] == st:
+            out[-1] = (out[-1][0], out[-1][1] + cnt)
+        else:
+            out.append((st, cnt))
+    return out
+
+
 @dataclass
 class Program:
     ops: np.ndarray                 # ir.OP_DT records
@@ -464,6 +475,15 @@ class Compiler:
     def add_weights(self, key, arr):
         """Append to the weight blob (256-byte aligned); identical keys are shared across plans."""
         return self.store.add(key, arr)
+
+    def need_dense(self, v: View, what):
+        """Consumers that address channels linearly (depthwise conv, pooling, element-wise ops) need one dense segment."""
+        if v.parts is not None:
+            v = self.materialize(v, what)
+        if v.segs != [(0, v.c)]:
+            raise UnsupportedGraph(f"{what}: input channels are laid out in segments {v.segs} (a concat of parts that are not "
+                                   "multiples of 8 channels); only convolutions can read such a tensor")
+        return v
 
     # -------------------------------------------------------------------------------------------- materialize
     def materialize(self, v: View, name="mat"):
@@ -1014,7 +1034,8 @@ class Compiler:
         outname = op["out"]["Output"][0]
         wname = op["in"]["Filter"][0]
         c, _, kh, kw = w.shape
-        assert c == inv.c and inv.segs == [(0, c)]
+        assert c == inv.c
+        inv = self.need_dense(inv, f"depthwise conv {outname}")
         gate = self.pending_gate.pop(op["in"]["Input"][0], None)
         inv = self.materialize(inv, outname)
         ep = self.absorb_epilogue(outname, i, c, allow_res=False)
@@ -1176,7 +1197,7 @@ class Compiler:
                 return o
             return (n + 2 * p - k) // s + 1
         oh, ow = osz(x.h, kh, sh, ph), osz(x.w, kw, sw, pw)
-        assert x.segs == [(0, x.c)]
+        x = self.need_dense(x, f"pool {name}")
         out = self.alloc_out(name, x.n, oh, ow, x.c)
         self.emit(ir.OP_POOL, name, [x], out,
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
@@ -1221,7 +1242,7 @@ class Compiler:
                     flags |= ir.F_RES
                     outname = o2["out"]["Out"][0]
                     self.done.add(cons[0])
-            assert big.segs == [(0, big.c)] and gate.segs == [(0, gate.c)]
+            big, gate = self.need_dense(big, f"gate multiply {name}"), self.need_dense(gate, f"gate multiply {name}")
             # SE gate whose only consumer is a depthwise conv (the stage transitions of the HGNet recognisers): the conv
             # applies the gate on load and the scaled tensor is never written
             cons2 = self._live_consumers(outname)
@@ -1243,7 +1264,7 @@ class Compiler:
             x, y = y, x
         x = self.materialize(x, name)
         assert (x.n, x.h, x.w, x.c) == (y.n, y.h, y.w, y.c), (i, x, y)
-        assert x.segs == [(0, x.c)] and y.segs == [(0, y.c)]
+        x, y = self.need_dense(x, f"add {name}"), self.need_dense(y, f"add {name}")
         act = ir.ACT_NONE
         outname = name
         cons = self._live_consumers(name)
@@ -1262,7 +1283,7 @@ class Compiler:
         a = op["attrs"]
         x = self.resolve(op["in"]["X"][0])
         name = op["out"]["Out"][0]
-        x = self.materialize(x, name)
+        x = self.need_dense(self.materialize(x, name), f"{t} {name}")
         out = self.alloc_out(name, x.n, x.h, x.w, x.c)
         out.tag = x.tag
         f = {ir.FS_PRE_A: 1.0, ir.FS_PRE_B: 0.0, ir.FS_POST_A: 1.0, ir.FS_POST_B: 0.0}
@@ -1291,7 +1312,7 @@ class Compiler:
             for v in ins:
                 segs.append((off, v.c))
                 off += v.span
-            self.env[name] = View(None, 0, v0.n, v0.h, v0.w, segs, off, 0, "nchw", parts=list(ins))
+            self.env[name] = View(None, 0, v0.n, v0.h, v0.w, merge_segs(segs), off, 0, "nchw", parts=list(ins))
             return
         lay = self._concat_buf(name, v0.n, v0.h, v0.w)
         b = lay["buf"]
@@ -1299,11 +1320,21 @@ class Compiler:
         for nm, v, (off, c) in zip(op["in"]["X"], ins, lay["offs"]):
             assert (v.n, v.h, v.w, v.c) == (b.n, b.h, b.w, c), (name, nm, v, c)
             if not (v.buf is b and v.coff == off and v.up == 0):
-                dst = View(b, off, v.n, v.h, v.w, [(0, c)], rup(c, 8))
-                assert v.segs == [(0, c)]
-                self.emit(ir.OP_RESIZE, name + ":" + nm, [v], dst, p={0: v.up})
+                if v.parts is not None:
+                    v = self.materialize(v, name + ":" + nm)
+                # a multi-segment input (a nested concat whose parts are not multiples of 8 channels) is copied piece by piece;
+                # every piece must land on an 8-channel boundary of the destination (the copy kernel moves 8-channel groups)
+                done_c = 0
+                for st, cnt in v.segs:
+                    if done_c % 8:
+                        raise UnsupportedGraph(f"concat {name}: input {nm} has channel segments {v.segs} that do not fall on "
+                                               "8-channel boundaries")
+                    piece = View(v.buf, v.coff + st, v.n, v.h, v.w, [(0, cnt)], rup(cnt, 8), v.up, v.tag)
+                    dst = View(b, off + done_c, v.n, v.h, v.w, [(0, cnt)], rup(cnt, 8))
+                    self.emit(ir.OP_RESIZE, name + ":" + nm, [piece], dst, p={0: v.up})
+                    done_c += cnt
             segs.append((off, c))
-        out = View(b, 0, v0.n, v0.h, v0.w, segs, b.ld)
+        out = View(b, 0, v0.n, v0.h, v0.w, merge_segs(segs), b.ld)
         self.env[name] = out
 
     def lower_layernorm(self, i):
@@ -1432,7 +1463,7 @@ class Compiler:
         if v.buf.ext is not None:
             return      # softmax head already wrote external outputs
         # dense fp16 map [N,H,W,c]: copy/convert into an external fp32 buffer, channel-exact
-        v = self.materialize(v, name)
+        v = self.need_dense(self.materialize(v, name), f"fetch of {name}")
         ob = self.new_buf(v.n, v.h, v.w, v.c, esize=4, ext=len(self.outputs) + 1)
         self.outputs.append(dict(name=name, kind="map", n=v.n, h=v.h, w=v.w, c=v.c, ld=v.c, esize=4))
         ov = View(ob, 0, v.n, v.h, v.w, [(0, v.c)], v.c)
