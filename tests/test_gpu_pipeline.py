@@ -157,15 +157,16 @@ def test_streaming_form_is_identical(ctx):
     det = net_ref.get_weights("V3_ch_det_fast")
     rec = net_ref.get_weights("V4_en_rec_fast")
     pipe = pipeline.OcrPipeline(ctx, det, rec, P.en_charset(), rec_mode="bucketed")
-    batches = [torch.from_numpy(synth.make_frames(3, 720, 1280, seed=40 + k, p_two_lines=0.5)).cuda() for k in range(3)]
+    batches = [torch.from_numpy(synth.make_frames(3, 720, 1280, seed=40 + k, p_two_lines=0.5)).cuda() for k in range(5)]
     seq = [pipe.ocr(b) for b in batches]
-    got = list(pipe.ocr_stream(iter(batches)))
-    assert len(got) == 3
-    for a, b in zip(seq, got):
-        assert len(a) == len(b)
-        for (ab, ar), (bb, br) in zip(a, b):
-            assert len(ab) == len(bb) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(ab, bb))
-            assert ar == br
+    for depth in (1, 2, 3):                         # detector batches in flight (default 2): slots and streams rotate
+        got = list(pipe.ocr_stream(iter(batches), depth=depth))
+        assert len(got) == 5
+        for a, b in zip(seq, got):
+            assert len(a) == len(b)
+            for (ab, ar), (bb, br) in zip(a, b):
+                assert len(ab) == len(bb) and all(np.array_equal(np.asarray(x), np.asarray(y)) for x, y in zip(ab, bb))
+                assert ar == br
     assert list(pipe.ocr_stream(iter([]))) == []
 
 
