@@ -312,3 +312,24 @@ def test_graph_fuzz_sample(ctx):
         assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())
         ok += 1
     assert ok >= 45
+
+
+def test_workspace_budget_evicts_least_recently_used(ctx):
+    """A long video meets many recogniser shapes, each with its own zero-initialised workspace: beyond the budget the least
+    recently used ones are dropped (after a device sync) and re-created on demand — results do not change."""
+    import torch
+    from vse_amd import engine
+    desc, w = net_ref.get_weights("V4_en_rec_fast")
+    net = engine.Net(ctx, desc, w, want_probs=True)
+    rng = np.random.default_rng(0)
+    xs = [torch.from_numpy(ir_emul.to_nhwc8(rng.uniform(-1, 1, (2, 3, 48, wd)).astype(np.float16).astype(np.float32))
+                           .astype(np.float16)).cuda() for wd in (96, 160, 224, 96)]
+    base = [net.run(x)[0].cpu().numpy() for x in xs]
+    sizes = sorted(int(v.numel()) for v in net.ws.values())
+    assert len(sizes) == 3
+    small = engine.Net(ctx, desc, w, want_probs=True)
+    small.ws_budget = sizes[-1] + sizes[0] // 2          # room for the largest workspace and a bit: one plan resident at a time
+    again = [small.run(x)[0].cpu().numpy() for x in xs]
+    assert len(small.ws) == 1 and list(small.ws)[0][0] == (2, 48, 96)
+    for a, b in zip(base, again):
+        assert np.array_equal(a, b)

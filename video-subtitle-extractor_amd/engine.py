@@ -236,6 +236,7 @@ class Net:
         self.wid = None
         self.wbytes = 0
         self.ws = {}          # one workspace per plan: plans of one net may run concurrently on different streams
+        self.ws_budget = int(float(os.environ.get("VSE_WS_BUDGET_GB", "64")) * (1 << 30))     # per net; LRU beyond it
 
     def program(self, n, h, w):
         key = (n, h, w)
@@ -274,9 +275,21 @@ class Net:
         """One workspace per (plan, slot): a plan is stateless between runs, so the same plan may run concurrently on
         several streams as long as every in-flight run has its own slot."""
         t = self.ctx.torch
-        if (key, slot) not in self.ws:
-            self.ws[(key, slot)] = t.zeros(max(prog.ws_bytes, 256), dtype=t.uint8, device=self.ctx.tdev)
-        return self.ws[(key, slot)]
+        k = (key, slot)
+        ws = self.ws.pop(k, None)
+        if ws is None:
+            # a long video meets many recogniser shapes (crops x width bucket), each with a workspace of its own (they are
+            # zero-initialised and their padding regions must stay zero, so plans cannot share one): keep the total under a
+            # budget by dropping the least recently used ones — after a device synchronisation, they may still be in flight
+            need = max(prog.ws_bytes, 256)
+            total = sum(int(w.numel()) for w in self.ws.values())
+            if self.ws and total + need > self.ws_budget:
+                t.cuda.synchronize(self.ctx.tdev)
+                while self.ws and total + need > self.ws_budget:
+                    total -= int(self.ws.pop(next(iter(self.ws))).numel())
+            ws = t.zeros(need, dtype=t.uint8, device=self.ctx.tdev)
+        self.ws[k] = ws                       # (re-)inserted last: dict order = least recently used first
+        return ws
 
     def _ext(self, prog, x):
         t = self.ctx.torch
