@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Shape fuzzing of the REAL model graphs: every recogniser / detector family at random batch sizes and input sizes (recogniser
+widths are arbitrary integers in the reference's grouping: 48 * max w/h ratio; detector inputs any multiple of 32), engine (--gpu)
+or CPU emulator of the compiled program against the fp32 interpreter.
+usage: python tools/fuzz_shapes.py [--cases 40] [--seed 0] [--gpu] [--models V4_en_rec_fast,V3_ch_det_fast,...]"""
+import argparse
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import ir_emul, net_ref
+from vse_amd import compiler
+
+DEFAULT = "V4_en_rec_fast,V4_ch_rec_fast,V3_korean_rec_fast,V3_ch_rec_fast,V2_ch_rec,V3_ch_det_fast,V4_ch_det_fast,V2_ch_det"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--models", default=DEFAULT)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    models = a.models.split(",")
+    nets = {}
+    if a.gpu:
+        import torch
+        from vse_amd import engine
+        ctx = engine.Context(0)
+    bad = []
+    for i in range(a.cases):
+        mid = models[i % len(models)]
+        desc, w = net_ref.get_weights(mid)
+        n = int(rng.integers(1, 6))
+        if "_det" in mid:
+            h, wd = int(rng.integers(1, 9)) * 32, int(rng.integers(1, 13)) * 32
+        else:
+            h = 32 if mid.startswith("V2") else 48
+            wd = int(rng.choice([rng.integers(16, 80), rng.integers(80, 700), 320, 321, 319, 8 * int(rng.integers(4, 90)) + int(rng.integers(0, 8))]))
+        x = rng.uniform(-1, 1, (n, 3, h, wd)).astype(np.float16).astype(np.float32)
+        try:
+            ref = net_ref.run_graph(desc, w, x)[0].numpy()
+        except Exception as e:                                       # noqa: BLE001 - the reference graph itself rejects the shape
+            continue
+        try:
+            if a.gpu:
+                if mid not in nets:
+                    nets[mid] = engine.Net(ctx, desc, w, want_probs=True)
+                xt = torch.from_numpy(ir_emul.to_nhwc8(x).astype(np.float16)).to(ctx.tdev)
+                out = [o.cpu().numpy() for o in nets[mid].run(xt)]
+            else:
+                prog = compiler.compile_model(desc, w, n, h, wd)
+                out = ir_emul.Emulator(prog).run(ir_emul.to_nhwc8(x))
+        except compiler.UnsupportedGraph as e:
+            bad.append((mid, (n, h, wd), "refused: " + str(e)[:100]))
+            continue
+        except Exception as e:                                       # noqa: BLE001
+            bad.append((mid, (n, h, wd), type(e).__name__ + ": " + str(e)[:140]))
+            continue
+        if "_det" in mid:
+            got, r = out[0][..., 0], ref[:, 0]
+            tol = 1e-1 if mid == "V3_ch_det_fast" else 2e-2
+        else:
+            got, r = out[0][:, 0], ref
+            tol = 1e-3 if not mid.startswith("V3") else None
+        if got.shape != r.shape:
+            bad.append((mid, (n, h, wd), f"shape {got.shape} vs {r.shape}"))
+            continue
+        err = np.abs(got - r)
+        okay = err.max() < tol if tol is not None else bool(np.all((err < 1e-3) | (err < 0.1 * np.abs(r))))
+        if not np.isfinite(got).all() or not okay:
+            bad.append((mid, (n, h, wd), f"max err {err.max():.4g}"))
+    print(f"{a.cases} (model, shape) cases over {len(models)} models; failures: {len(bad)}")
+    for b in bad[:30]:
+        print("FAIL", b)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
