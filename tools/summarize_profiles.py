@@ -38,6 +38,12 @@ def main():
     stats = os.path.join(go, f"prof_{tag}", "bench_kernel_stats.csv")
     if os.path.exists(stats):
         shutil.copy(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
+    seq = os.path.join(go, f"prof_{tag}_seq", "bench_kernel_stats.csv")
+    if os.path.exists(seq):
+        shutil.copy(seq, os.path.join(out, f"{tag}_kernel_stats_sequential.csv"))
+    sj = os.path.join(go, f"prof_{tag}_seq_bench.json")
+    if os.path.exists(sj):
+        shutil.copy(sj, os.path.join(out, f"{tag}_bench_sequential_under_rocprof.json"))
     bj = os.path.join(go, f"prof_{tag}_bench.json")
     if os.path.exists(bj):
         shutil.copy(bj, os.path.join(out, f"{tag}_bench_under_rocprof.json"))
