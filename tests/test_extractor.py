@@ -216,3 +216,54 @@ def test_run_ocr_tasks_with_uploader_equals_host_stacking():
     a = extractor.run_ocr_tasks(src, tasks, Ocr(), batch=4)
     b = extractor.run_ocr_tasks(src, tasks, OcrBatched(), batch=4, uploader=FakeUploader())
     assert a == b and len(a) == 13
+
+
+def test_run_ocr_tasks_uses_predict_stream_in_batch_order():
+    """A recogniser with predict_stream (detector of the next batches in flight) is fed the staged batches as a generator and
+    its results are matched back in batch order; same lines as frame by frame."""
+    from vse_amd import extractor
+
+    class Staged:
+        def __init__(self, frames):
+            self.frames = frames
+
+        def tensor(self):
+            return np.stack(self.frames)
+
+    class FakeUploader:
+        def bind_thread(self):
+            pass
+
+        def stage(self, frames):
+            return Staged([np.array(f) for f in frames])
+
+    class Ocr:
+        def predict(self, frame):
+            v = int(frame[0, 0, 0])
+            return [[(v, v), (v + 30, v), (v + 30, v + 10), (v, v + 10)]], [(f"t{v}", 0.9)]
+
+    class OcrStreamed(Ocr):
+        seen = []
+
+        def predict_batch(self, frames):
+            raise AssertionError("the streamed form must be preferred")
+
+        def predict_stream(self, batches):
+            held = []
+            for b in batches:                          # one batch ahead, like a detector in flight
+                held.append(b)
+                if len(held) > 1:
+                    f = held.pop(0)
+                    self.seen.append(len(f))
+                    yield [self.predict(x) for x in f]
+            for f in held:
+                self.seen.append(len(f))
+                yield [self.predict(x) for x in f]
+
+    frames = [np.full((8 + 2 * (i // 5), 40, 3), i, np.uint8) for i in range(13)]
+    src = extractor.ArraySource(frames, 10.0)
+    tasks = extractor.fps_tasks(13, 10.0, 10)
+    a = extractor.run_ocr_tasks(src, tasks, Ocr(), batch=4)
+    ocr = OcrStreamed()
+    b = extractor.run_ocr_tasks(src, tasks, ocr, batch=4, uploader=FakeUploader())
+    assert a == b and ocr.seen == [4, 1, 4, 1, 3]          # shape changes close a batch: 5 + 5 + 3 frames of three shapes

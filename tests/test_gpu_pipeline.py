@@ -305,6 +305,18 @@ def test_extractor_on_a_clip_engine_vs_oracle(ctx):
         def predict_batch(self, frames):
             return [shim.OcrRecogniser.arrange(b, r) for b, r in pipe.ocr(frames)]
 
+    class EngineOcrStreamed(EngineOcrBatched):
+        def predict_stream(self, batches):
+            for out in pipe.ocr_stream(batches):
+                yield [shim.OcrRecogniser.arrange(b, r) for b, r in out]
+
+        def predict_with_dets(self, frames, dets):
+            return [shim.OcrRecogniser.arrange(b, r) for b, r in pipe.ocr_from_det(frames, dets)]
+
+    def engine_detect_stream(batches):
+        for dets in pipe.detect_stream(batches):
+            yield [np.asarray(b, np.float32).reshape(-1, 4, 2) for b in dets]
+
     det_fn = lambda x: net_ref.run_graph(det[0], det[1], x)[0].numpy()[0, 0]
     rec_fn = lambda b: net_ref.run_graph(rec[0], rec[1], b)[0].numpy()
 
@@ -336,5 +348,10 @@ def test_extractor_on_a_clip_engine_vs_oracle(ctx):
         staged = extractor.SubtitleExtractor(src, EngineOcrBatched(), detect_batch=engine_detect,
                                              uploader=staging.Uploader(ctx.tdev), **kw)
         assert staged.run() == a and staged.raw_lines == one.raw_lines
+        # ... and with the detectors of the next batches in flight (predict_stream / detect_stream) and, in the accurate mode,
+        # the wanted frames recognised from the boxes the selector's detector already produced
+        streamed = extractor.SubtitleExtractor(src, EngineOcrStreamed(), detect_batch=engine_detect, detect_stream=engine_detect_stream,
+                                               uploader=staging.Uploader(ctx.tdev), **kw)
+        assert streamed.run() == a and streamed.raw_lines == one.raw_lines
         if kw is fps_kw:
             assert geo(many.raw_lines) == geo(ora.raw_lines)

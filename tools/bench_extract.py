@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--single", type=int, default=96, help="frames of the frame-by-frame run (slow)")
+    ap.add_argument("--workers", type=int, default=4, help="copy threads of the pinned-slab uploader")
+    ap.add_argument("--staged-only", action="store_true")
     a = ap.parse_args()
     ctx = engine.Context(0)
     det = modelzoo.get_model("V3_ch_det_fast", seed=0)
@@ -48,24 +50,42 @@ def main():
         def predict_batch(self, frames):
             return [shim.OcrRecogniser.arrange(b, r) for b, r in pipe.ocr(frames)]
 
+    def detect_stream(batches):
+        for dets in pipe.detect_stream(batches):
+            yield [np.asarray(b, np.float32).reshape(-1, 4, 2) for b in dets]
+
+    class OcrStreamed(OcrBatched):
+        def predict_with_dets(self, frames, dets):
+            return [shim.OcrRecogniser.arrange(b, r) for b, r in pipe.ocr_from_det(frames, dets)]
+
+        def predict_stream(self, batches):
+            for out in pipe.ocr_stream(batches):
+                yield [shim.OcrRecogniser.arrange(b, r) for b, r in out]
+
     def detect(frames):
         dev = frames if torch.is_tensor(frames) else torch.from_numpy(np.stack(frames)).to(ctx.tdev)
         return [np.asarray(b, np.float32).reshape(-1, 4, 2) for b in pipe.detect(dev)]
 
     area = extractor.SubtitleArea(ymin=int(0.75 * a.height), ymax=a.height, xmin=0, xmax=a.width)
-    up = staging.Uploader(ctx.tdev)
+    up = staging.Uploader(ctx.tdev, workers=a.workers)
     runs = [
+        ("fps sampler, every frame, staged upload + streamed detector", clip, OcrStreamed(),
+         dict(sub_area=None, mode="fast", extract_frequency=fps, uploader=up)),
         ("fps sampler, every frame, batched, staged upload", clip, OcrBatched(),
          dict(sub_area=None, mode="fast", extract_frequency=fps, uploader=up)),
+        ("accurate mode, staged upload + streamed detector, boxes reused", clip, OcrStreamed(),
+         dict(sub_area=area, mode="accurate", uploader=up, detect_stream=detect_stream)),
         ("accurate mode, batched, staged upload", clip, OcrBatched(), dict(sub_area=area, mode="accurate", uploader=up)),
         ("fps sampler, every frame, batched", clip, OcrBatched(), dict(sub_area=None, mode="fast", extract_frequency=fps)),
         ("fps sampler, every frame, frame by frame", clip[:a.single], Ocr(), dict(sub_area=None, mode="fast", extract_frequency=fps)),
         ("accurate mode, batched", clip, OcrBatched(), dict(sub_area=area, mode="accurate")),
     ]
+    if a.staged_only:
+        runs = runs[:4]
     for name, frames, ocr, kw in runs:
         src = extractor.ArraySource(frames, fps)
         ex = extractor.SubtitleExtractor(src, ocr, detect_batch=detect, drop_score=0.0, batch=a.batch, **kw)
-        ex_warm = extractor.SubtitleExtractor(extractor.ArraySource(frames[:2 * a.batch], fps), ocr, detect_batch=detect,
+        ex_warm = extractor.SubtitleExtractor(extractor.ArraySource(frames[:5 * a.batch], fps), ocr, detect_batch=detect,
                                               drop_score=0.0, batch=a.batch, **kw)
         ex_warm.run()
         torch.cuda.synchronize()

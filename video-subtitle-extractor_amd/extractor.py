@@ -17,6 +17,7 @@ cap.set(CAP_PROP_POS_FRAMES, frame_no - 1); cap.read()) and `frames()` (decode o
 ingest.py reads the lossless containers that need no codec (neither box has cv2 / ffmpeg).
 """
 import re
+from collections import deque
 from types import SimpleNamespace
 
 import numpy as np
@@ -116,9 +117,23 @@ def run_ocr_tasks(source, tasks, ocr, sub_area=None, rec_char_type="ch", drop_sc
             yield pend
 
     if batched and uploader is not None:
-        for items, staged in staging.prefetch(batches(), uploader):
-            for (k, _), r in zip(items, ocr.predict_batch(staged.tensor())):
-                results[k] = r
+        staged = staging.prefetch(batches(), uploader)
+        if hasattr(ocr, "predict_stream"):
+            # the recogniser overlaps the detector of the next batches with the recognition of the current one; results come
+            # back in batch order, so the item lists are matched through a queue
+            pending = deque()
+
+            def tensors():
+                for items, sb in staged:
+                    pending.append(items)
+                    yield sb.tensor()
+            for out in ocr.predict_stream(tensors()):
+                for (k, _), r in zip(pending.popleft(), out):
+                    results[k] = r
+        else:
+            for items, sb in staged:
+                for (k, _), r in zip(items, ocr.predict_batch(sb.tensor())):
+                    results[k] = r
     else:
         for items in batches():
             frames = [f for _, f in items]
@@ -164,7 +179,7 @@ class SubtitleExtractor:
     def __init__(self, source, ocr, detect_batch=None, sub_area=None, mode="fast", language="ch", extract_frequency=3,
                  default_subtitle_area=None, drop_score=0.75, deviation_rate=0.0, threshold=80, batch=64,
                  watermark_decide=None, scene_text_decide=lambda band: True, shard=None, gather_device=None,
-                 word_segmentation=False, segment=None, uploader=None):
+                 word_segmentation=False, segment=None, uploader=None, detect_stream=None):
         self.source, self.ocr, self.detect_batch = source, ocr, detect_batch
         self.sub_area, self.mode, self.language = sub_area, mode, language
         self.extract_frequency, self.default_subtitle_area = extract_frequency, default_subtitle_area
@@ -174,6 +189,9 @@ class SubtitleExtractor:
         # staging.Uploader (or "auto": one on the shim's device when there is a GPU): detect_batch / predict_batch then receive
         # device uint8 tensors [n,H,W,3] staged through pinned memory by a producer thread instead of lists of host frames
         self.uploader = uploader
+        # accurate mode with an uploader: detect_stream(iterable of device batches) -> generator of detect_batch results (the
+        # detector of the next chunks stays in flight); ocr.predict_with_dets, when it exists, recognises from those boxes
+        self.detect_stream = detect_stream
         self.word_segmentation, self.segment = word_segmentation, segment      # config.wordSegmentation (main.py:181-182)
         self.raw_lines = None
         self.short_lines = None
@@ -189,7 +207,9 @@ class SubtitleExtractor:
             up = self._uploader()
             sel = frame_select.AccurateFrameSelector(self.detect_batch, self.ocr.predict, self.sub_area, s.frame_count,
                                                      self.threshold, chunk=self.batch,
-                                                     predict_batch=getattr(self.ocr, "predict_batch", None) and self._predict_list)
+                                                     predict_batch=getattr(self.ocr, "predict_batch", None) and self._predict_list,
+                                                     detect_stream=self.detect_stream,
+                                                     predict_with_dets=getattr(self.ocr, "predict_with_dets", None))
             return [(t[0], t[1], t[2], t[3], None, None) for t in sel.run(s.frames(), uploader=up)]
         return fps_tasks(s.frame_count, s.fps, self.extract_frequency, self.default_subtitle_area)
 

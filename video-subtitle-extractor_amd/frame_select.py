@@ -40,13 +40,20 @@ class AccurateFrameSelector:
     # before the first subtitle / waiting for a start / waiting for the end / last frame consumed while tracking
     IDLE, ARMED, TRACKING, DONE = 0, 1, 2, 3
 
-    def __init__(self, detect_batch, predict, sub_area, frame_count, threshold=80, chunk=64, predict_batch=None):
+    def __init__(self, detect_batch, predict, sub_area, frame_count, threshold=80, chunk=64, predict_batch=None,
+                 detect_stream=None, predict_with_dets=None):
         """detect_batch(list of frames) -> list of ndarray[N,4,2];  predict(frame) -> (boxes, [(text, score)]);
         predict_batch(list of frames) -> list of those (optional: prefetches every frame of a chunk that has an in-area
-        box; the automaton asks for a subset of them)."""
+        box; the automaton asks for a subset of them).
+        With an uploader (run): detect_stream(iterable of device batches) -> generator of detect_batch results keeps the
+        detector of the next chunks in flight while a chunk is resolved, and predict_with_dets(device frames, their detections)
+        -> list of predict results recognises the wanted frames from the boxes the detector already produced (the reference
+        runs the same detector a second time inside predict: same frame, same boxes)."""
         self.detect_batch = detect_batch
         self.predict = predict
         self.predict_batch = predict_batch
+        self.detect_stream = detect_stream
+        self.predict_with_dets = predict_with_dets
         self.area = sub_area
         self.frame_count = frame_count
         self.threshold = threshold / 100.0
@@ -140,21 +147,39 @@ class AccurateFrameSelector:
                 yield buf
         if uploader is not None:
             from . import staging
-            for items, staged in staging.prefetch(chunks(), uploader):
-                self._consume([f for _, f in items], staged.tensor())
+            staged_chunks = staging.prefetch(chunks(), uploader)
+            if self.detect_stream is not None:
+                pending = deque()
+
+                def tensors():
+                    for items, staged in staged_chunks:
+                        dev = staged.tensor()
+                        pending.append((items, dev))
+                        yield dev
+                for dets in self.detect_stream(tensors()):
+                    items, dev = pending.popleft()
+                    self._consume([f for _, f in items], dev, dets)
+            else:
+                for items, staged in staged_chunks:
+                    self._consume([f for _, f in items], staged.tensor())
         else:
             for items in chunks():
                 self._consume([f for _, f in items])
         self._flush(0)
         return self.tasks
 
-    def _consume(self, frames, dev=None):
-        dets = self.detect_batch(frames if dev is None else dev)
-        if self.predict_batch is not None:
+    def _consume(self, frames, dev=None, dets=None):
+        if dets is None:
+            dets = self.detect_batch(frames if dev is None else dev)
+        if self.predict_batch is not None or (dev is not None and self.predict_with_dets is not None):
             want = [i for i, b in enumerate(dets) if self._has_subtitle(b)]
             if want:
                 sub = [frames[i] for i in want] if dev is None else dev[want]
-                for i, r in zip(want, self.predict_batch(sub)):
+                if dev is not None and self.predict_with_dets is not None:
+                    got = self.predict_with_dets(sub, [dets[i] for i in want])
+                else:
+                    got = self.predict_batch(sub)
+                for i, r in zip(want, got):
                     self._prefetched[self._no + 1 + i] = r
         for f, b in zip(frames, dets):
             self._step(f, b)

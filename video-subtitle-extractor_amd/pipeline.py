@@ -290,6 +290,40 @@ class OcrPipeline:
         while queue:
             yield self._finish_maps(*queue.pop(0))
 
+    def detect_stream(self, batches, depth=2):
+        """ocr_stream()'s detector half: yields detect(batch) for each batch, in order, with the detectors of the next `depth`
+        batches in flight — for clients that look at the boxes first and recognise a subset (accurate-mode frame selection)."""
+        t = self.ctx.torch
+        depth = max(1, int(depth))
+        if len(getattr(self, "_det_streams", [])) < depth:
+            self._det_streams = [t.cuda.Stream(device=self.ctx.tdev) for _ in range(depth)]
+        main = t.cuda.current_stream(self.ctx.tdev)
+        queue = []
+
+        def boxes_of(frames, maps, ev):
+            main.wait_event(ev)
+            maps.record_stream(main)
+            n, h, w, _ = frames.shape
+            return [r[0] for r in self.ctx.db_postprocess(maps, h, w, **self.db)]
+        for k, frames in enumerate(batches):
+            st = self._det_streams[k % depth]
+            st.wait_stream(main)
+            with t.cuda.stream(st):
+                maps = self.det_maps(frames, slot=k % (depth + 1))
+                ev = t.cuda.Event()
+                ev.record(st)
+            frames.record_stream(st)
+            queue.append((frames, maps, ev))
+            if len(queue) > depth:
+                yield boxes_of(*queue.pop(0))
+        while queue:
+            yield boxes_of(*queue.pop(0))
+
+    def ocr_from_det(self, frames, det):
+        """ocr(frames) for frames whose detect() result `det` is already known (the same boxes come out of the same frame):
+        box ordering, crops, recognition, drop_score filter."""
+        return self._finish(frames, [list(np.asarray(b, np.float32).reshape(-1, 4, 2)) for b in det])
+
     def _finish_maps(self, frames, maps, ev):
         main = self.ctx.torch.cuda.current_stream(self.ctx.tdev)
         main.wait_event(ev)

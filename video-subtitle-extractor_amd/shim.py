@@ -265,6 +265,10 @@ class SubtitleDetect:
     def detect_subtitle_batch(self, frames):
         return self.text_detector.batch(frames)
 
+    def detect_subtitle_stream(self, batches):
+        """iterable of frame batches -> generator of detect_subtitle_batch() results, next detectors in flight"""
+        return self.text_detector.pipe.detect_stream(batches)
+
 
 class TextDetector:
     def __init__(self, args):
@@ -355,6 +359,11 @@ class PaddleOCR:
     def batch(self, frames):
         return self.pipe.ocr(frames)
 
+    def stream(self, batches):
+        """iterable of frame batches -> generator of batch() results, the detectors of the next batches already in flight
+        (OcrPipeline.ocr_stream)."""
+        return self.pipe.ocr_stream(batches)
+
 
 class OcrRecogniser:
     """backend/tools/ocr.py:9-113."""
@@ -388,6 +397,21 @@ class OcrRecogniser:
         if not self.recogniser:
             self.recogniser = self.init_model()
         return [self.arrange(b, r) for b, r in self.recogniser.batch(frames)]
+
+    def predict_with_dets(self, frames, dets):
+        """predict_batch(frames) for frames whose detector output `dets` is already known (accurate mode: SubtitleDetect ran
+        on them a moment ago with the same detector)."""
+        if not self.recogniser:
+            self.recogniser = self.init_model()
+        return [self.arrange(b, r) for b, r in self.recogniser.pipe.ocr_from_det(frames, dets)]
+
+    def predict_stream(self, batches):
+        """iterable of frame batches (device uint8 [n,H,W,3]) -> generator of predict_batch() results in order, with the
+        detector of the following batches overlapping the recognition of the current one."""
+        if not self.recogniser:
+            self.recogniser = self.init_model()
+        for out in self.recogniser.stream(batches):
+            yield [self.arrange(b, r) for b, r in out]
 
     @classmethod
     def arrange(cls, detection_box, recognise_result):
