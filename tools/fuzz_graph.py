@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--cases", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--hilo", action="store_true", help="fp16 hi + lo weight pairs (the mobile detectors' default)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     if a.gpu:
@@ -248,11 +249,11 @@ def main():
             continue
         try:
             if a.gpu:
-                net = engine.Net(ctx, desc, wts, want_probs=True)
+                net = engine.Net(ctx, desc, wts, want_probs=True, hilo=a.hilo)
                 xt = torch.from_numpy(ir_emul.to_nhwc8(x).astype(np.float16)).to(ctx.tdev)
                 got = net.run(xt)[0].float().cpu().numpy()
             else:
-                prog = compiler.compile_model(desc, wts, n, h, w)
+                prog = compiler.compile_model(desc, wts, n, h, w, hilo=a.hilo)
                 got = ir_emul.Emulator(prog).run(ir_emul.to_nhwc8(x))[0]
         except compiler.UnsupportedGraph:
             refused += 1
