@@ -93,7 +93,7 @@ def test_params_stream_round_trip(tmp_path):
         assert back[k].dtype == t[k].dtype and back[k].shape == t[k].shape and (back[k] == t[k]).all()
     with open(path, "ab") as f:                     # trailing bytes = a different tensor list than the graph's: refuse
         f.write(b"\0\0\0\0")
-    with pytest.raises(AssertionError):
+    with pytest.raises(ValueError, match="bytes left"):
         paddle_io.parse_params(path, sorted(t))
 
 

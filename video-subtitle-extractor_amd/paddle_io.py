@@ -204,12 +204,16 @@ def parse_params(path, names_sorted):
         pos += 4
         dtype, dims = _parse_tensor_desc(buf[pos:pos + dlen])
         pos += dlen
+        if dtype not in _DT:
+            raise ValueError(f"{path}: tensor {name} has unsupported Paddle dtype code {dtype}")
         npdt = _DT[dtype]
         cnt = int(np.prod(dims)) if dims else 1
         arr = np.frombuffer(buf, dtype=npdt, count=cnt, offset=pos).reshape(dims).copy()
         pos += cnt * np.dtype(npdt).itemsize
         out[name] = arr
-    assert pos == len(buf), f"pdiparams not consumed to EOF ({pos} != {len(buf)})"
+    if pos != len(buf):
+        raise ValueError(f"{path}: {len(buf) - pos} bytes left after the {len(names_sorted)} tensors the graph declares "
+                         "(the weight file belongs to a different graph)")
     return out
 
 
