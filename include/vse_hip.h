@@ -74,7 +74,9 @@ int vse_plan_create(vse_ctx* ctx, int weights_id, const vse_op* ops, int n_ops, 
 void vse_plan_destroy(vse_plan* plan);
 
 /* Run the network: `ws` is a device workspace of >= ws_bytes, ext[0] the fp16 NHWC(8) input, ext[1..] the
- * output buffers.  Replaces the Paddle predictor.run() inside paddleocr predict_det.py / predict_rec.py,
+ * output buffers.  The caller zero-fills `ws` ONCE before its first use with a plan (channel-padding lanes that no kernel
+ * writes are read against zero weights and must hold finite values) and gives every run that may be in flight at the same
+ * time its own workspace; a plan keeps no state between runs.  Replaces the Paddle predictor.run() inside paddleocr predict_det.py / predict_rec.py,
  * i.e. the device work behind backend/tools/subtitle_detect.py:25 and backend/tools/ocr.py:27. */
 int vse_plan_run(vse_plan* plan, void* ws, void* const* ext, int n_ext, void* stream);
 
