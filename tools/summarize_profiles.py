@@ -78,9 +78,20 @@ def main():
         dur = collections.defaultdict(float)
         launches = collections.Counter()
         seen = set()
+        # launches of >= 100 us on their own: the GRBM counter of a short launch also covers the profiler's own activity
+        # around it, so the effective clock is taken from the long ones
+        lcnt = collections.defaultdict(lambda: collections.defaultdict(float))
+        ldur = collections.defaultdict(float)
+        lseen = set()
         for r in csv.DictReader(open(sq)):
             k = short(r["Kernel_Name"])
             cnt[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            if d >= 100000:
+                lcnt[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Dispatch_Id"] not in lseen:
+                    lseen.add(r["Dispatch_Id"])
+                    ldur[k] += d
             if r["Dispatch_Id"] not in seen:
                 seen.add(r["Dispatch_Id"])
                 dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -99,6 +110,13 @@ def main():
                      "wave_wait_any": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 3),
                      "wave_wait_inst_any": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3),
                      "wave_active_inst_any": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3)}
+            if ldur.get(k) and lcnt[k].get("GRBM_GUI_ACTIVE"):
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs (a bandwidth-bound fill kernel reads 8 x 2.41 cycles per ns: the
+                # maximum clock); MI355X_MICROARCH.md: effective clock = GRBM_GUI_ACTIVE / wall time
+                clk = lcnt[k]["GRBM_GUI_ACTIVE"] / 8.0 / ldur[k]
+                ks[k]["effective_clock_ghz"] = round(clk, 3)
+                ks[k]["mfma_busy_of_elapsed_shader_cycles"] = round(lcnt[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) /
+                                                                    (ldur[k] * clk * 1024), 4)
         conv = [k for k in ks if k.startswith("conv_")]
         tot_busy = sum(cnt[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) for k in conv)
         tot_dur = sum(dur[k] for k in conv)
@@ -106,7 +124,10 @@ def main():
             json.dump({"method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
                                  "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE over "
                                  "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline`; "
-                                 "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (duration_ns * 2.4 * 1024 SIMDs)",
+                                 "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (duration_ns * 2.4 * 1024 SIMDs), i.e. against the peak at "
+                                 "the 2.4 GHz maximum clock; effective_clock_ghz = GRBM_GUI_ACTIVE / 8 XCDs / duration over launches "
+                                 ">= 100 us (DVFS: the chip clocks to its power budget), mfma_busy_of_elapsed_shader_cycles = the "
+                                 "same busy cycles against the cycles that actually elapsed",
                        "all_conv_kernels_mfma_busy_frac": round(tot_busy / (tot_dur * 2.4 * 1024), 4) if tot_dur else None,
                        "kernels": ks}, fh, indent=1)
     print("wrote", sorted(os.listdir(out)))
