@@ -158,6 +158,9 @@ def test_streaming_form_is_identical(ctx):
     rec = net_ref.get_weights("V4_en_rec_fast")
     pipe = pipeline.OcrPipeline(ctx, det, rec, P.en_charset(), rec_mode="bucketed")
     batches = [torch.from_numpy(synth.make_frames(3, 720, 1280, seed=40 + k, p_two_lines=0.5)).cuda() for k in range(5)]
+    # a clip may change shape between batches (a short last batch, another resolution): plans and workspace slots are per shape
+    batches[2] = torch.from_numpy(synth.make_frames(2, 540, 960, seed=47, p_two_lines=0.5)).cuda()
+    batches[4] = batches[4][:1]
     seq = [pipe.ocr(b) for b in batches]
     for depth in (1, 2, 3):                         # detector batches in flight (default 2): slots and streams rotate
         got = list(pipe.ocr_stream(iter(batches), depth=depth))
