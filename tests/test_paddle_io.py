@@ -1,6 +1,5 @@
 """Paddle inference data formats read without Paddle (paddle_io.py) and the shim's model-directory loading
 (det_model_dir / rec_model_dir of backend/tools/ocr.py:93-99 are DIRECTORIES holding inference.pdmodel + inference.pdiparams)."""
-import json
 import os
 import struct
 

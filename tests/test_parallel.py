@@ -1,6 +1,5 @@
 """N>1 path on CPU: frame sharding + the single variable-length gather, world_size 2 over gloo."""
 import os
-import sys
 
 import numpy as np
 import torch.multiprocessing as mp

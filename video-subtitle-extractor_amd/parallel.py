@@ -6,7 +6,6 @@ step is the final variable-length gather of per-frame records (boxes, scores, te
 an all_gather of byte counts followed by an all_gather of one padded uint8 tensor (RCCL over xGMI when the
 backend is "nccl"; gloo in the CPU tests).  ~100 B/frame: latency-bound, so it is done once per job/chunk.
 """
-import json
 import struct
 
 import numpy as np
