@@ -184,9 +184,17 @@ class Emulator:
             if int(r["flags"]) & ir.F_HILO:           # w = hi + lo (the lo tiles follow the hi tiles)
                 wt = wt + self.wread(int(r["w_off"]) + 2 * cnt, cnt, np.float16).astype(np.float32)
             wmat = wt.reshape(Kp // kt, Np, kt).transpose(1, 0, 2).reshape(Np, Kp)[:, :kh * kw * cinp]
-        w4 = torch.from_numpy(np.ascontiguousarray(wmat.reshape(Np, kh, kw, cinp).transpose(0, 3, 1, 2)))
         bias = torch.from_numpy(self.wread(int(r["b_off"]), Np, np.float32).copy())
-        y = F.conv2d(x.permute(0, 3, 1, 2), w4, bias, (sh, sw), (ph, pw)).permute(0, 2, 3, 1)
+        if int(r["flags"]) & ir.F_IMGW:
+            # per-image weights written by OP_WSCALE into the workspace (in2): [N][Kp/kt][Np][kt]
+            assert (kh, kw) == (1, 1)
+            kt = 32 if int(r["flags"]) & ir.F_WK32 else KT
+            wimg = self.read(r["in2"]).reshape(x.shape[0], Kp // kt, Np, kt).permute(0, 2, 1, 3).reshape(x.shape[0], Np, Kp)[:, :, :cinp]
+            y = torch.stack([F.conv2d(x[n:n + 1].permute(0, 3, 1, 2), wimg[n].reshape(Np, cinp, 1, 1).float(), bias)[0]
+                             for n in range(x.shape[0])]).permute(0, 2, 3, 1)
+        else:
+            w4 = torch.from_numpy(np.ascontiguousarray(wmat.reshape(Np, kh, kw, cinp).transpose(0, 3, 1, 2)))
+            y = F.conv2d(x.permute(0, 3, 1, 2), w4, bias, (sh, sw), (ph, pw)).permute(0, 2, 3, 1)
         y = _act(y, int(p[ir.P_ACT]), float(f[ir.FS_ACT_A]), float(f[ir.FS_ACT_B]))
         y = y * float(f[ir.FS_POST_A]) + float(f[ir.FS_POST_B])
         flags = int(r["flags"])
@@ -326,6 +334,16 @@ class Emulator:
                 h = h.half().float()
             out[:, 0, t] = h
         self.write(r["out"], out)
+
+    def _op13(self, r):  # WSCALE: per-image 1x1 weights = tiled weight blob x SE gate over k, rounded to fp16 once
+        p = r["p"]
+        Kp, Np, kt = int(p[0]), int(p[1]), int(p[2])
+        w = self.wread(int(r["w_off"]), Kp * Np, np.float16).astype(np.float32).reshape(Kp // kt, Np, kt)
+        g = self.read(r["in0"]).float().reshape(-1, int(r["in0"]["c"]))               # [N, C]
+        gk = torch.zeros(g.shape[0], Kp)
+        gk[:, :g.shape[1]] = g
+        out = torch.from_numpy(w).unsqueeze(0) * gk.reshape(-1, Kp // kt, 1, kt)       # [N, Kp/kt, Np, kt]
+        self.write(r["out"], out.half().float().reshape(g.shape[0], 1, 1, Kp * Np))
 
 
 def to_nhwc8(x_nchw):

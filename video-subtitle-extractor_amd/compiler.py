@@ -151,6 +151,7 @@ PATCH_LIGHT = int(os.environ.get("VSE_PATCH_LIGHT", "2"))
 # the patch kernel (experiments / A-B)
 STEM = os.environ.get("VSE_STEM", "1") != "0"         # conv_stem_kernel for 3x3 convs over <= 4 real channels
 GATE_DW = os.environ.get("VSE_GATE_DW", "1") != "0"   # SE gate folded into a depthwise consumer
+GATE_FOLD = os.environ.get("VSE_GATE_FOLD", "1") != "0"   # SE gate whose consumers are a depthwise conv and 1x1 convs: folded into them
 WK32 = os.environ.get("VSE_WK32", "1") != "0"      # 32-deep weight tiles for conv_gemm_kernel (contiguous wave DMAs)
 HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
 COL = os.environ.get("VSE_COL", "1") != "0"           # conv_col_kernel (one filter column per step) for 9x9 / 7x7 / 5x5 layers
@@ -223,6 +224,7 @@ class Compiler:
         self.merged_gmac_credit = {}          # merged conv weight name -> algorithmic MAC factor of the original branches
         self.hilo = False                     # fp16 hi + lo weight pairs (compile_model(hilo=True))
         self.pending_gate = {}                # SE output name -> gate view its depthwise consumer applies on load (F_GATE)
+        self.pending_wgate = {}               # SE output name -> gate view its 1x1 conv consumers fold into per-image weights (F_IMGW)
         self._merge_parallel_convs()
         self.N, self.H, self.Wd = batch, height, width
         self.fetch_cols = tuple(fetch_cols)
@@ -705,6 +707,36 @@ class Compiler:
             return hi
         return np.concatenate([hi, (out.reshape(-1) - hi.astype(np.float64)).astype(np.float16)])
 
+    def _is_dw(self, o2, c):
+        if o2["type"] not in ("conv2d", "depthwise_conv2d"):
+            return False
+        w2 = self.W[o2["in"]["Filter"][0]]
+        g2 = o2["attrs"].get("groups", 1)
+        return (o2["type"] == "depthwise_conv2d" or (g2 > 1 and g2 == w2.shape[0])) and w2.shape[1] == 1 and w2.shape[0] == c
+
+    def _gate_foldable(self, name, big, flags):
+        """The SE output `name` (= big * gate) is read only by consumers that can apply the gate themselves: at most one
+        depthwise conv and any number of plain 1x1 stride-1 convs that run on conv_gemm_kernel over the whole dense tensor."""
+        if flags or name in self.placement or big.up or big.segs != [(0, big.c)] or big.span != big.c or big.c % 64 or big.c <= 64 or self.hilo:
+            return False
+        cons = self._live_consumers(name)
+        n_dw = n_pw = 0
+        for j in cons:
+            o2 = self.ops[j]
+            if o2["type"] not in ("conv2d", "depthwise_conv2d") or o2["in"]["Input"][0] != name:
+                return False
+            if self._is_dw(o2, big.c):
+                n_dw += 1
+                continue
+            a2 = o2["attrs"]
+            w2 = self.W[o2["in"]["Filter"][0]]
+            pads = a2["paddings"]
+            if (o2["type"] != "conv2d" or a2.get("groups", 1) != 1 or tuple(w2.shape[1:]) != (big.c, 1, 1) or list(a2["strides"]) != [1, 1]
+                    or any(pads) or big.h * big.w < 256):
+                return False
+            n_pw += 1
+        return n_dw <= 1 and n_pw >= 1
+
     @staticmethod
     def gemm_eligible(kh, kw, ph, pw, cinp, inshift, flags):
         """Mirror of conv_gemm_mode() (csrc/conv_gemm.hip): the layer runs on conv_gemm_kernel.  The launcher refuses an
@@ -954,7 +986,8 @@ class Compiler:
             while len(ins) < 2:
                 ins.append(None)
             ins.append(inv.parts[1])
-        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch_std and th == 16 and coutp <= 128) else None
+        # (conv_patch_kernel's fused projection: one cout tile, no residual — launch_conv_patch refuses the rest)
+        dot = self._try_fuse_dot1(ep["out_name"], cout, coutp) if (patch_std and th == 16 and coutp <= pbn and res is None) else None
         if patch:
             # taps padded to whole kernel steps (2 taps in the LIGHT variant, else 4), channels to 32
             light = light_ok and dot is None
@@ -1006,6 +1039,20 @@ class Compiler:
             w_off = self.add_weights(("conv", wname, tuple(inv.segs), ep["out_name"], wk32, self.hilo),
                                      lambda: self.tile_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], 32 if wk32 else ir.KT,
                                                                hilo=self.hilo))
+            wgate = self.pending_wgate.get(op["in"]["Input"][0])
+            if wgate is not None:
+                # the input is an SE output whose gate multiply was left to its consumers (_gate_foldable): this image's
+                # weights = W * gate (OP_WSCALE, fp16), read by conv_gemm_kernel through M tiles aligned to images (F_IMGW)
+                assert (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and dot is None and not (flags & ~(ir.F_RES | ir.F_WK32))
+                assert self.gemm_eligible(kh, kw, ph, pw, inv.span, inv_main.up, flags), outname
+                wbuf = self.new_buf(inv.n, 1, 1, Kp * coutp, esize=2)
+                wview = View(wbuf, 0, inv.n, 1, 1, [(0, Kp * coutp)], Kp * coutp)
+                self.emit(ir.OP_WSCALE, ep["out_name"] + ":wgate", [wgate], wview, p={0: Kp, 1: coutp, 2: 32 if wk32 else ir.KT},
+                          w_off=w_off)
+                flags |= ir.F_IMGW
+                while len(ins) < 2:
+                    ins.append(None)
+                ins.append(wview)
         b_off = self.add_weights(("convb", wname, ep["out_name"]), bias)
         if dot is not None:
             aux_off = self.add_weights(("dot1", dot["wname"], ep["out_name"]), dot["w"])
@@ -1255,6 +1302,16 @@ class Compiler:
                         self.pending_gate[outname] = (gate, flags)
                         self.env[outname] = big
                         return
+            if GATE_FOLD and self._gate_foldable(outname, big, flags):
+                # every consumer applies the gate itself: the depthwise conv on load (F_GATE), the 1x1 convs through per-image
+                # weights W * gate (OP_WSCALE + F_IMGW) — the scaled tensor (a full read + write of the stage output) is never made
+                for j in cons2:
+                    if self._is_dw(self.ops[j], big.c):
+                        self.pending_gate[outname] = (gate, flags)
+                    else:
+                        self.pending_wgate[outname] = gate
+                self.env[outname] = big
+                return
             out = self.alloc_out(outname, big.n, big.h, big.w, big.c)
             self.emit(ir.OP_SCALE, outname, [big, gate], out, flags=flags)
             self.env[outname] = out

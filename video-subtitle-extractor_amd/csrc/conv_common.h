@@ -30,6 +30,8 @@ struct ConvParams {
     int in2_ld, in2_shift, in2_hs, in2_ws, nv0;
     unsigned long long* trace;   // -DVSE_TRACE builds only: per-block phase stamps
     int vec16;              // output (and residual) rows allow 16-byte accesses at every 8-channel group
+    long wimg_stride;       // F_IMGW: weight elements per image (Kp * Np); M tiles are then aligned to images
+    int hw_img, tiles_img;  // F_IMGW: output pixels per image, M tiles per image
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

@@ -71,7 +71,16 @@ void conv_gemm_kernel(const ConvParams p) {
     const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
     const unsigned logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     const unsigned mtile = logical / p.ntn, ntile = logical - mtile * p.ntn;
-    const long m0 = (long)mtile * BM;
+    // F_IMGW (per-image weights): M tiles are aligned to images, so that one tile has one weight matrix
+    long m0 = (long)mtile * BM;
+    long mend = p.M;                                 // rows at or beyond it do not exist
+    const half_t* wsrc = p.w;
+    if (p.flags & F_IMGW) {
+        const unsigned img = mtile / (unsigned)p.tiles_img, ti = mtile - img * (unsigned)p.tiles_img;
+        m0 = (long)img * p.hw_img + (long)ti * BM;
+        mend = (long)(img + 1) * p.hw_img;
+        wsrc += (long)img * p.wimg_stride;
+    }
     const int n0 = ntile * BN;
 
     // LDS image: row-major [row][BKT halfs], 16-byte slots XOR-swizzled by the row so that the MFMA fragment reads
@@ -92,10 +101,10 @@ void conv_gemm_kernel(const ConvParams p) {
     }
 #if VSE_GEMM_ASM
     const rsrc4_t rsA = make_rsrc4(p.in + pix0 * p.in_ld);
-    const rsrc4_t rsW = make_rsrc4(p.w + (long)n0 * ((p.flags & F_WK32) ? 32 : 64));
+    const rsrc4_t rsW = make_rsrc4(wsrc + (long)n0 * ((p.flags & F_WK32) ? 32 : 64));
 #else
     const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + pix0 * p.in_ld), 0, 0x7fffffff, 0x00020000);
-    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)n0 * ((p.flags & F_WK32) ? 32 : 64)), 0, 0x7fffffff, 0x00020000);
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(wsrc + (long)n0 * ((p.flags & F_WK32) ? 32 : 64)), 0, 0x7fffffff, 0x00020000);
 #endif
 
     // ---- per-thread, loop-invariant offsets ------------------------------------------------------------------
@@ -110,7 +119,7 @@ void conv_gemm_kernel(const ConvParams p) {
         const long m = m0 + r;
         voffA[j] = OOB;
         ntap[j] = 0xffffffffu;
-        if (m < p.M) {
+        if (m < mend) {
             const int ow = (int)(m % p.OW);
             const long t = m / p.OW;
             const int oh = (int)(t % p.OH);
@@ -282,7 +291,7 @@ void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const long m = m0 + wm * WTM + i * 32 + (lane & 31);
-        if (m >= p.M) continue;
+        if (m >= mend) continue;
         const int ow = (int)(m % p.OW);
         const long t = m / p.OW;
         const int oh = (int)(t % p.OH);
@@ -378,7 +387,12 @@ int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st) {
     p.nk = Kp / g.bk;
     p.nkh = p.nk;
     if (p.flags & F_HILO) p.nk *= 2;
-    const unsigned long long tiles = (unsigned long long)((p.M + g.bm - 1) / g.bm) * p.ntn;
+    unsigned long long tiles = (unsigned long long)((p.M + g.bm - 1) / g.bm) * p.ntn;
+    if (p.flags & F_IMGW) {
+        if (mode != 2 || p.hw_img <= 0 || p.M % p.hw_img) return VSE_E_UNSUPPORTED;      // unmasked 1x1 only
+        p.tiles_img = (p.hw_img + g.bm - 1) / g.bm;
+        tiles = (unsigned long long)(p.M / p.hw_img) * p.tiles_img * p.ntn;
+    }
     if (tiles == 0 || tiles > 0x7fffffffull) return VSE_E_INVAL;
     dim3 grid((unsigned)tiles);
     switch (c) {

@@ -3,6 +3,7 @@
 // arg-max, LSTM recurrence.  One thread handles one 16-byte (8-channel) vector of one pixel wherever the
 // layout allows it, so a wave reads/writes 1 KiB per instruction with consecutive lanes on consecutive
 // channel groups of the same pixel (coalesced NHWC).
+#include <stdlib.h>
 #include "common.h"
 
 #define GRID_CAP 16384
@@ -34,6 +35,15 @@ __device__ __forceinline__ half8 dw_gate(half8 x, const half8& g, int mode) {
         }
     }
     return x;
+}
+// Compile-time gate mode for the row kernel: 1 = x * g as FOUR packed fp16 multiplies per vector (the product of two fp16 values is
+// exact in fp32, so one rounding to fp16 either way; the fp32 form costs 24 conversions / multiplies per vector and made the gated
+// stage-transition conv of the detector VALU-bound: 0.58 vs 0.34 ms); a run-time switch between the forms cost the UNGATED kernel
+// 60 % (0.34 -> 0.55 ms: register allocation), hence the template parameter.
+template <int GM> __device__ __forceinline__ half8 dw_gate_t(half8 x, const half8& g) {
+    if constexpr (GM == 1) return x * g;
+    else if constexpr (GM == 2) return dw_gate(x, g, 2);
+    else return x;
 }
 __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView gate, int gmode, int hilo, const half_t* __restrict__ w,
                                                      const float* __restrict__ bias, int kh, int kw, int sh, int sw,
@@ -84,12 +94,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
 // input vector of a filter row is loaded once for the outputs that share it ((4-1)*SW + KW loads instead of 4*KW) and every
 // weight vector once per tap instead of once per output.  Same accumulation order per output as dwconv_kernel (bias, then
 // taps row-major) -> bit-identical results.  The mobile (PP-LCNetV3 / MobileNetV3) models spend half of their time here.
-template <int KW, int SW>
-__global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TView gate, int gmode, int hilo, const half_t* __restrict__ w,
+template <int KW, int SW, int GM>
+__global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TView gate, int hilo, const half_t* __restrict__ w,
                                                          const float* __restrict__ bias, int kh, int sh, int ph, int pw,
                                                          int act, float act_a, float act_b, float post_a, float post_b) {
     constexpr int OUTW = 4, WIN = (OUTW - 1) * SW + KW;
-    const int gated = gate.ptr != nullptr ? gmode : 0;
     const int cg = in.c >> 3;
     const int owq = (out.w + OUTW - 1) / OUTW;
     const long total = (long)out.n * out.h * owq * cg;
@@ -106,7 +115,7 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
         for (int o = 0; o < OUTW; ++o)
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[o][e] = bias[g * 8 + e];
-        const half8 gv = gated ? ld8(gate, n, g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+        const half8 gv = GM ? ld8(gate, n, g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
         for (int dy = 0; dy < kh; ++dy) {
             const int ih = oh * sh - ph + dy;
             if (ih < 0 || ih >= in.h) continue;
@@ -115,7 +124,14 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
 #pragma unroll
             for (int c = 0; c < WIN; ++c) {
                 const int iw = iw0 + c;
-                x[c] = (iw >= 0 && iw < in.w) ? dw_gate(ld8(in, rowpix + iw, g * 8), gv, gated) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+                x[c] = (iw >= 0 && iw < in.w) ? ld8(in, rowpix + iw, g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            // all loads of the row first, arithmetic afterwards: multiplying each vector as it arrives serialises the loads
+            // (the kernel is HBM-bound on the detector's maps: 0.52 ms gated against 0.32 ms with the loads batched)
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (GM != 0) {
+#pragma unroll
+                for (int c = 0; c < WIN; ++c) x[c] = dw_gate_t<GM>(x[c], gv);
             }
 #pragma unroll
             for (int dx = 0; dx < KW; ++dx) {
@@ -515,6 +531,25 @@ __global__ __launch_bounds__(256) void lstm_kernel(TView gates, TView out, const
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
+// OP_WSCALE: per-image 1x1 conv weights = the tiled weight blob [Kp/kt][Np][kt] times the image's SE gate over k (rounded to fp16
+// once, like the separate gate multiply rounds its products).  One thread per 8 consecutive k of one cout row.
+__global__ __launch_bounds__(256) void wscale_kernel(const half_t* __restrict__ w, TView gate, half_t* __restrict__ out, int n_img,
+                                                     int Kp, int Np, int kt) {
+    const long per = (long)Kp * Np / 8;
+    const long total = per * n_img;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / per);
+        const long e = (i - (long)n * per) * 8;                  // element index inside the tiled blob
+        const int k = (int)(e / ((long)Np * kt)) * kt + (int)(e % kt);
+        const half8 wv = *reinterpret_cast<const half8*>(w + e);
+        const half_t* g = reinterpret_cast<const half_t*>(gate.ptr) + (long)n * gate.ld;
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)wv[j] * (k + j < gate.c ? (float)g[k + j] : 0.f));
+        *reinterpret_cast<half8*>(out + (long)n * Kp * Np + e) = o;
+    }
+}
+
 int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const TView& in2, const TView& out,
                      const TView& out2, const char* wbase, hipStream_t st) {
     const int* p = op.p;
@@ -534,8 +569,13 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             if ((kw == 3 || kw == 5) && (sw == 1 || sw == 2)) {
                 const long items4 = (long)out.n * out.h * ((out.w + 3) / 4) * (in0.c >> 3);
                 const dim3 g4(grid_for(items4, 256)), b4(256);
-#define DW_ROW(KW_, SW_) hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_>), g4, b4, 0, st, in0, out, gate, gmode, hilo, wk, bk, p[P_KH], p[P_SH], \
-                                            p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B])
+#define DW_ROW(KW_, SW_) do { \
+                    if (!gate.ptr) hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_, 0>), g4, b4, 0, st, in0, out, gate, hilo, wk, bk, p[P_KH], p[P_SH], \
+                                                      p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B]); \
+                    else if (gmode == 1) hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_, 1>), g4, b4, 0, st, in0, out, gate, hilo, wk, bk, p[P_KH], \
+                                                            p[P_SH], p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B]); \
+                    else hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_, 2>), g4, b4, 0, st, in0, out, gate, hilo, wk, bk, p[P_KH], p[P_SH], \
+                                            p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B]); } while (0)
                 if (kw == 3 && sw == 1) DW_ROW(3, 1);
                 else if (kw == 3) DW_ROW(3, 2);
                 else if (sw == 1) DW_ROW(5, 1);
@@ -625,6 +665,14 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             if (H > 256) return VSE_E_UNSUPPORTED;
             hipLaunchKernelGGL(lstm_kernel, dim3(in0.n), dim3(256), H * sizeof(float), st, in0, out,
                                reinterpret_cast<const half_t*>(wbase + op.w_off), H, p[1]);
+            break;
+        }
+        case OP_WSCALE: {
+            const int Kp = p[0], Np = p[1], kt = p[2];
+            if (Kp <= 0 || Np <= 0 || (kt != 32 && kt != 64) || Kp % kt || in0.esize != 2 || out.esize != 2) return VSE_E_INVAL;
+            const long items = (long)in0.n * Kp * Np / 8;
+            hipLaunchKernelGGL(wscale_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st,
+                               reinterpret_cast<const half_t*>(wbase + op.w_off), in0, reinterpret_cast<half_t*>(out.ptr), in0.n, Kp, Np, kt);
             break;
         }
         default:

@@ -118,7 +118,7 @@ int vse_plan_create(vse_ctx* c, int weights_id, const vse_op* ops, int n_ops, si
     const size_t wbytes = c->weight_bytes[weights_id];
     for (int i = 0; i < n_ops; ++i) {
         const vse_op& o = ops[i];
-        if (o.kind < OP_CONV || o.kind > OP_LSTM) {
+        if (o.kind < OP_CONV || o.kind > OP_WSCALE) {
             set_err("op %d: unknown kind %d", i, o.kind);
             delete p;
             return VSE_E_INVAL;
@@ -178,6 +178,7 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, hipStream_t st
         a.dotw = reinterpret_cast<const float*>(wts + o.aux_off);
         a.dotb = o.f[FS_PRE_B]; a.dotact = o.p[P_DOTACT]; a.dot_out = out2;
         a.in2 = in2; a.in2shift = o.p[P_IN2SHIFT];
+        if (o.flags & F_IMGW) a.w = reinterpret_cast<const half_t*>(in2.ptr);      // per-image weights in the workspace
         rc = launch_conv(a, st);
     } else {
         rc = launch_simple_op(o, in0, in1, in2, out, out2, wts, st);

@@ -20,6 +20,8 @@ OP_LAYERNORM = 9  # over channels
 OP_ATTN = 10      # fused multi-head self-attention over T (SVTR mixer)
 OP_SOFTMAX = 11   # class softmax -> fp32 probs (optional) + argmax + max prob
 OP_LSTM = 12      # one direction of one LSTM layer (recurrent part; input projection is an OP_CONV)
+OP_WSCALE = 13    # per-image conv weights: out[n][e] = fp16(W[e] * gate[n][k(e)]) over the tiled 1x1 weight blob at w_off
+                  # ([Kp/kt][Np][kt], kt = p[2]); in0 = SE gate [N,1,1,C], out = [N,1,1,Kp*Np] in the workspace; p[0] = Kp, p[1] = Np
 
 ACT_NONE, ACT_RELU, ACT_HSWISH, ACT_SWISH, ACT_SIGMOID, ACT_HSIGMOID = 0, 1, 2, 3, 4, 5
 
@@ -71,6 +73,8 @@ F_GATE = 256        # OP_DWCONV: in1 = SE gate [N,1,1,C]; the input is multiplie
                     # separate OP_SCALE pass of an SE block whose only consumer is this depthwise conv disappears
 F_WK32 = 128        # weights tiled [Kp/32][Np][32] (one wave DMA = 1 KiB contiguous) for conv_gemm_kernel; else [Kp/64][Np][64]
 F_PW = 4096         # pointwise conv over <= 64 input channels / <= 64 couts (conv_pw.hip): weights plain [Np][cinp] fp16
+F_IMGW = 8192       # OP_CONV (1x1 on conv_gemm_kernel): weights differ per image and come from in2 ([N,1,1,Kp*Np], written by
+                    # OP_WSCALE): an SE gate folded into its 1x1 consumer; M tiles do not straddle images
 F_COL = 2048        # column-per-step LDS-patch kernel (conv_col.hip): weights packed [cinp/16][kw][kh][Np][16] + 3 zero stages
 F_UP2HEAD = 64      # F_SRC2 | F_DOT1 3x3 conv over [1-channel full-res map, x2-upsampled 64-channel map] evaluated on the LOW-RES
                     # grid: weights packed [chunk][parity][2x2 tap][Np][32] + [Np][32] for the 1-channel source (conv_head.hip)
