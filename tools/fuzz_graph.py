@@ -151,7 +151,7 @@ def random_graph(rng, h, w):
     c, ls = c0, 1
     hist.append((cur, c, ls))
     for _ in range(int(rng.integers(3, 12))):
-        kind = pick(["conv", "conv", "conv", "conv1", "dw", "pool", "res", "cat", "se", "fpn", "deconv", "scale", "conv9"])
+        kind = pick(["conv", "conv", "conv", "conv1", "dw", "pool", "res", "cat", "se", "sefold", "fpn", "deconv", "scale", "conv9"])
         hh, ww = hw()
         if kind == "conv":
             k = pick([(3, 3), (3, 3), (5, 5), (1, 3), (3, 1)])
@@ -198,6 +198,19 @@ def random_graph(rng, h, w):
             t = g.act(g.bias(g.conv(gp, c, mid, (1, 1), (1, 1), (0, 0)), mid), mid, "relu")
             t = g.act(g.bias(g.conv(t, mid, c, (1, 1), (1, 1), (0, 0)), c), c, pick(["hard_sigmoid", "sigmoid"]))
             cur = g.binary(cur, t, c, "elementwise_mul", axis=-1)
+        elif kind == "sefold" and hh * ww >= 256:
+            # SE output read only by a depthwise conv and a 1x1 conv: the compiler folds the gate into both (F_GATE + F_IMGW)
+            cse = pick([128, 192, 256])
+            conv_block(c, cse, (1, 1), 1)
+            c = cse
+            gp = g.pool(cur, c, "avg", 1, 1, 0, glob=True)
+            mid = max(8, c // 4)
+            t = g.act(g.bias(g.conv(gp, c, mid, (1, 1), (1, 1), (0, 0)), mid), mid, "relu")
+            t = g.act(g.bias(g.conv(t, mid, c, (1, 1), (1, 1), (0, 0)), c), c, pick(["hard_sigmoid", "sigmoid"]))
+            se = g.binary(cur, t, c, "elementwise_mul", axis=-1)
+            lat = g.act(g.bias(g.conv(se, c, c, (1, 1), (1, 1), (0, 0)), c), c, "relu")
+            dw = g.bn(g.conv(se, c, c, (3, 3), (1, 1), (1, 1), groups=c, typ="depthwise_conv2d"), c)
+            cur = g.binary(lat, dw, c)
         elif kind == "fpn" and ls >= 2:
             big = [t for t in hist if t[2] == ls - 1]
             if big:
