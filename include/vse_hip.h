@@ -80,8 +80,20 @@ void vse_plan_destroy(vse_plan* plan);
  * i.e. the device work behind backend/tools/subtitle_detect.py:25 and backend/tools/ocr.py:27. */
 int vse_plan_run(vse_plan* plan, void* ws, void* const* ext, int n_ext, void* stream);
 
-/* Per-op timing of one run with HIP events on `stream` (synchronises); ms[n_ops] filled. */
-int vse_plan_profile(vse_plan* plan, void* ws, void* const* ext, int n_ext, void* stream, float* ms);
+/* Ragged recogniser batches.  The reference recognises the crops of ONE frame in chunks of rec_batch_num (6,
+ * backend/config.py:58 -> backend/tools/ocr.py:99), every chunk zero-padded to its own widest crop; what a crop's logits are
+ * depends on that padded width (conv borders, SVTR attention span), not on its neighbours.  A plan compiled for ragged batches
+ * takes a batch whose tensor is `Wmax` wide and a device table d_widths[level][n] (int32; level 0 = the padded width sample
+ * n would have had in its reference chunk, further levels = that width behind each stride / pooling step, computed by the
+ * compiler's Program.width_table): every kernel treats x >= width as outside the image, so sample n receives bit for bit the
+ * values a batch of exactly its width yields — crops of many frames share one launch sequence.  vse_plan_run refuses such a plan. */
+int vse_plan_run_ragged(vse_plan* plan, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream);
+/* Number of width levels a ragged plan expects in d_widths (0 for an ordinary plan). */
+int vse_plan_width_levels(vse_plan* plan);
+
+/* Per-op timing of one run with HIP events on `stream` (synchronises); ms[n_ops] filled.  d_widths as for
+ * vse_plan_run_ragged (NULL for an ordinary plan). */
+int vse_plan_profile(vse_plan* plan, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream, float* ms);
 
 /* Which kernel instantiation op `i` dispatches to: for conv ops the BN of conv_mfma_kernel<BM,BN,..> (128/64/32),
  * 0 for every other op kind.  Lets the bench attribute measured time to the kernel names rocprofv3 reports. */

@@ -48,6 +48,7 @@ class Buf:
     first: int = 1 << 30
     last: int = -1
     offset: int = 0
+    wl: Optional[int] = None       # ragged plans: width level of the tensor (index into Program.wlevels); None = no width
 
     @property
     def nbytes(self):
@@ -107,6 +108,31 @@ class Program:
     names: List[str] = field(default_factory=list)      # debug: op -> originating tensor name
     gmacs: float = 0.0              # algorithmic MACs of conv/linear ops (for the roofline)
     op_gmacs: List[float] = field(default_factory=list)   # per op, aligned with `ops`
+    # ragged plans (compile_model(ragged=True)): level 0 = the input width of a sample; level l = (parent, k, s, p, ceil):
+    # width = the output width of a window of k, stride s, padding p over the parent's width.  width_table() evaluates it.
+    wlevels: Optional[list] = None
+    out_level: int = 0              # level of the sequence the class softmax runs over (T of a sample)
+
+    def width_table(self, widths):
+        """int32 [levels][N]: per-sample width of every level for input widths `widths` (len N)."""
+        assert self.wlevels is not None, "not a ragged plan"
+        w0 = np.asarray(widths, dtype=np.int64).reshape(-1)
+        assert w0.shape[0] == self.in_shape[0] and w0.min() >= 1 and w0.max() <= self.in_shape[2], (w0, self.in_shape)
+        tab = np.zeros((len(self.wlevels), w0.shape[0]), np.int64)
+        tab[0] = w0
+        for l in range(1, len(self.wlevels)):
+            parent, k, s, p, ceil = self.wlevels[l]
+            tab[l] = level_width(tab[parent], k, s, p, ceil)
+        return tab.astype(np.int32)
+
+
+def level_width(w, k, s, p, ceil):
+    """Output width of a k-wide window with stride s and padding p over width w (numpy array or int); Paddle's pool2d
+    ceil_mode rule when `ceil` (the last window must start inside the input or its left padding)."""
+    if not ceil:
+        return (w + 2 * p - k) // s + 1
+    o = -(-(w + 2 * p - k) // s) + 1
+    return np.where((o - 1) * s >= w + p, o - 1, o) if isinstance(o, np.ndarray) else (o - 1 if (o - 1) * s >= w + p else o)
 
 
 class WeightStore:
@@ -225,6 +251,11 @@ class Compiler:
         self.hilo = False                     # fp16 hi + lo weight pairs (compile_model(hilo=True))
         self.pending_gate = {}                # SE output name -> gate view its depthwise consumer applies on load (F_GATE)
         self.pending_wgate = {}               # SE output name -> gate view its 1x1 conv consumers fold into per-image weights (F_IMGW)
+        # ragged plans (recognisers): every sample of the batch carries its own width; see ir.P_WLIN / Program.wlevels
+        self.ragged = False
+        self.wlevels = [None]                 # level 0 = the input width
+        self.wlevel_index = {}
+        self.sel_w0 = 320                     # kernel selection of a ragged plan looks at THIS input width, never at the batch's
         self._merge_parallel_convs()
         self.N, self.H, self.Wd = batch, height, width
         self.fetch_cols = tuple(fetch_cols)
@@ -457,10 +488,74 @@ class Compiler:
         r["c"], r["ld"], r["esize"] = v.span, b.ld, b.esize
         return r
 
+    # -------------------------------------------------------------------------------------------- ragged widths
+    def wl_after(self, lvl, k, s, p, ceil=False):
+        """Width level behind a k-wide window (stride s, padding p) over level `lvl`."""
+        if lvl is None:
+            return None
+        if s == 1 and k - 1 == 2 * p:
+            return lvl
+        key = (lvl, k, s, p, bool(ceil))
+        if key not in self.wlevel_index:
+            self.wlevel_index[key] = len(self.wlevels)
+            self.wlevels.append(key)
+        return self.wlevel_index[key]
+
+    def sel_width(self, lvl, actual):
+        """Width the kernel SELECTION sees for a tensor: in a ragged plan the width of level `lvl` for a nominal sample
+        (sel_w0 wide), so that every plan of the model — whatever its batch and widest sample — sends a layer to the same
+        kernel family and therefore sums its products in the same order (results are then bit-identical across batch
+        compositions); otherwise the tensor's own width."""
+        if not self.ragged or lvl is None:
+            return actual
+        def width(l):
+            if l == 0:
+                return self.sel_w0
+            parent, k, s, p, ceil = self.wlevels[l]
+            return int(level_width(width(parent), k, s, p, ceil))
+        return width(lvl)
+
+    def _ragged_levels(self, kind, name, ins, out, out2, flags, p):
+        """Levels of in0 / of the output of one emitted op (ragged plans); refuses what the masked kernels do not cover."""
+        in0 = next((v for v in ins if v is not None), None)
+        lin = in0.buf.wl if in0 is not None else None
+        for v in list(ins) + [out, out2]:
+            if v is not None and (v.up or v.parts is not None):
+                raise UnsupportedGraph(f"ragged plan: {name} reads or writes a virtually upsampled / two-source view")
+        if kind in (ir.OP_CONV, ir.OP_DWCONV):
+            if flags & (ir.F_PIXSHUF | ir.F_DOT1 | ir.F_SRC2 | ir.F_UP2HEAD) or p.get(ir.P_INSHIFT, 0) or p.get(ir.P_RESSHIFT, 0):
+                raise UnsupportedGraph(f"ragged plan: {name} uses a conv form without a per-sample width (transposed / fused head / upsampled)")
+            lout = self.wl_after(lin, p[ir.P_KW], p[ir.P_SW], p[ir.P_PW])
+        elif kind == ir.OP_POOL:
+            lout = self.wl_after(lin, p[ir.P_KW], p[ir.P_SW], p[ir.P_PW], bool(p.get(ir.P_POOL_CEIL, 0)))
+        elif kind in (ir.OP_GAP, ir.OP_WSCALE):
+            lout = None
+        elif kind == ir.OP_BINARY:
+            if p.get(ir.P_BIN_SHIFT, 0):
+                raise UnsupportedGraph(f"ragged plan: {name} adds an upsampled tensor")
+            lout = lin
+        elif kind == ir.OP_RESIZE:
+            if p.get(0, 0):
+                raise UnsupportedGraph(f"ragged plan: {name} upsamples")
+            lout = lin
+        else:
+            lout = lin
+        for v in (out, out2):
+            if v is None:
+                continue
+            if v.buf.wl is not None and v.buf.last >= 0 and v.buf.wl != lout:
+                raise UnsupportedGraph(f"ragged plan: {name} writes level {lout} into a buffer of level {v.buf.wl}")
+            v.buf.wl = lout
+        return lin, lout
+
     def emit(self, kind, name, ins, out, flags=0, p=None, f=None, w_off=0, b_off=0, aux_off=0, out2=None):
         idx = len(self.ir_ops)
         rec = dict(kind=kind, name=name, flags=flags, p=dict(p or {}), f=dict(f or {}), ins=list(ins), out=out,
                    out2=out2, w_off=w_off, b_off=b_off, aux_off=aux_off)
+        if self.ragged:
+            lin, lout = self._ragged_levels(kind, name, ins, out, out2, flags, rec["p"])
+            rec["p"][ir.P_WLIN] = 0 if lin is None else lin + 1
+            rec["p"][ir.P_WLOUT] = 0 if lout is None else lout + 1
         for v in list(ins) + [out, out2]:
             if v is not None and v.buf is not None:
                 v.buf.first = min(v.buf.first, idx)
@@ -1423,6 +1518,7 @@ class Compiler:
         pv = View(pb, 0, B, 1, T, [(0, ncls)], ncls) if pb is not None else None
         iv = View(ib, 0, B, 1, T, [(0, 2)], 2)
         self.emit(ir.OP_SOFTMAX, name, [x], iv, p={ir.P_NCLS: ncls}, out2=pv)
+        self._out_level = x.buf.wl
         self.env[name] = iv
         self._fetched = name
 
@@ -1472,6 +1568,8 @@ class Compiler:
     def compile(self) -> Program:
         N, H, Wd = self.N, self.H, self.Wd
         inb = self.new_buf(N, H, Wd, 8, ext=0)
+        if self.ragged:
+            inb.wl = 0
         for i, op in enumerate(self.ops):
             if i in self.done or not self.live[i]:
                 continue
@@ -1570,7 +1668,8 @@ class Compiler:
             names.append(o["name"])
         return Program(ops=recs, weights=self.store, ws_bytes=int(ws_bytes), in_shape=(self.N, self.H, self.Wd, 8),
                        outputs=self.outputs, names=names, gmacs=self.gmacs,
-                       op_gmacs=[o["gmac"] for o in self.ir_ops])
+                       op_gmacs=[o["gmac"] for o in self.ir_ops],
+                       wlevels=list(self.wlevels) if self.ragged else None, out_level=getattr(self, "_out_level", 0) or 0)
 
     def _final_view(self, v: View):
         r = self.vrec(v)
@@ -1584,11 +1683,15 @@ class Compiler:
         return r
 
 
-def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True, hilo=False):
+def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True, hilo=False,
+                  ragged=False):
     """reuse=False gives every buffer its own workspace range (debugging: all intermediates stay readable).
     hilo=True stores every conv / depthwise / transposed-conv weight as an fp16 hi + lo pair (F_HILO): ~22-bit weights for
-    twice the MFMA work — for nets whose boxes must track an fp32 reference closely."""
+    twice the MFMA work — for nets whose boxes must track an fp32 reference closely.
+    ragged=True (recognisers): `width` is the widest sample of the batch; the plan runs with a per-sample width table
+    (Program.width_table) and every sample gets the values a batch of its own width would have produced, bit for bit."""
     c = Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse)
+    c.ragged = bool(ragged)
     c.hilo = bool(hilo)
     if c.hilo:
         c.use_patch = False          # conv_patch_kernel has no two-pass K walk (the implicit-GEMM, stem and column kernels do)

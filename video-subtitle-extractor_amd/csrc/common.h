@@ -17,6 +17,8 @@ enum { F_RES = 1, F_PIXSHUF = 2, F_OUT_F32 = 4, F_PATCH = 8, F_DOT1 = 16, F_SRC2
 // p[] slots (keep in sync with ir.py)
 enum { P_KH = 0, P_KW, P_SH, P_SW, P_PH, P_PW, P_ACT, P_ACT2, P_COUT, P_KTOT, P_INSHIFT, P_RESSHIFT, P_CINP, P_DOTACT, P_IN2SHIFT };
 enum { P_POOL_MAX = 6, P_POOL_CEIL = 7, P_POOL_EXCL = 8 };
+// ragged plans: 1 + width level of in0 / of the output (0 = no per-sample width); the run supplies widths[level][n]
+enum { P_WLIN = 20, P_WLOUT = 21 };
 enum { FS_ACT_A = 0, FS_ACT_B, FS_POST_A, FS_POST_B, FS_PRE_A, FS_PRE_B, FS_EPS, FS_SCALE };
 
 __device__ __forceinline__ float vse_act(float x, int code, float a, float b) {
@@ -52,8 +54,11 @@ struct ConvArgs {
     // F_SRC2: second input source of a virtual channel concat
     TView in2;
     int in2shift;
+    // ragged plans: per-sample output widths (device, [n]); output pixels at x >= wl_out[n] are written as zeros
+    const int* wl_out;
 };
 int launch_conv(const ConvArgs& a, hipStream_t st);
 int conv_tile_bn(int Np);   // which conv_mfma_kernel instantiation (BN = 128 / 64 / 32) serves Np output channels
+// wl_in / wl_out: per-sample widths of in0 / of the output in a ragged plan (device, [n]), else nullptr
 int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const TView& in2, const TView& out,
-                     const TView& out2, const char* wbase, hipStream_t st);
+                     const TView& out2, const char* wbase, const int* wl_in, const int* wl_out, hipStream_t st);

@@ -32,6 +32,7 @@ struct ConvParams {
     int vec16;              // output (and residual) rows allow 16-byte accesses at every 8-channel group
     long wimg_stride;       // F_IMGW: weight elements per image (Kp * Np); M tiles are then aligned to images
     int hw_img, tiles_img;  // F_IMGW: output pixels per image, M tiles per image
+    const int* wl_out;      // ragged plans: per-image output width; pixels at ow >= wl_out[n] are stored as zeros
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -224,6 +225,12 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
         }
     }
     vse_act_n(v, p.act2, 0.f, 0.f);
+    if (p.wl_out != nullptr && ow >= p.wl_out[n]) {
+        // ragged batch: this pixel lies right of its sample's own width — the next layer must see what zero padding would
+        // have given it there
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = 0.f;
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (!live[g]) continue;

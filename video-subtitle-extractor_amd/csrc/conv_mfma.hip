@@ -284,6 +284,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.in2 = reinterpret_cast<const half_t*>(a.in2.ptr); p.in2_ld = a.in2.ld; p.in2_shift = a.in2shift;
     p.in2_hs = a.in2.h; p.in2_ws = a.in2.w; p.nv0 = a.in.c >> 3;
     p.wimg_stride = 0; p.hw_img = 0; p.tiles_img = 0;
+    p.wl_out = a.wl_out;
+    if (a.wl_out && (a.flags & (F_DOT1 | F_SRC2 | F_UP2HEAD | F_PIXSHUF))) return VSE_E_UNSUPPORTED;   // no per-sample width in these forms
     if (a.flags & F_IMGW) {
         // per-image weights (an SE gate folded into a 1x1 consumer): conv_gemm_kernel only
         if (a.kh != 1 || a.kw != 1 || (a.flags & (F_SRC2 | F_DOT1 | F_PATCH | F_COL | F_PW | F_HILO | F_PIXSHUF))) return VSE_E_UNSUPPORTED;

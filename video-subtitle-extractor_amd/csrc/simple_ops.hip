@@ -48,7 +48,7 @@ template <int GM> __device__ __forceinline__ half8 dw_gate_t(half8 x, const half
 __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView gate, int gmode, int hilo, const half_t* __restrict__ w,
                                                      const float* __restrict__ bias, int kh, int kw, int sh, int sw,
                                                      int ph, int pw, int act, float act_a, float act_b, float post_a,
-                                                     float post_b) {
+                                                     float post_b, const int* __restrict__ wl_out) {
     const int gated = gate.ptr != nullptr ? gmode : 0;
     const int cg = in.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
         half8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (half_t)(vse_act(acc[e], act, act_a, act_b) * post_a + post_b);
+        if (wl_out != nullptr && ow >= wl_out[n]) o = half8{0, 0, 0, 0, 0, 0, 0, 0};      // ragged batch: right of the sample's width
         st8(out, pix, g * 8, o);
     }
 }
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
 template <int KW, int SW, int GM>
 __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TView gate, int hilo, const half_t* __restrict__ w,
                                                          const float* __restrict__ bias, int kh, int sh, int ph, int pw,
-                                                         int act, float act_a, float act_b, float post_a, float post_b) {
+                                                         int act, float act_a, float act_b, float post_a, float post_b,
+                                                         const int* __restrict__ wl_out) {
     constexpr int OUTW = 4, WIN = (OUTW - 1) * SW + KW;
     const int cg = in.c >> 3;
     const int owq = (out.w + OUTW - 1) / OUTW;
@@ -159,14 +161,18 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
             half8 r;
 #pragma unroll
             for (int e = 0; e < 8; ++e) r[e] = (half_t)(vse_act(acc[o][e], act, act_a, act_b) * post_a + post_b);
+            if (wl_out != nullptr && ow0 + o >= wl_out[n]) r = half8{0, 0, 0, 0, 0, 0, 0, 0};
             st8(out, (n * out.h + oh) * out.w + ow0 + o, g * 8, r);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ pooling
+// wl_in / wl_out (ragged batch): the sample's own input / output width — the window is clipped to the sample, not to the
+// batch tensor, and outputs right of the sample are zeros.
 __global__ __launch_bounds__(256) void pool_kernel(TView in, TView out, int kh, int kw, int sh, int sw, int ph, int pw,
-                                                   int is_max, int exclusive) {
+                                                   int is_max, int exclusive, const int* __restrict__ wl_in,
+                                                   const int* __restrict__ wl_out) {
     const int cg = in.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -176,6 +182,11 @@ __global__ __launch_bounds__(256) void pool_kernel(TView in, TView out, int kh, 
         long t = pix / out.w;
         const int oh = (int)(t % out.h);
         const long n = t / out.h;
+        const int inw = wl_in != nullptr ? wl_in[n] : in.w;
+        if (wl_out != nullptr && ow >= wl_out[n]) {
+            st8(out, pix, g * 8, half8{0, 0, 0, 0, 0, 0, 0, 0});
+            continue;
+        }
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = is_max ? -65504.f : 0.f;
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256) void pool_kernel(TView in, TView out, int kh, 
             if (ih < 0 || ih >= in.h) continue;
             for (int dx = 0; dx < kw; ++dx) {
                 const int iw = ow * sw - pw + dx;
-                if (iw < 0 || iw >= in.w) continue;
+                if (iw < 0 || iw >= inw) continue;
                 const half8 x = ld8(in, (n * in.h + ih) * in.w + iw, g * 8);
                 ++cnt;
 #pragma unroll
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(256) void pool_kernel(TView in, TView out, int kh, 
             // exclusive: divide by the number of in-bounds taps; inclusive: by the window clipped to the padded input
             float div = (float)cnt;
             if (!exclusive) {
-                const int h1 = min(oh * sh - ph + kh, in.h + ph), w1 = min(ow * sw - pw + kw, in.w + pw);
+                const int h1 = min(oh * sh - ph + kh, in.h + ph), w1 = min(ow * sw - pw + kw, inw + pw);
                 div = (float)((h1 - (oh * sh - ph)) * (w1 - (ow * sw - pw)));
             }
             const float inv = 1.f / div;
@@ -250,6 +261,50 @@ __global__ void gap_finish_kernel(const float* __restrict__ part, TView out, int
         const int c = (int)(i % out.c);
         float s = 0.f;
         for (int q = 0; q < splits; ++q) s += part[(n * splits + q) * out.c + c];
+        reinterpret_cast<half_t*>(out.ptr)[n * out.ld + c] = (half_t)(s * inv_hw);
+    }
+}
+
+// Ragged batches: the same pool with a summation order that depends on the pixel's (row, column) only — never on the width of
+// the batch tensor: grid (n, ceil(cg/8), h); lane pl of a block sums columns pl, pl + 32, ... of ROW blockIdx.z up to the
+// sample's own width, the 32 lane sums are added in lane order, gap_rows_finish adds the rows in order and divides by
+// h * width[n].  A sample therefore gets the same bits whatever batch it rides in (columns right of it would add zeros).
+__global__ __launch_bounds__(256) void gap_rows_kernel(TView in, float* __restrict__ part, const int* __restrict__ wl_in) {
+    __shared__ float red[32][8][8];
+    const int cgl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int g = blockIdx.y * 8 + cgl;
+    const int n = blockIdx.x, y = blockIdx.z;
+    const int cg = in.c >> 3;
+    const int wn = min(wl_in[n], in.w);
+    const long row = ((long)n * in.h + y) * in.w;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (g < cg) {
+#pragma unroll 4
+        for (int x = pl; x < wn; x += 32) {
+            const half8 v = ld8(in, row + x, g * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[pl][cgl][e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = threadIdx.x;
+        float sum = 0.f;
+        for (int q = 0; q < 32; ++q) sum += red[q][c >> 3][c & 7];
+        const int ch = blockIdx.y * 64 + c;
+        if (ch < in.c) part[((long)n * in.h + y) * in.c + ch] = sum;
+    }
+}
+__global__ void gap_rows_finish_kernel(const float* __restrict__ part, TView out, int rows, const int* __restrict__ wl_in) {
+    const long total = (long)out.n * out.c;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / out.c;
+        const int c = (int)(i % out.c);
+        float s = 0.f;
+        for (int q = 0; q < rows; ++q) s += part[(n * rows + q) * out.c + c];
+        const float inv_hw = 1.f / ((float)rows * (float)wl_in[n]);
         reinterpret_cast<half_t*>(out.ptr)[n * out.ld + c] = (half_t)(s * inv_hw);
     }
 }
@@ -322,7 +377,8 @@ __global__ __launch_bounds__(256) void resize_kernel(TView in, TView out, int sh
 // out = act(x*pre_a+pre_b)*post_a+post_b.  Vector path when both sides are fp16 with 8-aligned spans; scalar
 // path otherwise (e.g. the final 1-channel fp32 probability map).
 __global__ __launch_bounds__(256) void unary_vec_kernel(TView in, TView out, int act, float act_a, float act_b,
-                                                        float pre_a, float pre_b, float post_a, float post_b) {
+                                                        float pre_a, float pre_b, float post_a, float post_b,
+                                                        const int* __restrict__ wl_out) {
     const int cg = out.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -333,11 +389,13 @@ __global__ __launch_bounds__(256) void unary_vec_kernel(TView in, TView out, int
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             o[e] = (half_t)(vse_act((float)a[e] * pre_a + pre_b, act, act_a, act_b) * post_a + post_b);
+        if (wl_out != nullptr && (int)(pix % out.w) >= wl_out[pix / ((long)out.h * out.w)]) o = half8{0, 0, 0, 0, 0, 0, 0, 0};
         st8(out, pix, g * 8, o);
     }
 }
 __global__ __launch_bounds__(256) void unary_scalar_kernel(TView in, TView out, int act, float act_a, float act_b,
-                                                           float pre_a, float pre_b, float post_a, float post_b) {
+                                                           float pre_a, float pre_b, float post_a, float post_b,
+                                                           const int* __restrict__ wl_out) {
     const long total = (long)out.n * out.h * out.w * out.c;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % out.c);
@@ -345,7 +403,8 @@ __global__ __launch_bounds__(256) void unary_scalar_kernel(TView in, TView out, 
         float x;
         if (in.esize == 2) x = (float)reinterpret_cast<const half_t*>(in.ptr)[pix * in.ld + c];
         else x = reinterpret_cast<const float*>(in.ptr)[pix * in.ld + c];
-        const float y = vse_act(x * pre_a + pre_b, act, act_a, act_b) * post_a + post_b;
+        float y = vse_act(x * pre_a + pre_b, act, act_a, act_b) * post_a + post_b;
+        if (wl_out != nullptr && (int)(pix % out.w) >= wl_out[pix / ((long)out.h * out.w)]) y = 0.f;
         if (out.esize == 2) reinterpret_cast<half_t*>(out.ptr)[pix * out.ld + c] = (half_t)y;
         else reinterpret_cast<float*>(out.ptr)[pix * out.ld + c] = y;
     }
@@ -353,7 +412,8 @@ __global__ __launch_bounds__(256) void unary_scalar_kernel(TView in, TView out, 
 
 // ------------------------------------------------------------------------------------------------ LayerNorm
 // 16 lanes per row (8 channels each; C <= 128), 4 rows per wave, two-pass mean/variance in fp32.
-__global__ __launch_bounds__(256) void layernorm_kernel(TView in, TView out, const float* __restrict__ gb, float eps) {
+__global__ __launch_bounds__(256) void layernorm_kernel(TView in, TView out, const float* __restrict__ gb, float eps,
+                                                        const int* __restrict__ wl_out) {
     const int C = in.c;
     const long rows = (long)in.n * in.h * in.w;
     const int sub = threadIdx.x & 15;
@@ -385,6 +445,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(TView in, TView out, con
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 o8[e] = (half_t)((v[e] - mean) * rstd * gb[sub * 8 + e] + gb[C + sub * 8 + e]);
+            if (wl_out != nullptr && (int)(r % in.w) >= wl_out[r / ((long)in.h * in.w)]) o8 = half8{0, 0, 0, 0, 0, 0, 0, 0};
             st8(out, r, sub * 8, o8);
         }
     }
@@ -393,14 +454,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(TView in, TView out, con
 // ------------------------------------------------------------------------------------------------ attention
 // One block per (batch, head).  K and V of the head live in LDS as fp32 [T][hd]; thread t owns query row t and
 // runs an online-softmax pass over all keys.  T <= a few hundred, hd <= 16: tiny FLOPs, latency-bound.
-__global__ __launch_bounds__(256) void attn_kernel(TView qkv, TView out, int heads, int hd, float scale) {
+// tl (ragged batch): the sample's own sequence length — keys / queries at t >= tl[b] do not exist (their output rows are zeros).
+__global__ __launch_bounds__(256) void attn_kernel(TView qkv, TView out, int heads, int hd, float scale, const int* __restrict__ tl) {
     extern __shared__ float kvs[];   // K [T][16] then V [T][16], head dim zero-padded to 16
-    const int T = qkv.w;
+    const int Tfull = qkv.w;
     const int b = blockIdx.x / heads, hix = blockIdx.x % heads;
+    const int T = tl != nullptr ? min(tl[b], Tfull) : Tfull;
     const int C = heads * hd;
     float* Ks = kvs;
     float* Vs = kvs + (long)T * 16;
-    const half_t* base = reinterpret_cast<const half_t*>(qkv.ptr) + (long)b * T * qkv.ld;
+    const half_t* base = reinterpret_cast<const half_t*>(qkv.ptr) + (long)b * Tfull * qkv.ld;
     for (int i = threadIdx.x; i < T * 16; i += blockDim.x) {
         const int t = i >> 4, d = i & 15;
         const bool ok = d < hd;
@@ -439,11 +502,13 @@ __global__ __launch_bounds__(256) void attn_kernel(TView qkv, TView out, int hea
             mx = nm;
         }
         const float inv = 1.f / l;
-        half_t* op = reinterpret_cast<half_t*>(out.ptr) + ((long)b * T + t) * out.ld + hix * hd;
+        half_t* op = reinterpret_cast<half_t*>(out.ptr) + ((long)b * Tfull + t) * out.ld + hix * hd;
 #pragma unroll
         for (int d = 0; d < 16; ++d)
             if (d < hd) op[d] = (half_t)(o[d] * inv);
     }
+    for (int i = T * hd + threadIdx.x; i < Tfull * hd; i += blockDim.x)
+        reinterpret_cast<half_t*>(out.ptr)[((long)b * Tfull + i / hd) * out.ld + hix * hd + i % hd] = (half_t)0.f;
 }
 
 // ------------------------------------------------------------------------------------------------ class softmax
@@ -495,17 +560,19 @@ __global__ __launch_bounds__(256) void softmax_kernel(TView in, TView idxp, TVie
 // One block per batch row; gates fp32 [B,1,T,4H] hold x.W_ih^T + b_ih + b_hh for every step (one MFMA GEMM up
 // front); this kernel adds h.W_hh^T and runs the cell.  W_hh^T is fp16 [H][4H] read through L2 every step.
 // H = 256 -> 1024 gate columns; thread j (of 256) owns hidden unit j and computes its 4 gates.
-__global__ __launch_bounds__(256) void lstm_kernel(TView gates, TView out, const half_t* __restrict__ whh, int H, int rev) {
+__global__ __launch_bounds__(256) void lstm_kernel(TView gates, TView out, const half_t* __restrict__ whh, int H, int rev,
+                                                   const int* __restrict__ tl) {
     extern __shared__ float hs[];   // h [H]
     const int b = blockIdx.x;
-    const int T = gates.w;
+    const int Tfull = gates.w;
+    const int T = tl != nullptr ? min(tl[b], Tfull) : Tfull;     // ragged batch: the sample's own length (the reverse pass starts at ITS end)
     const int j = threadIdx.x;
     float c = 0.f;
     if (j < H) hs[j] = 0.f;
     __syncthreads();
     for (int step = 0; step < T; ++step) {
         const int t = rev ? T - 1 - step : step;
-        const float* g = reinterpret_cast<const float*>(gates.ptr) + ((long)b * T + t) * gates.ld;
+        const float* g = reinterpret_cast<const float*>(gates.ptr) + ((long)b * Tfull + t) * gates.ld;
         float zi = 0.f, zf = 0.f, zg = 0.f, zo = 0.f;
         if (j < H) {
             zi = g[j]; zf = g[H + j]; zg = g[2 * H + j]; zo = g[3 * H + j];
@@ -524,10 +591,12 @@ __global__ __launch_bounds__(256) void lstm_kernel(TView gates, TView out, const
             c = f_ * c + i_ * tanhf(zg);
             const float h = o_ * tanhf(c);
             hs[j] = h;
-            reinterpret_cast<half_t*>(out.ptr)[((long)b * T + t) * out.ld + j] = (half_t)h;
+            reinterpret_cast<half_t*>(out.ptr)[((long)b * Tfull + t) * out.ld + j] = (half_t)h;
         }
         __syncthreads();
     }
+    if (j < H)
+        for (int t = T; t < Tfull; ++t) reinterpret_cast<half_t*>(out.ptr)[((long)b * Tfull + t) * out.ld + j] = (half_t)0.f;
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
@@ -551,7 +620,7 @@ __global__ __launch_bounds__(256) void wscale_kernel(const half_t* __restrict__ 
 }
 
 int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const TView& in2, const TView& out,
-                     const TView& out2, const char* wbase, hipStream_t st) {
+                     const TView& out2, const char* wbase, const int* wl_in, const int* wl_out, hipStream_t st) {
     const int* p = op.p;
     const float* f = op.f;
     switch (op.kind) {
@@ -571,11 +640,11 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
                 const dim3 g4(grid_for(items4, 256)), b4(256);
 #define DW_ROW(KW_, SW_) do { \
                     if (!gate.ptr) hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_, 0>), g4, b4, 0, st, in0, out, gate, hilo, wk, bk, p[P_KH], p[P_SH], \
-                                                      p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B]); \
+                                                      p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B], wl_out); \
                     else if (gmode == 1) hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_, 1>), g4, b4, 0, st, in0, out, gate, hilo, wk, bk, p[P_KH], \
-                                                            p[P_SH], p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B]); \
+                                                            p[P_SH], p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B], wl_out); \
                     else hipLaunchKernelGGL((dwconv_row_kernel<KW_, SW_, 2>), g4, b4, 0, st, in0, out, gate, hilo, wk, bk, p[P_KH], p[P_SH], \
-                                            p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B]); } while (0)
+                                            p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B], wl_out); } while (0)
                 if (kw == 3 && sw == 1) DW_ROW(3, 1);
                 else if (kw == 3) DW_ROW(3, 2);
                 else if (sw == 1) DW_ROW(5, 1);
@@ -585,19 +654,27 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             }
             hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, gate, gmode, hilo, wk, bk, p[P_KH], p[P_KW],
                                p[P_SH], p[P_SW], p[P_PH], p[P_PW], p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A],
-                               f[FS_POST_B]);
+                               f[FS_POST_B], wl_out);
             break;
         }
         case OP_POOL: {
             if ((in0.c & 7) || out.c != in0.c) return VSE_E_INVAL;
             const long items = (long)out.n * out.h * out.w * (in0.c >> 3);
             hipLaunchKernelGGL(pool_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, p[P_KH], p[P_KW],
-                               p[P_SH], p[P_SW], p[P_PH], p[P_PW], p[P_POOL_MAX], p[P_POOL_EXCL]);
+                               p[P_SH], p[P_SW], p[P_PH], p[P_PW], p[P_POOL_MAX], p[P_POOL_EXCL], wl_in, wl_out);
             break;
         }
         case OP_GAP: {
             if ((in0.c & 7) || out.c != in0.c || in2.ptr == nullptr) return VSE_E_INVAL;
             const int splits = in2.h;   // scratch view [n, splits, 1, c] fp32
+            if (wl_in != nullptr) {      // ragged batch: row-structured sums (one split per row), per-sample divisor
+                if (splits != in0.h) return VSE_E_INVAL;
+                hipLaunchKernelGGL(gap_rows_kernel, dim3(in0.n, (in0.c + 63) / 64, in0.h), dim3(256), 0, st, in0,
+                                   reinterpret_cast<float*>(in2.ptr), wl_in);
+                hipLaunchKernelGGL(gap_rows_finish_kernel, dim3(grid_for((long)out.n * out.c, 256)), dim3(256), 0, st,
+                                   reinterpret_cast<const float*>(in2.ptr), out, in0.h, wl_in);
+                break;
+            }
             dim3 grid(in0.n, (in0.c + 63) / 64, splits);
             hipLaunchKernelGGL(gap_partial_kernel, grid, dim3(256), 0, st, in0, reinterpret_cast<float*>(in2.ptr), splits);
             const long items = (long)out.n * out.c;
@@ -627,11 +704,11 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             if (vec) {
                 const long items = (long)out.n * out.h * out.w * (out.c >> 3);
                 hipLaunchKernelGGL(unary_vec_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, p[0],
-                                   f[FS_ACT_A], f[FS_ACT_B], f[FS_PRE_A], f[FS_PRE_B], f[FS_POST_A], f[FS_POST_B]);
+                                   f[FS_ACT_A], f[FS_ACT_B], f[FS_PRE_A], f[FS_PRE_B], f[FS_POST_A], f[FS_POST_B], wl_out);
             } else {
                 const long items = (long)out.n * out.h * out.w * out.c;
                 hipLaunchKernelGGL(unary_scalar_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, p[0],
-                                   f[FS_ACT_A], f[FS_ACT_B], f[FS_PRE_A], f[FS_PRE_B], f[FS_POST_A], f[FS_POST_B]);
+                                   f[FS_ACT_A], f[FS_ACT_B], f[FS_PRE_A], f[FS_PRE_B], f[FS_POST_A], f[FS_POST_B], wl_out);
             }
             break;
         }
@@ -639,7 +716,7 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             if (in0.c > 128 || (in0.c & 7)) return VSE_E_UNSUPPORTED;
             const long rows = (long)in0.n * in0.h * in0.w;
             hipLaunchKernelGGL(layernorm_kernel, dim3(grid_for(rows * 16, 256)), dim3(256), 0, st, in0, out,
-                               reinterpret_cast<const float*>(wbase + op.w_off), f[FS_EPS]);
+                               reinterpret_cast<const float*>(wbase + op.w_off), f[FS_EPS], wl_out);
             break;
         }
         case OP_ATTN: {
@@ -647,7 +724,7 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             if (hd > 16) return VSE_E_UNSUPPORTED;
             const size_t lds = (size_t)2 * in0.w * 16 * sizeof(float);
             if (lds > 160 * 1024) return VSE_E_UNSUPPORTED;
-            hipLaunchKernelGGL(attn_kernel, dim3(in0.n * heads), dim3(256), lds, st, in0, out, heads, hd, f[FS_SCALE]);
+            hipLaunchKernelGGL(attn_kernel, dim3(in0.n * heads), dim3(256), lds, st, in0, out, heads, hd, f[FS_SCALE], wl_in);
             break;
         }
         case OP_SOFTMAX: {
@@ -664,7 +741,7 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             const int H = p[0];
             if (H > 256) return VSE_E_UNSUPPORTED;
             hipLaunchKernelGGL(lstm_kernel, dim3(in0.n), dim3(256), H * sizeof(float), st, in0, out,
-                               reinterpret_cast<const half_t*>(wbase + op.w_off), H, p[1]);
+                               reinterpret_cast<const half_t*>(wbase + op.w_off), H, p[1], wl_in);
             break;
         }
         case OP_WSCALE: {

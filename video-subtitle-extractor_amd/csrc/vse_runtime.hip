@@ -40,6 +40,8 @@ struct vse_plan {
     std::vector<vse_op> ops;
     size_t ws_bytes;
     int max_ext;
+    int n_levels;                     // ragged plans: width levels referenced by the ops (0 = not a ragged plan)
+    int batch;                        // images per run (n of the first op's input)
 };
 
 extern "C" {
@@ -47,7 +49,7 @@ extern "C" {
 const char* vse_last_error(void) { return g_err.c_str(); }
 size_t vse_sizeof_op(void) { return sizeof(vse_op); }
 size_t vse_sizeof_view(void) { return sizeof(vse_view); }
-int vse_abi_version(void) { return 1; }
+int vse_abi_version(void) { return 2; }
 
 int vse_init(int device_id, vse_ctx** out) {
     if (!out) return VSE_E_INVAL;
@@ -115,6 +117,8 @@ int vse_plan_create(vse_ctx* c, int weights_id, const vse_op* ops, int n_ops, si
     p->ops.assign(ops, ops + n_ops);
     p->ws_bytes = ws_bytes;
     p->max_ext = -1;
+    p->n_levels = 0;
+    p->batch = ops[0].in0.n;
     const size_t wbytes = c->weight_bytes[weights_id];
     for (int i = 0; i < n_ops; ++i) {
         const vse_op& o = ops[i];
@@ -123,6 +127,12 @@ int vse_plan_create(vse_ctx* c, int weights_id, const vse_op* ops, int n_ops, si
             delete p;
             return VSE_E_INVAL;
         }
+        if (o.p[P_WLIN] < 0 || o.p[P_WLOUT] < 0) {
+            set_err("op %d: negative width level", i);
+            delete p;
+            return VSE_E_INVAL;
+        }
+        p->n_levels = std::max(p->n_levels, std::max(o.p[P_WLIN], o.p[P_WLOUT]));
         const vse_view* vs[5] = {&o.in0, &o.in1, &o.in2, &o.out, &o.out2};
         for (const vse_view* v : vs) {
             if (v->n == 0) continue;
@@ -158,8 +168,11 @@ static inline TView resolve(const vse_view& v, char* ws, char* wts, void* const*
     return t;
 }
 
-static int run_op(vse_plan* p, int i, char* ws, void* const* ext, hipStream_t st) {
+static int run_op(vse_plan* p, int i, char* ws, void* const* ext, const int32_t* wtab, hipStream_t st) {
     const vse_op& o = p->ops[i];
+    // ragged plans: widths[level][n]
+    const int* wl_in = (wtab && o.p[P_WLIN]) ? wtab + (size_t)(o.p[P_WLIN] - 1) * p->batch : nullptr;
+    const int* wl_out = (wtab && o.p[P_WLOUT]) ? wtab + (size_t)(o.p[P_WLOUT] - 1) * p->batch : nullptr;
     char* wts = reinterpret_cast<char*>(p->ctx->weights[p->weights_id]);
     const TView in0 = resolve(o.in0, ws, wts, ext), in1 = resolve(o.in1, ws, wts, ext),
                 in2 = resolve(o.in2, ws, wts, ext), out = resolve(o.out, ws, wts, ext),
@@ -179,27 +192,48 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, hipStream_t st
         a.dotb = o.f[FS_PRE_B]; a.dotact = o.p[P_DOTACT]; a.dot_out = out2;
         a.in2 = in2; a.in2shift = o.p[P_IN2SHIFT];
         if (o.flags & F_IMGW) a.w = reinterpret_cast<const half_t*>(in2.ptr);      // per-image weights in the workspace
+        a.wl_out = wl_out;
         rc = launch_conv(a, st);
     } else {
-        rc = launch_simple_op(o, in0, in1, in2, out, out2, wts, st);
+        rc = launch_simple_op(o, in0, in1, in2, out, out2, wts, wl_in, wl_out, st);
     }
     if (rc != VSE_OK) set_err("op %d (kind %d) failed to launch: rc=%d (%s)", i, o.kind, rc, hipGetErrorString(hipGetLastError()));
     return rc;
 }
 
-int vse_plan_run(vse_plan* p, void* ws, void* const* ext, int n_ext, void* stream) {
+static int check_run(vse_plan* p, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, const char* who) {
     if (!p || !ext || n_ext <= p->max_ext) {
-        set_err("vse_plan_run: need %d external pointers", p ? p->max_ext + 1 : 0);
+        set_err("%s: need %d external pointers", who, p ? p->max_ext + 1 : 0);
         return VSE_E_INVAL;
     }
     if (!ws && p->ws_bytes) return VSE_E_INVAL;
+    if (p->n_levels && !d_widths) {
+        set_err("%s: the plan was compiled for ragged batches (%d width levels): run it with a width table", who, p->n_levels);
+        return VSE_E_INVAL;
+    }
+    if (!p->n_levels && d_widths) {
+        set_err("%s: width table given to a plan that was not compiled for ragged batches", who);
+        return VSE_E_INVAL;
+    }
+    return VSE_OK;
+}
+
+int vse_plan_run(vse_plan* p, void* ws, void* const* ext, int n_ext, void* stream) {
+    return vse_plan_run_ragged(p, ws, ext, n_ext, nullptr, stream);
+}
+
+int vse_plan_run_ragged(vse_plan* p, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream) {
+    int rc = check_run(p, ws, ext, n_ext, d_widths, "vse_plan_run");
+    if (rc != VSE_OK) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     for (int i = 0; i < (int)p->ops.size(); ++i) {
-        int rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, st);
+        rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, d_widths, st);
         if (rc != VSE_OK) return rc;
     }
     return VSE_OK;
 }
+
+int vse_plan_width_levels(vse_plan* p) { return p ? p->n_levels : VSE_E_INVAL; }
 
 int vse_plan_op_variant(vse_plan* p, int i) {
     if (!p || i < 0 || i >= (int)p->ops.size()) return VSE_E_INVAL;
@@ -232,15 +266,17 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     return (o.p[P_INSHIFT] ? 10000 : 0) + conv_tile_bn(o.p[P_COUT]);
 }
 
-int vse_plan_profile(vse_plan* p, void* ws, void* const* ext, int n_ext, void* stream, float* ms) {
-    if (!p || !ext || !ms || n_ext <= p->max_ext) return VSE_E_INVAL;
+int vse_plan_profile(vse_plan* p, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream, float* ms) {
+    if (!ms) return VSE_E_INVAL;
+    int rc0 = check_run(p, ws, ext, n_ext, d_widths, "vse_plan_profile");
+    if (rc0 != VSE_OK) return rc0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int n = (int)p->ops.size();
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventRecord(ev[0], st));
     for (int i = 0; i < n; ++i) {
-        int rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, st);
+        int rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, d_widths, st);
         if (rc != VSE_OK) return rc;
         HIP_TRY(hipEventRecord(ev[i + 1], st));
     }

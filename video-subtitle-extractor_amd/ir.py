@@ -98,5 +98,11 @@ P_NCLS = 0
 P_HID, P_REVERSE = 0, 1
 
 
+# ragged recogniser batches (every op kind): 1 + width level of in0 / of the output, 0 = the tensor has no per-sample width.
+# A plan compiled with ragged=True runs with a device table widths[level][n] (vse_plan_run_ragged): every producer writes
+# zeros at x >= widths[out level][n], so each sample computes exactly what a batch of its own width would have given it.
+P_WLIN, P_WLOUT = 20, 21
+
+
 def empty_view():
     return np.zeros((), dtype=VIEW_DT)
