@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--models", default="server", choices=["server", "fast", "fast-real"])
     ap.add_argument("--boxes", default="db", choices=["gt", "db"])
-    ap.add_argument("--rec-mode", default="bucketed", choices=["bucketed", "reference"],
-                    help="recogniser batching of the headline number; the other mode is timed beside it (`rec_modes` in the JSON line)")
-    ap.add_argument("--other-mode-steps", type=int, default=4, help="timed steps of the non-headline rec mode (0 = skip)")
+    ap.add_argument("--rec-mode", default="ragged", choices=["ragged", "bucketed", "reference"],
+                    help="recogniser batching of the headline number (ragged = the reference's per-crop padded widths in shared "
+                         "launches, bit-identical to `reference`); the other modes are timed beside it (`rec_modes` in the JSON line)")
+    ap.add_argument("--other-mode-steps", type=int, default=4, help="timed steps of each non-headline rec mode (0 = skip)")
     ap.add_argument("--bucket", type=int, default=256, help="rec width bucket (px)")
     ap.add_argument("--batch-round", type=int, default=4)
     ap.add_argument("--min-rec-group", type=int, default=8,
@@ -294,8 +295,9 @@ def main():
     # one launch sequence per <= 6 crops of ONE frame and is launch-bound)
     rec_modes = {args.rec_mode: {"value": round(world * args.batch * args.steps / dt, 2), "ms_per_step": round(1e3 * dt / args.steps, 3),
                                  "steps": args.steps}}
-    other = "reference" if args.rec_mode == "bucketed" else "bucketed"
-    if args.other_mode_steps > 0:
+    for other in ("ragged", "reference", "bucketed"):
+        if other == args.rec_mode or args.other_mode_steps <= 0:
+            continue
         pipe.rec_mode = other
         _o, dt2 = timed(1, args.other_mode_steps)
         pipe.rec_mode = args.rec_mode
@@ -314,8 +316,12 @@ def main():
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{args.batch}x{args.height}p frames/GPU/step, precise mode: {det_id} @544x960 + "
                                    f"{rec_id}, {n_lines} text lines/batch, rec boxes={args.boxes}, rec batching="
-                                   + (f"bucketed({args.bucket}px, min group {args.min_rec_group})" if args.rec_mode == "bucketed" else
-                                      "reference (per frame, <= 6 crops per chunk, chunk padded to its widest crop)"),
+                                   + {"bucketed": f"bucketed({args.bucket}px, min group {args.min_rec_group}): crops padded to their bucket, NOT "
+                                                  "the reference's padding",
+                                      "ragged": f"ragged({args.bucket}px groups, min group {args.min_rec_group}): every crop at the padded "
+                                                "width of its reference chunk, crops of all frames share launches, results bit-identical "
+                                                "to the reference grouping",
+                                      "reference": "reference (per frame, <= 6 crops per chunk, chunk padded to its widest crop)"}[args.rec_mode],
                        "det_map": ("detector output" if overlay is None else
                                    f"stand-in detector output (head bias -8) max-overlaid inside the step with the text-kernel map of the "
                                    f"generator's lines: {100.0 * float((overlay_np > pipe.db['thresh']).mean()):.2f} % of pixels > thresh"),

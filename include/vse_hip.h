@@ -162,6 +162,10 @@ size_t vse_rec_preprocess_scratch_bytes(int n_crops, int max_crop_w, int max_cro
  * Replaces paddleocr CTCLabelDecode (App. C.6) behind backend/tools/ocr.py:27. */
 int vse_ctc_collapse(vse_ctx* ctx, const void* d_idx_maxp, int b, int t, int32_t* d_out_idx, int32_t* d_out_len,
                      float* d_out_conf, void* stream);
+/* The same over a ragged batch: d_tlen[b] (device int32) = sequence length of each row (the last level's row of the width
+ * table handed to vse_plan_run_ragged); time steps at or behind it are not decoded.  d_tlen == NULL = vse_ctc_collapse. */
+int vse_ctc_collapse_ragged(vse_ctx* ctx, const void* d_idx_maxp, int b, int t, const int32_t* d_tlen, int32_t* d_out_idx,
+                            int32_t* d_out_len, float* d_out_conf, void* stream);
 
 #ifdef __cplusplus
 }

@@ -74,8 +74,32 @@ class Emulator:
         idx = (np.arange(n * h * w)[:, None] * ld + np.arange(c)[None, :])
         return torch.from_numpy(flat[idx].astype(np.float32).reshape(n, h, w, c))
 
+    def masked(self, t):
+        """Ragged plans: what every producing kernel does — zeros right of each sample's own output width."""
+        if getattr(self, "wl_out", None) is None:
+            return t
+        t = t.clone()
+        for n, wn in enumerate(self.wl_out):
+            t[n, :, int(wn):] = 0
+        return t
+
+    def per_sample(self, x, fn):
+        """Ragged plans: ops whose window / span is clipped to the sample (pooling, global pool, attention, LSTM) are evaluated
+        on each sample's own slice [.., :width_in] and written left-aligned into a zero tensor of the output's shape."""
+        if getattr(self, "wl_in", None) is None:
+            return fn(x)
+        outs = [fn(x[n:n + 1, :, :int(wn)]) for n, wn in enumerate(self.wl_in)]
+        wmax = max(o.shape[2] for o in outs)
+        full = torch.zeros((x.shape[0], outs[0].shape[1], wmax, outs[0].shape[3]), dtype=outs[0].dtype)
+        for n, o in enumerate(outs):
+            full[n, :, :o.shape[2]] = o[0]
+        return full
+
     def write(self, v, t, as_int=False):
         n, h, w, c, ld, es = (int(v[k]) for k in ("n", "h", "w", "c", "ld", "esize"))
+        if t.shape[2] < w:          # per_sample(): the widest sample of the batch is narrower than the tensor
+            t = F.pad(t, (0, 0, 0, w - t.shape[2]))
+        t = self.masked(t)
         arena = self._arena(v)
         arr = t.detach().numpy().reshape(n * h * w, c)
         if self._shadow(v):
@@ -94,13 +118,27 @@ class Emulator:
         return self.wblob[off:off + count * np.dtype(dt).itemsize].view(dt)
 
     # ---- run -----------------------------------------------------------------------------------------
-    def run(self, x_nhwc8):
-        """x: float array [N,H,W,8] (fp16-representable).  Returns list of output arrays."""
+    def run(self, x_nhwc8, widths=None):
+        """x: float array [N,H,W,8] (fp16-representable).  Returns list of output arrays.
+        widths: per-sample input widths of a ragged plan (compile_model(ragged=True)); x must be zero right of them."""
         prog = self.prog
+        self.wtab = None
+        if prog.wlevels is not None:
+            self.wtab = prog.width_table(widths if widths is not None else [x_nhwc8.shape[2]] * x_nhwc8.shape[0])
+            for n, wn in enumerate(self.wtab[0]):
+                assert not np.asarray(x_nhwc8)[n, :, wn:].any(), "ragged input must be zero right of the sample's width"
+        else:
+            assert widths is None
         self.ext[0] = np.ascontiguousarray(x_nhwc8.astype(np.float16)).view(np.uint8).reshape(-1)
         for k, o in enumerate(prog.outputs):
             self.ext[k + 1] = np.zeros(o["n"] * o["h"] * o["w"] * o["ld"] * o["esize"], dtype=np.uint8)
         for r in prog.ops:
+            self.wl_in = self.wl_out = None
+            if self.wtab is not None:
+                if int(r["p"][ir.P_WLIN]):
+                    self.wl_in = self.wtab[int(r["p"][ir.P_WLIN]) - 1]
+                if int(r["p"][ir.P_WLOUT]):
+                    self.wl_out = self.wtab[int(r["p"][ir.P_WLOUT]) - 1]
             getattr(self, "_op%d" % int(r["kind"]))(r)
         outs = []
         for k, o in enumerate(prog.outputs):
@@ -238,18 +276,21 @@ class Emulator:
     def _op3(self, r):   # POOL
         p = r["p"]
         kh, kw, sh, sw, ph, pw = (int(p[i]) for i in range(6))
-        x = self.read(r["in0"]).permute(0, 3, 1, 2)
         ceil = bool(p[ir.P_POOL_CEIL])
-        if p[ir.P_POOL_MAX]:
-            y = F.max_pool2d(x, (kh, kw), (sh, sw), (ph, pw), ceil_mode=ceil)
-        else:
-            y = F.avg_pool2d(x, (kh, kw), (sh, sw), (ph, pw), ceil_mode=ceil,
-                             count_include_pad=not bool(p[ir.P_POOL_EXCL]))
-        self.write(r["out"], y.permute(0, 2, 3, 1))
+
+        def pool(xs):
+            xs = xs.permute(0, 3, 1, 2)
+            if p[ir.P_POOL_MAX]:
+                y = F.max_pool2d(xs, (kh, kw), (sh, sw), (ph, pw), ceil_mode=ceil)
+            else:
+                y = F.avg_pool2d(xs, (kh, kw), (sh, sw), (ph, pw), ceil_mode=ceil,
+                                 count_include_pad=not bool(p[ir.P_POOL_EXCL]))
+            return y.permute(0, 2, 3, 1)
+        self.write(r["out"], self.per_sample(self.read(r["in0"]), pool))
 
     def _op4(self, r):   # GAP
         x = self.read(r["in0"])
-        self.write(r["out"], x.mean((1, 2), keepdim=True))
+        self.write(r["out"], self.per_sample(x, lambda xs: xs.mean((1, 2), keepdim=True)))
 
     def _op5(self, r):   # SCALE
         x = self.read(r["in0"])
@@ -291,13 +332,13 @@ class Emulator:
     def _op10(self, r):  # ATTN
         heads, hd = int(r["p"][ir.P_HEADS]), int(r["p"][ir.P_HDIM])
         scale = float(r["f"][ir.FS_SCALE])
-        x = self.read(r["in0"])                    # [B,1,T,3*C]
-        B, _, T, _ = x.shape
-        qkv = x.reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)   # [3,B,h,T,d]
-        q, k, v = qkv[0] * scale, qkv[1], qkv[2]
-        att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
-        y = (att @ v).permute(0, 2, 1, 3).reshape(B, 1, T, heads * hd)
-        self.write(r["out"], y)
+        def attn(x):                               # [B,1,T,3*C]
+            B, _, T, _ = x.shape
+            qkv = x.reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4)   # [3,B,h,T,d]
+            q, k, v = qkv[0] * scale, qkv[1], qkv[2]
+            att = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
+            return (att @ v).permute(0, 2, 1, 3).reshape(B, 1, T, heads * hd)
+        self.write(r["out"], self.per_sample(self.read(r["in0"]), attn))
 
     def _op11(self, r):  # SOFTMAX
         ncls = int(r["p"][ir.P_NCLS])
@@ -319,21 +360,23 @@ class Emulator:
     def _op12(self, r):  # LSTM (one direction of one layer); in0 = fp32 gate pre-activations [B,1,T,4H]
         H = int(r["p"][ir.P_HID])
         rev = bool(r["p"][ir.P_REVERSE])
-        g = self.read(r["in0"])
-        B, _, T, _ = g.shape
         whh = torch.from_numpy(self.wread(int(r["w_off"]), H * 4 * H, np.float16).astype(np.float32).reshape(H, 4 * H))
-        h = torch.zeros(B, H)
-        c = torch.zeros(B, H)
-        out = torch.zeros(B, 1, T, H)
-        for t in (range(T - 1, -1, -1) if rev else range(T)):
-            z = g[:, 0, t] + h @ whh
-            i, f_, gg, o = z.chunk(4, dim=1)
-            c = torch.sigmoid(f_) * c + torch.sigmoid(i) * torch.tanh(gg)
-            h = torch.sigmoid(o) * torch.tanh(c)
-            if self.round:
-                h = h.half().float()
-            out[:, 0, t] = h
-        self.write(r["out"], out)
+
+        def lstm(g):
+            B, _, T, _ = g.shape
+            h = torch.zeros(B, H)
+            c = torch.zeros(B, H)
+            out = torch.zeros(B, 1, T, H)
+            for t in (range(T - 1, -1, -1) if rev else range(T)):
+                z = g[:, 0, t] + h @ whh
+                i, f_, gg, o = z.chunk(4, dim=1)
+                c = torch.sigmoid(f_) * c + torch.sigmoid(i) * torch.tanh(gg)
+                h = torch.sigmoid(o) * torch.tanh(c)
+                if self.round:
+                    h = h.half().float()
+                out[:, 0, t] = h
+            return out
+        self.write(r["out"], self.per_sample(self.read(r["in0"]), lstm))
 
     def _op13(self, r):  # WSCALE: per-image 1x1 weights = tiled weight blob x SE gate over k, rounded to fp16 once
         p = r["p"]

@@ -28,7 +28,7 @@ def test_record_layouts(built_lib):
     lib = engine.load_library()
     assert lib.vse_sizeof_op() == ir.OP_DT.itemsize == 352
     assert lib.vse_sizeof_view() == ir.VIEW_DT.itemsize == 40
-    assert lib.vse_abi_version() == 1
+    assert lib.vse_abi_version() == 2
 
 
 def test_product_refuses_without_gpu(built_lib):

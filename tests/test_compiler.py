@@ -294,3 +294,45 @@ def test_se_gate_folds_into_depthwise_and_pointwise_consumers():
     k2 = [int(o["kind"]) for o in plain.ops]
     assert k2.count(ir.OP_WSCALE) == 0 and k2.count(ir.OP_SCALE) == 5
     assert np.abs(ir_emul.Emulator(plain).run(ir_emul.to_nhwc8(x))[0][..., 0] - ref).max() < 5e-3
+
+
+RAGGED_CASES = [("V4_ch_rec", 48, (96, 131, 77)), ("V4_en_rec_fast", 48, (97, 64, 160)), ("V3_ch_rec_fast", 48, (80, 123, 99)),
+                ("V2_ch_rec", 32, (64, 101, 88))]
+
+
+@pytest.mark.parametrize("mid,h,widths", RAGGED_CASES)
+def test_ragged_plan_gives_every_sample_its_own_width(mid, h, widths):
+    """compile_model(ragged=True): samples of different widths share one batch tensor, and each receives what the oracle
+    computes for a batch of exactly its width (paddleocr pads a chunk of <= 6 crops of ONE frame to the chunk's widest crop,
+    backend/tools/ocr.py:99 + backend/config.py:58; the padded width, not the neighbours, is what a crop's logits depend on)."""
+    desc, w = net_ref.get_weights(mid)
+    rng = np.random.default_rng(3)
+    wmax = max(widths) + 9                                  # the tensor may be wider than every sample
+    x = np.zeros((len(widths), 3, h, wmax), np.float32)
+    for n, wn in enumerate(widths):
+        x[n, :, :, :wn] = rng.uniform(-1, 1, (3, h, wn))
+    x = x.astype(np.float16).astype(np.float32)
+    prog = compiler.compile_model(desc, w, len(widths), h, wmax, ragged=True)
+    assert prog.wlevels is not None and len(prog.wlevels) >= 3
+    tab = prog.width_table(widths)
+    out = ir_emul.Emulator(prog).run(ir_emul.to_nhwc8(x), widths=widths)
+    probs, idx = out[0][:, 0], out[-1].view(np.int32)[:, 0, :, 0]
+    for n, wn in enumerate(widths):
+        ref = net_ref.run_graph(desc, w, x[n:n + 1, :, :, :wn])[0].numpy()[0]        # [T_n, classes]
+        tn = int(tab[prog.out_level][n])
+        assert ref.shape[0] == tn
+        assert np.abs(probs[n, :tn] - ref).max() < 1e-3
+        srt = np.sort(ref, -1)
+        clear = (srt[..., -1] - srt[..., -2]) > 0.05 * srt[..., -1]
+        assert np.array_equal(idx[n, :tn][clear], ref.argmax(-1)[clear])
+    # the same kernel family per layer whatever the batch and its widest sample (a layer sums its products in one order)
+    def families(p):       # op kinds and every flag (kernel family, gate folding, weight tiling ...), layer by layer
+        return [(int(o["kind"]), int(o["flags"])) for o in p.ops]
+    assert families(prog) == families(compiler.compile_model(desc, w, 48, h, 1283, ragged=True)) \
+        == families(compiler.compile_model(desc, w, 1, h, 320, ragged=True))
+
+
+def test_ragged_plan_refuses_detector_graphs():
+    desc, w = net_ref.get_weights("V4_ch_det_fast")
+    with pytest.raises(compiler.UnsupportedGraph):
+        compiler.compile_model(desc, w, 1, 64, 96, ragged=True)

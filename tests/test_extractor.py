@@ -111,6 +111,31 @@ def test_uncompressed_avi_roundtrip_and_refusals(tmp_path):
         ingest.AviBgr24Source(str(tmp_path / "junk.avi"))
 
 
+def test_avi_opendml_segments_and_dropped_frames(tmp_path):
+    """ffmpeg's AVI muxer opens a new `RIFF....AVIX` segment about every GiB (~170 frames of 1080p bgr24): all segments are
+    read, trailing bytes that are not a segment are an error (never a silently shorter clip), and a zero-length frame chunk
+    (dropped frame) shows the previous picture."""
+    from vse_amd import ingest
+    rng = np.random.default_rng(9)
+    frames = rng.integers(0, 256, (11, 10, 21, 3), dtype=np.uint8)
+    p = str(tmp_path / "seg.avi")
+    ingest.write_avi_bgr24(p, frames, 25.0, riff_frames=4, dropped=(0, 5, 6))
+    raw = open(p, "rb").read()
+    assert raw.count(b"AVIX") == 2
+    src = ingest.open_source(p)
+    assert src.frame_count == 11
+    got = list(src.frames())
+    assert got[0] is None                                         # a dropped FIRST frame has no predecessor
+    for k in range(1, 11):
+        want = frames[4] if k in (5, 6) else frames[k]
+        assert np.array_equal(got[k], want), k
+    assert np.array_equal(src.read(7), frames[4]) and np.array_equal(src.read(11), frames[10])
+    src.close()
+    (tmp_path / "tail.avi").write_bytes(raw + b"JUNKJUNKJUNKJUNK")
+    with pytest.raises(ValueError, match="not an AVI segment"):
+        ingest.AviBgr24Source(str(tmp_path / "tail.avi"))
+
+
 def _shard_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -199,7 +199,7 @@ def test_box_parity_rate_real_detector(ctx):
     assert n >= 20 and same >= 0.95 * n and low <= 1, (n, same, low)
 
 
-@pytest.mark.parametrize("mode", ["bucketed", "reference"])
+@pytest.mark.parametrize("mode", ["bucketed", "reference", "ragged"])
 def test_recognizer_side_streams_keep_results(ctx, mode):
     """rec_streams > 1: width groups run on side streams.  Groups that share one plan key (n, h, w) — a bucket split into
     max_rec_batch chunks, reference-mode chunks of equal shape — are in flight at the same time and must each own a
@@ -216,7 +216,7 @@ def test_recognizer_side_streams_keep_results(ctx, mode):
     dev = torch.from_numpy(frames).cuda()
     pipe = pipeline.OcrPipeline(ctx, det, rec, P.en_charset(), rec_mode=mode, bucket=256, max_rec_batch=4, rec_batch_num=2)
     groups = pipe._groups(pipe._crop_specs(quads))
-    keys = [(len(idx), w) for idx, w in groups]
+    keys = [(len(idx), w) for idx, w, _ in groups]
     assert len(keys) > len(set(keys)), "the case must contain groups that share a plan key"
     pipe.rec_streams = 1
     want = pipe.recognize(dev, quads)
@@ -279,7 +279,12 @@ def test_text_recognizer_call_site(ctx):
     # what this call site adds over the net-level parity tests — the crop route above and the grouping — is checked exactly)
     want_groups = [(list(idx), int(w)) for idx, w in P.rec_batches(crops, 3)]
     gspecs = [dict(frame=i, gframe=0, ratio=c.shape[1] / float(c.shape[0])) for i, c in enumerate(crops)]
-    assert [(list(idx), int(w)) for idx, w in tr.pipe._groups(gspecs)] == want_groups
+    assert [(list(idx), int(w)) for idx, w, _ in tr.pipe._reference_chunks(gspecs) and
+            [(c, w, None) for c, w in tr.pipe._reference_chunks(gspecs)]] == want_groups
+    # the default (ragged) grouping gives every crop exactly that chunk width, and the reference launch structure the same answers
+    assert {i: wi for idx, _, ws in tr.pipe._groups(gspecs) for i, wi in zip(idx, ws)} == {i: int(w) for idx, w in want_groups for i in idx}
+    tr.pipe.rec_mode = "reference"
+    assert tr(crops)[0] == got
     assert tr([])[0] == []
 
 
@@ -358,3 +363,42 @@ def test_extractor_on_a_clip_engine_vs_oracle(ctx):
         assert streamed.run() == a and streamed.raw_lines == one.raw_lines
         if kw is fps_kw:
             assert geo(many.raw_lines) == geo(ora.raw_lines)
+
+
+def test_ragged_recognition_is_bit_identical_to_the_reference_grouping(ctx):
+    """crops of many frames in a handful of launches (rec_mode="ragged") vs one launch sequence per <= 6-crop
+    chunk of one frame (rec_mode="reference", backend/tools/ocr.py:99 + backend/config.py:58): every (text, score) pair is
+    EQUAL — the score is the mean of the kept time steps' max probabilities, so equality means the same arg-max indices and
+    the same probability bits — on 240 crops of mixed widths, 1 to 8 per frame, on the server and the mobile recogniser,
+    single stream and side streams, several bucket / batch-rounding settings."""
+    import torch
+    from vse_amd import pipeline, synth
+    det = net_ref.get_weights("V3_ch_det_fast")
+    frames, truth = synth.make_frames(48, 720, 1280, seed=21, p_two_lines=0.5, return_truth=True)
+    rng = np.random.default_rng(8)
+    quads = []
+    for tr in truth:
+        qs = []
+        for (x0, y0, x1, y1, _t) in tr:
+            qs.append(np.array([[x0 - 4, y0 - 4], [x1 + 4, y0 - 4], [x1 + 4, y1 + 4], [x0 - 4, y1 + 4]], np.float32))
+        while len(qs) < 8 and rng.random() < 0.85:          # sub-boxes of random widths: word-sized to line-sized crops
+            x0, y0, x1, y1, _t = tr[int(rng.integers(len(tr)))]
+            a = int(rng.integers(x0, max(x0 + 1, x1 - 40)))
+            b = int(rng.integers(min(a + 30, x1), x1 + 1))
+            qs.append(np.array([[a, y0 - 3], [b, y0 - 3], [b, y1 + 3], [a, y1 + 3]], np.float32))
+        quads.append(qs)
+    assert sum(len(q) for q in quads) >= 240
+    dev = torch.from_numpy(frames).cuda()
+    for rec_id, charset in (("V4_ch_rec", None), ("V4_en_rec_fast", P.en_charset())):
+        rec = net_ref.get_weights(rec_id)
+        from vse_amd import shim
+        cs = charset or P.standin_charset(shim._ncls(rec[0]))
+        pipe = pipeline.OcrPipeline(ctx, det, rec, cs, rec_mode="reference")
+        want = pipe.recognize(dev, quads)
+        assert sum(1 for r in want for (t, s) in r if t) > 100           # the comparison is not about empty strings
+        pipe.rec_mode = "ragged"
+        for bucket, rnd, mg, streams in ((256, 4, 8, 1), (64, 1, 0, 1), (128, 8, 4, 3), (1024, 1, 0, 2)):
+            pipe.bucket, pipe.batch_round, pipe.min_rec_group, pipe.rec_streams = bucket, rnd, mg, streams
+            got = pipe.recognize(dev, quads)
+            assert got == want, (rec_id, bucket, rnd, mg, streams)
+        pipe.rec_streams = 1

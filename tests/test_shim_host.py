@@ -1,6 +1,7 @@
 """Host-side behaviour of the drop-in shim that needs no GPU: dictionaries, kwargs, error behaviour."""
 import os
 
+import numpy as np
 import pytest
 
 from vse_amd import shim
@@ -77,15 +78,48 @@ def test_bucketed_groups_fold_small_buckets_upwards():
     ratios = [10] * 28 + [15] * 28 + [20] * 22 + [26] * 4
     specs = [dict(ratio=r) for r in ratios]
     p.min_rec_group = 0
-    assert [(len(i), w) for i, w in p._groups(specs)] == [(28, 512), (28, 768), (22, 1024), (4, 1280)]
+    assert [(len(i), w) for i, w, _ in p._groups(specs)] == [(28, 512), (28, 768), (22, 1024), (4, 1280)]
     p.min_rec_group = 8
     groups = p._groups(specs)
-    assert [(len(i), w) for i, w in groups] == [(28, 512), (28, 768), (26, 1280)]
-    seen = sorted(i for idx, _ in groups for i in idx)
+    assert [(len(i), w) for i, w, _ in groups] == [(28, 512), (28, 768), (26, 1280)]
+    assert all(ws == [w] * len(idx) for idx, w, ws in groups)          # bucketed: every crop padded to the bucket's width
+    seen = sorted(i for idx, _, _ in groups for i in idx)
     assert seen == list(range(len(specs)))
-    assert all(48 * ratios[i] <= w for idx, w in groups for i in idx)
+    assert all(48 * ratios[i] <= w for idx, w, _ in groups for i in idx)
     # cascades: every bucket too small -> one group at the widest width; more than max_rec_batch crops are chunked as before
     p.min_rec_group = 8
-    assert [(len(i), w) for i, w in p._groups([dict(ratio=r) for r in [10] * 3 + [15] * 2 + [20] * 2 + [26]])] == [(8, 1280)]
+    assert [(len(i), w) for i, w, _ in p._groups([dict(ratio=r) for r in [10] * 3 + [15] * 2 + [20] * 2 + [26]])] == [(8, 1280)]
     p.max_rec_batch = 16
-    assert [len(i) for i, _ in p._groups([dict(ratio=10)] * 40)] == [16, 16, 8]
+    assert [len(i) for i, _, _ in p._groups([dict(ratio=10)] * 40)] == [16, 16, 8]
+
+
+def test_ragged_groups_keep_every_crop_at_its_reference_width():
+    """Ragged recognition (default): a crop's width is the padded width of ITS reference chunk (per frame, sorted by w/h,
+    chunks of rec_batch_num, chunk as wide as its widest member, at least 320: oracle.pipeline_ref.rec_batches ==
+    paddleocr's TextRecognizer loop behind backend/tools/ocr.py:27), while crops of all frames share the launch groups."""
+    from oracle import pipeline_ref as P
+    from vse_amd import pipeline
+    rng = np.random.default_rng(4)
+    p = pipeline.OcrPipeline.__new__(pipeline.OcrPipeline)
+    p.rec_h, p.rec_base_w, p.bucket, p.max_rec_batch, p.rec_batch_num, p.min_rec_group = 48, 320, 256, 64, 6, 8
+    specs, want = [], {}
+    for f in range(30):
+        k = int(rng.integers(0, 9))
+        sizes = [(int(rng.integers(20, 900)), int(rng.integers(16, 60))) for _ in range(k)]
+        crops = [np.zeros((h, w, 3), np.uint8) for w, h in sizes]
+        base = len(specs)
+        for w, h in sizes:
+            specs.append(dict(frame=f, ratio=w / float(h)))
+        for idx, img_w in P.rec_batches(crops, 6):
+            for i in idx:
+                want[base + i] = int(img_w)
+    p.rec_mode = "reference"
+    ref_groups = p._groups(specs)
+    assert all(len(idx) <= 6 and len({specs[i]["frame"] for i in idx}) == 1 and ws == [w] * len(idx) for idx, w, ws in ref_groups)
+    assert {i: w for idx, w, _ in ref_groups for i in idx} == want
+    p.rec_mode = "ragged"
+    groups = p._groups(specs)
+    assert sorted(i for idx, _, _ in groups for i in idx) == list(range(len(specs)))
+    assert {i: wi for idx, _, ws in groups for i, wi in zip(idx, ws)} == want          # same width as in the reference
+    assert all(max(ws) <= w and w % 256 == 0 for _, w, ws in groups)                    # the tensor covers its widest sample
+    assert len(groups) <= 8 and len(ref_groups) >= 30                                  # ... in a handful of launches

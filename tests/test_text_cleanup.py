@@ -47,3 +47,32 @@ def test_missing_segmenter_is_an_error():
         pytest.skip("wordsegment is installed here")
     with pytest.raises(RuntimeError, match="word segmenter"):
         text_cleanup.execute("/nonexistent.srt", "en")
+
+
+def test_a_failing_block_is_kept_and_execute_returns_true(tmp_path):
+    """reformat.execute (backend/tools/reformat.py:16-214) keeps a block whose clean-up raises (segmenter failure, a segment
+    with regex metacharacters) and goes on with the next one; it returns True."""
+    srt = "1\n00:00:01,000 --> 00:00:02,000\nhelloworld (a+b)*[c\n\n2\n00:00:03,000 --> 00:00:04,000\nthisisfine\n\n"
+    p = tmp_path / "x.srt"
+    p.write_text(srt, encoding="utf-8")
+
+    def seg(text):
+        if "(" in text or "hello" in text:
+            raise RuntimeError("segmenter failure")
+        return ["this", "is", "fine"]
+    assert text_cleanup.execute(str(p), "en", segment=seg, typo_map={}) is True
+    out = p.read_text(encoding="utf-8")
+    assert "helloworld (a+b)*[c" in out and "this is fine" in out.lower()
+
+
+def test_sharded_run_without_process_group_raises():
+    from vse_amd import extractor
+
+    class Ocr:
+        def predict(self, f):
+            return [], []
+    import numpy as np
+    src = extractor.ArraySource(np.zeros((4, 8, 8, 3), np.uint8), 25.0)
+    tasks = [(2, 1, None, None, None, None), (2, 2, None, None, None, None)]
+    with pytest.raises(RuntimeError, match="not initialised"):
+        extractor.run_ocr_tasks(src, tasks, Ocr(), None, "ch", 0.5, 0.0, shard=(0, 2))

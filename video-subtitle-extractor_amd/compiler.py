@@ -234,6 +234,8 @@ def check_attrs(ops):
             if k not in a:
                 continue
             got = a[k]
+            if v == [] and isinstance(got, (list, tuple)) and not any(got):
+                continue        # output_padding / output_size written out as explicit zeros = the default
             ok = got in v if isinstance(v, tuple) else (abs(got - v) < 1e-6 if isinstance(v, float) else got == v)
             if not ok:
                 raise UnsupportedGraph(f"op {i} ({op['type']}): attribute {k}={got!r} is not supported (the kernels "
@@ -280,6 +282,7 @@ class Compiler:
             for ins in op["in"].values():
                 for n in ins:
                     self.consumers.setdefault(n, []).append(i)
+        self.fetched_names = {n for op in self.ops if op["type"] == "fetch" for n in op["in"].get("X", [])}
         self._mark_live()
         self._plan_concats()
 
@@ -814,6 +817,8 @@ class Compiler:
         depthwise conv and any number of plain 1x1 stride-1 convs that run on conv_gemm_kernel over the whole dense tensor."""
         if flags or name in self.placement or big.up or big.segs != [(0, big.c)] or big.span != big.c or big.c % 64 or big.c <= 64 or self.hilo:
             return False
+        if name in self.fetched_names:       # a fetched SE output must exist as a tensor: env[name] = big would hand out the un-gated one
+            return False
         cons = self._live_consumers(name)
         n_dw = n_pw = 0
         for j in cons:
@@ -827,7 +832,7 @@ class Compiler:
             w2 = self.W[o2["in"]["Filter"][0]]
             pads = a2["paddings"]
             if (o2["type"] != "conv2d" or a2.get("groups", 1) != 1 or tuple(w2.shape[1:]) != (big.c, 1, 1) or list(a2["strides"]) != [1, 1]
-                    or any(pads) or big.h * big.w < 256):
+                    or any(pads) or big.h * self.sel_width(big.buf.wl if big.buf is not None else None, big.w) < 256):
                 return False
             n_pw += 1
         return n_dw <= 1 and n_pw >= 1
@@ -1021,6 +1026,13 @@ class Compiler:
         out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
         res = ep["res"]
         flags = 0
+        # width the kernel selection sees: the map's own — or, in a ragged plan, the map width of a nominal sample, so that a
+        # layer runs on the same kernel family (same summation order) in every plan of the model
+        ow_real = ow
+        if self.ragged:
+            if inv.buf is None:
+                raise UnsupportedGraph(f"ragged plan: conv {outname} reads a virtual concat")
+            ow = self.sel_width(self.wl_after(inv.buf.wl, kw, sw, pw), ow)
         # k x k stride-1 convs on maps that tile well into 8x32 output patches go to the LDS-resident-patch kernel
         pbn = 64 if rup(coutp, 64) < rup(coutp, 128) else 128          # mirrors conv_patch_bn / conv_patch_th in csrc
         pcap = 960 if pbn == 64 else 640
@@ -1052,6 +1064,7 @@ class Compiler:
         if col:
             patch_std = light_ok = False
         patch = patch_std or light_ok
+        ow = ow_real
         self.env_dims_tmp = (inv.n, oh, ow)
         if patch:
             flags |= ir.F_PATCH
@@ -1320,6 +1333,8 @@ class Compiler:
                 out = View(self.new_buf(x.n, 1, 1, x.span), 0, x.n, 1, 1, list(x.segs), x.span)
             # enough blocks to hide the load latency on small maps too (one block streams 64 channels of h*w/splits pixels)
             splits = max(1, min(64, (x.h * x.w) // 256))
+            if self.ragged:
+                splits = x.h          # gap_rows_kernel: one partial sum per row, a summation order that ignores the tensor's width
             sb = self.new_buf(x.n, splits, 1, x.span, esize=4)
             scratch = View(sb, 0, x.n, splits, 1, [(0, x.span)], x.span)
             self.emit(ir.OP_GAP, name, [x, None, scratch], out)
@@ -1388,7 +1403,7 @@ class Compiler:
             # SE gate whose only consumer is a depthwise conv (the stage transitions of the HGNet recognisers): the conv
             # applies the gate on load and the scaled tensor is never written
             cons2 = self._live_consumers(outname)
-            if GATE_DW and len(cons2) == 1 and outname not in self.placement:
+            if GATE_DW and len(cons2) == 1 and outname not in self.placement and outname not in self.fetched_names:
                 o2 = self.ops[cons2[0]]
                 if o2["type"] in ("conv2d", "depthwise_conv2d") and o2["in"]["Input"][0] == outname:
                     w2 = self.W[o2["in"]["Filter"][0]]

@@ -644,12 +644,15 @@ extern "C" int vse_rec_preprocess(vse_ctx*, const void* d_bgr, int n_frames, int
 // ================================================================================================ CTC collapse
 // One wave per sequence: lane l looks at t = base + l, keep = idx[t] != 0 && idx[t] != idx[t-1]; the 64-bit
 // ballot gives each kept element its output slot by a popcount of the lower lanes (wavefront scan).
-__global__ __launch_bounds__(256) void ctc_collapse_kernel(const int2* __restrict__ ip, int b, int t, int* __restrict__ out_idx,
-                                                           int* __restrict__ out_len, float* __restrict__ out_conf) {
+// tlen (ragged batch): the sequence length of each row; time steps at or behind it are not part of the sample.
+__global__ __launch_bounds__(256) void ctc_collapse_kernel(const int2* __restrict__ ip, int b, int tfull, const int* __restrict__ tlen,
+                                                           int* __restrict__ out_idx, int* __restrict__ out_len,
+                                                           float* __restrict__ out_conf) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= b) return;
-    const int2* r = ip + (long)row * t;
+    const int2* r = ip + (long)row * tfull;
+    const int t = tlen != nullptr ? min(max(tlen[row], 0), tfull) : tfull;
     int n = 0;
     float sum = 0.f;
     for (int base = 0; base < t; base += 64) {
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(256) void ctc_collapse_kernel(const int2* __restric
         }
         const bool keep = (tt < t) && idx != 0 && idx != prev;
         const unsigned long long m = __ballot(keep);
-        if (keep) out_idx[(long)row * t + n + __popcll(m & ((1ull << lane) - 1ull))] = idx;
+        if (keep) out_idx[(long)row * tfull + n + __popcll(m & ((1ull << lane) - 1ull))] = idx;
         float ps = keep ? p : 0.f;
         for (int o = 32; o >= 1; o >>= 1) ps += __shfl_xor(ps, o);
         sum += ps;
@@ -676,10 +679,14 @@ __global__ __launch_bounds__(256) void ctc_collapse_kernel(const int2* __restric
     }
 }
 
-extern "C" int vse_ctc_collapse(vse_ctx*, const void* d_idx_maxp, int b, int t, int32_t* d_out_idx, int32_t* d_out_len,
-                                float* d_out_conf, void* stream) {
+extern "C" int vse_ctc_collapse_ragged(vse_ctx*, const void* d_idx_maxp, int b, int t, const int32_t* d_tlen, int32_t* d_out_idx,
+                                       int32_t* d_out_len, float* d_out_conf, void* stream) {
     if (!d_idx_maxp || !d_out_idx || !d_out_len || !d_out_conf || b <= 0 || t <= 0) return VSE_E_INVAL;
     hipLaunchKernelGGL(ctc_collapse_kernel, dim3((b + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       reinterpret_cast<const int2*>(d_idx_maxp), b, t, d_out_idx, d_out_len, d_out_conf);
+                       reinterpret_cast<const int2*>(d_idx_maxp), b, t, d_tlen, d_out_idx, d_out_len, d_out_conf);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}
+extern "C" int vse_ctc_collapse(vse_ctx* c, const void* d_idx_maxp, int b, int t, int32_t* d_out_idx, int32_t* d_out_len,
+                                float* d_out_conf, void* stream) {
+    return vse_ctc_collapse_ragged(c, d_idx_maxp, b, t, nullptr, d_out_idx, d_out_len, d_out_conf, stream);
 }

@@ -15,9 +15,9 @@ LIB_PATH = os.path.join(_HERE, "libvse_hip.so")
 
 EXPORTS = [
     "vse_init", "vse_destroy", "vse_last_error", "vse_sizeof_op", "vse_sizeof_view", "vse_abi_version",
-    "vse_weights_upload", "vse_weights_free", "vse_plan_create", "vse_plan_destroy", "vse_plan_run",
-    "vse_plan_profile", "vse_plan_op_variant", "vse_det_preprocess", "vse_db_workspace_bytes", "vse_db_postprocess",
-    "vse_rec_preprocess", "vse_rec_preprocess_scratch_bytes", "vse_ctc_collapse",
+    "vse_weights_upload", "vse_weights_free", "vse_plan_create", "vse_plan_destroy", "vse_plan_run", "vse_plan_run_ragged",
+    "vse_plan_width_levels", "vse_plan_profile", "vse_plan_op_variant", "vse_det_preprocess", "vse_db_workspace_bytes",
+    "vse_db_postprocess", "vse_rec_preprocess", "vse_rec_preprocess_scratch_bytes", "vse_ctc_collapse", "vse_ctc_collapse_ragged",
 ]
 
 
@@ -79,7 +79,9 @@ def load_library(path=None):
     lib.vse_plan_destroy.argtypes = [C.c_void_p]
     lib.vse_plan_destroy.restype = None
     lib.vse_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
-    lib.vse_plan_profile.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+    lib.vse_plan_run_ragged.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p]
+    lib.vse_plan_width_levels.argtypes = [C.c_void_p]
+    lib.vse_plan_profile.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p,
                                      C.POINTER(C.c_float)]
     lib.vse_plan_op_variant.argtypes = [C.c_void_p, C.c_int]
     lib.vse_det_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
@@ -93,6 +95,8 @@ def load_library(path=None):
                                        C.c_size_t, C.c_void_p]
     lib.vse_ctc_collapse.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p]
+    lib.vse_ctc_collapse_ragged.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
     if lib.vse_sizeof_op() != ir.OP_DT.itemsize or lib.vse_sizeof_view() != ir.VIEW_DT.itemsize:
         raise VseError(f"ABI mismatch: vse_op {lib.vse_sizeof_op()} vs {ir.OP_DT.itemsize}, "
                        f"vse_view {lib.vse_sizeof_view()} vs {ir.VIEW_DT.itemsize}")
@@ -206,26 +210,32 @@ class Context:
                "vse_rec_preprocess")
         return out
 
-    def ctc_collapse(self, idx_maxp):
+    def ctc_collapse(self, idx_maxp, tlen=None):
         """idx_maxp: cuda [B,1,T,2] (int32 idx / fp32 prob bit-pairs, as float32 tensor) ->
-        (idx int32 [B,T], len int32 [B], conf fp32 [B]) cuda tensors."""
+        (idx int32 [B,T], len int32 [B], conf fp32 [B]) cuda tensors.  tlen: cuda int32 [B] sequence lengths of a ragged batch."""
         t = self.torch
         b, tt = idx_maxp.shape[0], idx_maxp.shape[2]
         oi = t.zeros((b, tt), dtype=t.int32, device=self.tdev)
         ol = t.empty((b,), dtype=t.int32, device=self.tdev)
         oc = t.empty((b,), dtype=t.float32, device=self.tdev)
-        _check(self.lib.vse_ctc_collapse(self.handle, C.c_void_p(idx_maxp.data_ptr()), b, tt,
-                                         C.c_void_p(oi.data_ptr()), C.c_void_p(ol.data_ptr()),
-                                         C.c_void_p(oc.data_ptr()), self.stream()), "vse_ctc_collapse")
+        if tlen is not None:
+            assert tlen.dtype == t.int32 and tlen.is_contiguous() and tlen.numel() == b
+        _check(self.lib.vse_ctc_collapse_ragged(self.handle, C.c_void_p(idx_maxp.data_ptr()), b, tt,
+                                                C.c_void_p(tlen.data_ptr()) if tlen is not None else None,
+                                                C.c_void_p(oi.data_ptr()), C.c_void_p(ol.data_ptr()),
+                                                C.c_void_p(oc.data_ptr()), self.stream()), "vse_ctc_collapse")
         return oi, ol, oc
 
 
 class Net:
     """One model (descriptor + fp32 weights) with plans compiled per static input shape."""
 
-    def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True, hilo=False):
-        """hilo=True: conv weights as fp16 hi + lo pairs (compiler.compile_model): ~22-bit weights, twice the MFMA work."""
+    def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True, hilo=False, ragged=False):
+        """hilo=True: conv weights as fp16 hi + lo pairs (compiler.compile_model): ~22-bit weights, twice the MFMA work.
+        ragged=True (recognisers): every plan takes a per-sample width vector (run(x, widths=...)); a sample's outputs do
+        not depend on the batch it rides in (compiler.compile_model(ragged=True))."""
         self.ctx = ctx
+        self.ragged = bool(ragged)
         self.desc = desc
         self.weights = weights
         self.fetch_cols = fetch_cols
@@ -242,7 +252,7 @@ class Net:
         key = (n, h, w)
         if key not in self.plans:
             prog = compiler.compile_model(self.desc, self.weights, n, h, w, self.fetch_cols, self.want_probs,
-                                          self.store, hilo=self.hilo)
+                                          self.store, hilo=self.hilo, ragged=self.ragged)
             self.plans[key] = [prog, None]
         return self.plans[key][0]
 
@@ -298,8 +308,21 @@ class Net:
         ptrs = (C.c_void_p * (1 + len(outs)))(x.data_ptr(), *[o.data_ptr() for o in outs])
         return outs, ptrs
 
-    def run(self, x, slot=0):
-        """x: cuda fp16 [N,H,W,8] NHWC (3 real channels).  Returns list of fp32 cuda tensors (prog.outputs order)."""
+    def _width_table(self, prog, widths, n, w):
+        """Device int32 [levels][n] for a ragged plan (None for an ordinary one)."""
+        if not self.ragged:
+            if widths is not None:
+                raise VseError("per-sample widths given to a net that was not built with ragged=True")
+            return None
+        if widths is None:
+            widths = np.full(n, w, np.int32)          # a uniform batch: every sample as wide as the tensor
+        tab = prog.width_table(widths)
+        return self.ctx.torch.from_numpy(tab).to(self.ctx.tdev)
+
+    def run(self, x, slot=0, widths=None):
+        """x: cuda fp16 [N,H,W,8] NHWC (3 real channels).  Returns list of fp32 cuda tensors (prog.outputs order).
+        widths (ragged nets): per-sample input width (<= W; x is zero right of it); self.last_tlen then holds the device
+        int32 [N] sequence lengths of the head's output."""
         t = self.ctx.torch
         assert x.dtype == t.float16 and x.is_contiguous() and x.shape[3] == 8, (x.dtype, x.shape)
         n, h, w, _ = x.shape
@@ -307,11 +330,14 @@ class Net:
         prog, handle = self._ensure((n, h, w))
         outs, ptrs = self._ext(prog, x)
         ws = self._workspace((n, h, w), prog, slot)
-        _check(self.ctx.lib.vse_plan_run(handle, C.c_void_p(ws.data_ptr()), ptrs, len(ptrs), self.ctx.stream()),
+        wt = self._width_table(prog, widths, n, w)
+        self.last_tlen = wt[prog.out_level] if wt is not None else None
+        _check(self.ctx.lib.vse_plan_run_ragged(handle, C.c_void_p(ws.data_ptr()), ptrs, len(ptrs),
+                                                C.c_void_p(wt.data_ptr()) if wt is not None else None, self.ctx.stream()),
                "vse_plan_run")
         return outs
 
-    def profile(self, x, slot=0):
+    def profile(self, x, slot=0, widths=None):
         """Per-op milliseconds (HIP events) for one run; returns (ms ndarray, program)."""
         n, h, w, _ = x.shape
         self.program(n, h, w)
@@ -319,7 +345,9 @@ class Net:
         outs, ptrs = self._ext(prog, x)
         ms = (C.c_float * len(prog.ops))()
         ws = self._workspace((n, h, w), prog, slot)
-        _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(ws.data_ptr()), ptrs, len(ptrs), self.ctx.stream(), ms),
+        wt = self._width_table(prog, widths, n, w)
+        _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(ws.data_ptr()), ptrs, len(ptrs),
+                                             C.c_void_p(wt.data_ptr()) if wt is not None else None, self.ctx.stream(), ms),
                "vse_plan_profile")
         variants = [self.ctx.lib.vse_plan_op_variant(handle, i) for i in range(len(prog.ops))]
         return np.array(ms[:], dtype=np.float32), prog, variants

@@ -141,6 +141,10 @@ def run_ocr_tasks(source, tasks, ocr, sub_area=None, rec_char_type="ch", drop_sc
             for (k, _), r in zip(items, out):
                 results[k] = r
     if shard is not None and shard[1] > 1:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() != shard[1]:
+            raise RuntimeError(f"run_ocr_tasks(shard={shard}): torch.distributed is not initialised with world size {shard[1]} — "
+                               "this rank recognised only its slice of the tasks and the other slices cannot be gathered")
         recs = [(k, _boxes_array(results[k][0]), list(results[k][1])) for k in sorted(results)]
         results = {k: (_boxes_list(b), r) for k, b, r in parallel.gather_records(recs, device=gather_device, to_all=True)}
     lines = []

@@ -13,8 +13,10 @@ import struct
 import numpy as np
 
 
-def write_avi_bgr24(path, frames, fps):
-    """Uncompressed AVI (one 'vids' stream, BI_RGB 24 bit, bottom-up rows padded to 4 bytes, idx1 index)."""
+def write_avi_bgr24(path, frames, fps, riff_frames=None, dropped=()):
+    """Uncompressed AVI (one 'vids' stream, BI_RGB 24 bit, bottom-up rows padded to 4 bytes, idx1 index).
+    riff_frames: start a new `RIFF....AVIX` segment (OpenDML, what ffmpeg's muxer does after ~1 GiB) every that many frames;
+    dropped: 0-based frame indices written as zero-length chunks (a dropped frame: the previous picture is shown again)."""
     frames = [np.asarray(f) for f in frames]
     h, w, _ = frames[0].shape
     stride = (w * 3 + 3) & ~3
@@ -30,16 +32,28 @@ def write_avi_bgr24(path, frames, fps):
     strh = b"vids" + b"DIB " + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, scale, rate, 0, len(frames), size, 0xFFFFFFFF, 0, 0, 0, w, h)
     strf = struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, size, 0, 0, 0, 0)
     hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
-    movi, idx = b"", b""
-    for f in frames:
+    segments, movi, idx = [], b"", b""
+    for k, f in enumerate(frames):
         assert f.shape == (h, w, 3) and f.dtype == np.uint8
-        rows = np.zeros((h, stride), np.uint8)
-        rows[:, :w * 3] = f[::-1].reshape(h, w * 3)
-        idx += b"00db" + struct.pack("<III", 0x10, 4 + len(movi), size)
-        movi += chunk(b"00db", rows.tobytes())
-    body = b"AVI " + hdrl + lst(b"movi", movi) + chunk(b"idx1", idx)
+        if riff_frames and k and k % riff_frames == 0:
+            segments.append(movi)
+            movi = b""
+        if k in dropped:
+            data = b""
+        else:
+            rows = np.zeros((h, stride), np.uint8)
+            rows[:, :w * 3] = f[::-1].reshape(h, w * 3)
+            data = rows.tobytes()
+        if not segments:
+            idx += b"00db" + struct.pack("<III", 0x10, 4 + len(movi), len(data))       # idx1 covers the first RIFF only
+        movi += chunk(b"00db", data)
+    segments.append(movi)
+    body = b"AVI " + hdrl + lst(b"movi", segments[0]) + chunk(b"idx1", idx)
     with open(path, "wb") as fp:
         fp.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        for seg in segments[1:]:
+            body = b"AVIX" + lst(b"movi", seg)
+            fp.write(b"RIFF" + struct.pack("<I", len(body)) + body)
 
 
 class AviBgr24Source:
@@ -54,7 +68,17 @@ class AviBgr24Source:
         self._offsets = []
         self.width = self.height = None
         self.fps = None
-        self._walk(12, struct.unpack("<I", head[4:8])[0] + 8)
+        # every top-level RIFF chunk: the 'AVI ' one, then the OpenDML 'AVIX' segments a muxer opens about every GiB (170 frames
+        # of 1080p bgr24) — a reader that stops after the first would silently see the first seconds of a clip only
+        self._fp.seek(0, 2)
+        size, pos = self._fp.tell(), 0
+        while pos + 12 <= size:
+            self._fp.seek(pos)
+            tag, n, kind = struct.unpack("<4sI4s", self._fp.read(12))
+            if tag != b"RIFF" or kind not in (b"AVI ", b"AVIX"):
+                raise ValueError(f"{path}: {size - pos} bytes behind the last RIFF chunk are not an AVI segment ({tag!r} {kind!r})")
+            self._walk(pos + 12, min(pos + 8 + n, size))
+            pos += 8 + n + (n & 1)
         if self.width is None or self.fps is None:
             raise ValueError(f"{path}: no video stream header")
         self.frame_count = len(self._offsets)
@@ -91,6 +115,11 @@ class AviBgr24Source:
         if not 1 <= frame_no <= self.frame_count:
             return None
         off, n = self._offsets[frame_no - 1]
+        while n == 0 and frame_no > 1:          # zero-length chunk = dropped frame: the previous picture stays on screen
+            frame_no -= 1
+            off, n = self._offsets[frame_no - 1]
+        if n < self._stride * self.height:
+            return None
         self._fp.seek(off)
         rows = np.frombuffer(self._fp.read(n), np.uint8)[:self._stride * self.height].reshape(self.height, self._stride)
         img = rows[:, :self.width * 3].reshape(self.height, self.width, 3)

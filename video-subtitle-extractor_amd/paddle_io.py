@@ -226,7 +226,7 @@ _KEEP = {
                          "output_size", "data_format"],
     "batch_norm": ["epsilon", "data_layout"],
     "pool2d": ["pooling_type", "ksize", "strides", "paddings", "ceil_mode", "exclusive", "adaptive",
-               "global_pooling", "padding_algorithm"],
+               "global_pooling", "padding_algorithm", "data_format"],
     "hard_swish": ["offset", "scale", "threshold"],
     "hard_sigmoid": ["slope", "offset"],
     "swish": ["beta"],

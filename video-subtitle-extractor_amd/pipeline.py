@@ -7,11 +7,16 @@ Replaces paddleocr's TextDetector / TextRecognizer / TextSystem as called from b
 and backend/tools/ocr.py:27.  Unlike the reference (one frame per call) every stage takes a BATCH of
 frames: frames are independent, so det runs N frames per launch and rec runs the crops of all N frames.
 
-Two recognition batching modes:
-  * "reference": per frame, crops sorted by w/h, chunks of rec_batch_num, each chunk padded to its own
-    max width — bit-for-bit the reference's grouping (batch composition changes logits).
-  * "bucketed": crops of all frames sorted by width and grouped into width buckets (multiples of `bucket`)
-    for throughput; padding differs from the reference grouping, so logits near the right edge may differ.
+Recognition batching.  The reference recognises the crops of ONE frame in chunks of rec_batch_num (6), each chunk
+zero-padded to its own widest crop, and what a crop's logits are depends on that padded width (conv borders, SVTR
+attention span).  Three modes:
+  * "reference": exactly that launch structure — one network run per chunk.
+  * "ragged" (default): every crop keeps the padded width of ITS reference chunk, but crops of all frames share
+    launches: the recogniser plans are compiled for ragged batches (compiler.compile_model(ragged=True)), every
+    kernel treats x >= a sample's width as outside the image, and a sample's outputs are bit-identical to the
+    "reference" mode's whatever batch it rides in.  Groups are formed for throughput only (width buckets).
+  * "bucketed": crops padded to the width of their bucket — faster grouping of round 1-2, NOT the reference's
+    padding (logits near the right edge differ); kept for A/B.
 """
 import math
 
@@ -59,7 +64,7 @@ def resolve_det_weights(det_weights, weights):
 class OcrPipeline:
     def __init__(self, ctx, det_model, rec_model, charset, rec_batch_num=6, rec_h=48, rec_base_w=320,
                  limit_side_len=960, db_thresh=0.3, db_box_thresh=0.6, db_unclip_ratio=1.5, drop_score=0.0,
-                 rec_mode="reference", bucket=64, batch_round=1, max_rec_batch=64, det_weights="auto", min_rec_group=0):
+                 rec_mode="ragged", bucket=64, batch_round=1, max_rec_batch=64, det_weights="auto", min_rec_group=0):
         """det_model / rec_model: (descriptor, weights dict).
         det_weights: "fp16" | "fp16x2" | "auto".  fp16x2 stores the detector's conv weights as fp16 hi + lo pairs (two K
         passes into the same fp32 accumulators): the rounding of BN-folded weights to fp16 is what moves box borders against
@@ -68,7 +73,8 @@ class OcrPipeline:
         self.ctx = ctx
         self.det_weights = det_weights = resolve_det_weights(det_weights, det_model[1])
         self.det = engine.Net(ctx, det_model[0], det_model[1], fetch_cols=(0,), hilo=det_weights == "fp16x2")
-        self.rec = engine.Net(ctx, rec_model[0], rec_model[1], want_probs=False)
+        # ragged plans for every mode: "reference" runs them with uniform widths, so the modes share kernels and summation orders
+        self.rec = engine.Net(ctx, rec_model[0], rec_model[1], want_probs=False, ragged=True)
         self.charset = charset
         self.rec_batch_num = rec_batch_num
         self.rec_h = rec_h
@@ -84,10 +90,10 @@ class OcrPipeline:
         self.profile_sink = None              # list: when set, every net run is profiled per op and appended here
         self.rec_streams = 1                  # >1: width groups of the recogniser run on that many side streams
 
-    def _run(self, net, x, slot=0):
+    def _run(self, net, x, slot=0, widths=None):
         if getattr(self, "profile_sink", None) is not None:
-            self.profile_sink.append(net.profile(x, slot))
-        return net.run(x, slot)
+            self.profile_sink.append(net.profile(x, slot, widths=widths))
+        return net.run(x, slot, widths=widths)
 
     # ---- detection ---------------------------------------------------------------------------------------
     def det_maps(self, frames, slot=0):
@@ -134,45 +140,58 @@ class OcrPipeline:
                                   iw=max(iw, 1), ih=max(ih, 1)))
         return specs
 
-    def _groups(self, specs):
-        """-> list of (list of spec indices, img_w)."""
-        groups = []
+    def _reference_chunks(self, specs):
+        """The reference's grouping: per frame, crops sorted by w/h, chunks of rec_batch_num, every chunk as wide as its
+        widest crop (at least rec_base_w).  -> list of (spec indices, img_w)."""
+        chunks = []
         base = self.rec_base_w / float(self.rec_h)
+        by_frame = {}
+        for i, s in enumerate(specs):
+            by_frame.setdefault(s.get("gframe", s["frame"]), []).append(i)
+        for f in sorted(by_frame):
+            idx = by_frame[f]
+            order = [idx[j] for j in np.argsort(np.array([specs[i]["ratio"] for i in idx]), kind="stable")]
+            for b in range(0, len(order), self.rec_batch_num):
+                chunk = order[b:b + self.rec_batch_num]
+                mx = max([base] + [specs[i]["ratio"] for i in chunk])
+                chunks.append((chunk, int(self.rec_h * mx)))
+        return chunks
+
+    def _groups(self, specs):
+        """-> list of (spec indices, tensor width, per-sample widths): one recogniser run each."""
         if self.rec_mode == "reference":
-            by_frame = {}
-            for i, s in enumerate(specs):
-                by_frame.setdefault(s.get("gframe", s["frame"]), []).append(i)
-            for f in sorted(by_frame):
-                idx = by_frame[f]
-                order = [idx[j] for j in np.argsort(np.array([specs[i]["ratio"] for i in idx]), kind="stable")]
-                for b in range(0, len(order), self.rec_batch_num):
-                    chunk = order[b:b + self.rec_batch_num]
-                    mx = max([base] + [specs[i]["ratio"] for i in chunk])
-                    groups.append((chunk, int(self.rec_h * mx)))
+            return [(chunk, w, [w] * len(chunk)) for chunk, w in self._reference_chunks(specs)]
+        if self.rec_mode == "ragged":
+            own = {}
+            for chunk, w in self._reference_chunks(specs):
+                for i in chunk:
+                    own[i] = w                      # the padded width crop i has in the reference
+            need = [own[i] for i in range(len(specs))]
         else:
-            def wneed(s):
-                return max(self.rec_base_w, int(math.ceil(self.rec_h * s["ratio"])))
-            buckets = {}
-            for i, s in enumerate(specs):
-                wb = (wneed(s) + self.bucket - 1) // self.bucket * self.bucket
-                buckets.setdefault(wb, []).append(i)
-            # a bucket with a handful of crops runs ~80 launches that fill a fraction of the chip (4 crops x 1280 px: 2.9 ms,
-            # 24 x 1024: 4.2 ms on MI355X): fold the next narrower bucket into it (its crops are padded further) until the
-            # group is worth its launches — from the widest bucket down, since only wider buckets can hold narrower crops
-            min_group = getattr(self, "min_rec_group", 0)
-            if min_group > 1:
-                widths = sorted(buckets, reverse=True)
-                k = 0
-                while k < len(widths) - 1:
-                    if len(buckets[widths[k]]) < min_group:
-                        buckets[widths[k]] += buckets.pop(widths[k + 1])
-                        del widths[k + 1]
-                    else:
-                        k += 1
-            for wb in sorted(buckets):
-                idx = buckets[wb]
-                for b in range(0, len(idx), self.max_rec_batch):
-                    groups.append((idx[b:b + self.max_rec_batch], wb))
+            need = [max(self.rec_base_w, int(math.ceil(self.rec_h * s["ratio"]))) for s in specs]
+        buckets = {}
+        for i, wn in enumerate(need):
+            wb = (wn + self.bucket - 1) // self.bucket * self.bucket
+            buckets.setdefault(wb, []).append(i)
+        # a bucket with a handful of crops runs ~80 launches that fill a fraction of the chip (4 crops x 1280 px: 2.9 ms,
+        # 24 x 1024: 4.2 ms on MI355X): fold the next narrower bucket into it (its crops are padded further) until the
+        # group is worth its launches — from the widest bucket down, since only wider buckets can hold narrower crops
+        min_group = getattr(self, "min_rec_group", 0)
+        if min_group > 1:
+            widths = sorted(buckets, reverse=True)
+            k = 0
+            while k < len(widths) - 1:
+                if len(buckets[widths[k]]) < min_group:
+                    buckets[widths[k]] += buckets.pop(widths[k + 1])
+                    del widths[k + 1]
+                else:
+                    k += 1
+        groups = []
+        for wb in sorted(buckets):
+            idx = buckets[wb]
+            for b in range(0, len(idx), self.max_rec_batch):
+                part = idx[b:b + self.max_rec_batch]
+                groups.append((part, wb, [need[i] for i in part] if self.rec_mode == "ragged" else [wb] * len(part)))
         return groups
 
     def recognize(self, frames, boxes_per_frame):
@@ -228,21 +247,24 @@ class OcrPipeline:
             for st in self._streams[:nstreams]:
                 st.wait_stream(main)
         try:
-            for gi, (idx, img_w) in enumerate(groups):
+            for gi, (idx, img_w, widths) in enumerate(groups):
                 if nstreams > 1:
                     t.cuda.set_stream(self._streams[gi % nstreams])
                 crops = []
-                for i in idx:
+                for i, wi in zip(idx, widths):
                     s = specs[i]
-                    rw = min(img_w, int(math.ceil(self.rec_h * s["ratio"])))
+                    rw = min(wi, int(math.ceil(self.rec_h * s["ratio"])))
                     crops.append(dict(quad=s["quad"], frame=s["frame"], crop_w=s["crop_w"], crop_h=s["crop_h"],
                                       resized_w=max(rw, 1), rotate=s["rotate"]))
+                widths = list(widths)
                 if self.rec_mode != "reference" and self.batch_round > 1:
                     while len(crops) % self.batch_round:
                         crops.append(crops[-1])           # dummy rows; their results are never read
+                        widths.append(widths[-1])
                 x = self.ctx.rec_preprocess(frames, crops, self.rec_h, img_w)
-                idx_maxp = self._run(self.rec, x, slot=gi % nstreams if nstreams > 1 else 0)[-1]          # [B,1,T,2]
-                oi, ol, oc = self.ctx.ctc_collapse(idx_maxp)
+                slot = gi % nstreams if nstreams > 1 else 0
+                idx_maxp = self._run(self.rec, x, slot=slot, widths=np.asarray(widths, np.int32))[-1]          # [B,1,T,2]
+                oi, ol, oc = self.ctx.ctc_collapse(idx_maxp, self.rec.last_tlen)
                 pending.append((idx, oi, ol, oc))
         finally:
             if nstreams > 1:

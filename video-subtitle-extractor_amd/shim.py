@@ -305,12 +305,13 @@ class TextRecognizer:
         ctx = _context()
         self.pipe = pipeline.OcrPipeline.__new__(pipeline.OcrPipeline)
         self.pipe.ctx = ctx
-        self.pipe.rec = engine.Net(ctx, model[0], model[1], want_probs=False)
+        self.pipe.rec = engine.Net(ctx, model[0], model[1], want_probs=False, ragged=True)
         self.pipe.charset = charset
         self.pipe.rec_batch_num = getattr(args, "rec_batch_num", 6)
         self.pipe.rec_h, self.pipe.rec_base_w = shp[1], shp[2]
-        self.pipe.rec_mode = "reference"
-        self.pipe.bucket, self.pipe.batch_round, self.pipe.max_rec_batch = 64, 1, 64
+        # every crop at the padded width of its reference chunk (sorted by w/h, chunks of rec_batch_num), chunks sharing launches
+        self.pipe.rec_mode = getattr(args, "rec_mode", "ragged")
+        self.pipe.bucket, self.pipe.batch_round, self.pipe.max_rec_batch, self.pipe.min_rec_group = 64, 1, 64, 0
         self.pipe.profile_sink = None
         self.pipe.rec_streams = 1
 
@@ -330,7 +331,7 @@ class PaddleOCR:
                        "det_limit_type", "benchmark", "warmup"}
 
     def __init__(self, det_model_dir=None, rec_model_dir=None, rec_batch_num=6, drop_score=0.5, lang="ch",
-                 use_angle_cls=False, rec_image_shape="3,48,320", rec_mode="reference", rec_char_dict_path=None,
+                 use_angle_cls=False, rec_image_shape="3,48,320", rec_mode="ragged", rec_char_dict_path=None,
                  use_space_char=True, det_algorithm="DB", rec_algorithm="CRNN", det_limit_side_len=960,
                  det_db_thresh=0.3, det_db_box_thresh=0.6, det_db_unclip_ratio=1.5, **backend):
         if use_angle_cls:

@@ -155,14 +155,18 @@ def cleanup_srt(srt_text, lang, segment, typo_map=None):
     """The same over SRT text in memory -> (new SRT text, number of modified blocks)."""
     out, modified = [], 0
     for idx, tm, text in parse_srt(srt_text):
-        new = cleanup_text(text, lang, segment, typo_map)
+        try:
+            new = cleanup_text(text, lang, segment, typo_map)
+        except Exception:               # reformat.py keeps a block it cannot process (segmenter / regex failure) and goes on
+            new = text
         modified += int(new != text)
         out.append((idx, tm, new))
     return format_srt(out), modified
 
 
 def execute(path, lang="en", segment=None, typo_map=None):
-    """reformat.execute(path, lang): rewrites the SRT file in place; -> number of modified blocks."""
+    """reformat.execute(path, lang): rewrites the SRT file in place; -> True like the reference (the number of modified
+    blocks is available from cleanup_srt)."""
     if segment is None:
         segment = default_segmenter()
     if typo_map is None:
@@ -172,4 +176,4 @@ def execute(path, lang="en", segment=None, typo_map=None):
         new, modified = cleanup_srt(f.read(), lang, segment, typo_map)
     with open(path, "w", encoding="utf-8") as f:
         f.write(new)
-    return modified
+    return True
