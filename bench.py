@@ -41,12 +41,15 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--models", default="server", choices=["server", "fast", "fast-real"])
+    ap.add_argument("--models", default="server", choices=["server", "fast", "fast-real", "v2"],
+                    help="server = V4_ch_det + V4_ch_rec (the headline); v2 = V2_ch_det + V2_ch_rec (ResNet + BiLSTM CRNN, 32-px crops)")
     ap.add_argument("--boxes", default="db", choices=["gt", "db"])
     ap.add_argument("--rec-mode", default="ragged", choices=["ragged", "bucketed", "reference"],
                     help="recogniser batching of the headline number (ragged = the reference's per-crop padded widths in shared "
                          "launches, bit-identical to `reference`); the other modes are timed beside it (`rec_modes` in the JSON line)")
     ap.add_argument("--other-mode-steps", type=int, default=4, help="timed steps of each non-headline rec mode (0 = skip)")
+    ap.add_argument("--limit-side", type=int, default=960, help="det_limit_side_len (960 = the reference's default; 3840 = BASELINE "
+                    "configs[2]'s stress form: a 4K frame becomes a 2176 x 3840 detector input)")
     ap.add_argument("--bucket", type=int, default=256, help="rec width bucket (px)")
     ap.add_argument("--batch-round", type=int, default=4)
     ap.add_argument("--min-rec-group", type=int, default=8,
@@ -183,6 +186,8 @@ def main():
         det_id, rec_id, lang = "V4_ch_det", "V4_ch_rec", "ch"
     elif args.models == "fast":
         det_id, rec_id, lang = "V4_ch_det_fast", "V4_ch_rec_fast", "ch"
+    elif args.models == "v2":
+        det_id, rec_id, lang = "V2_ch_det", "V2_ch_rec", "ch"
     else:
         det_id, rec_id, lang = "V3_ch_det_fast", "V4_en_rec_fast", "en"
     det = modelzoo.get_model(det_id, seed=0)
@@ -191,7 +196,8 @@ def main():
         det = (det[0], empty_det_head(det[0], det[1]))
     charset = shim.standin_charset(lang, shim._ncls(rec[0]))      # stand-in weights: index-faithful placeholder table
     pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode=args.rec_mode, bucket=args.bucket,
-                                batch_round=args.batch_round, min_rec_group=args.min_rec_group)
+                                batch_round=args.batch_round, min_rec_group=args.min_rec_group,
+                                rec_h=32 if args.models == "v2" else 48, limit_side_len=args.limit_side)
 
     pipe.rec_streams = args.rec_streams
     frames_np, truth = synth.make_frames(args.batch, args.height, args.width, seed=100 + rank, return_truth=True)
@@ -216,15 +222,17 @@ def main():
 
     coll_dev = ctx.tdev if backend == "nccl" else "cpu"
 
-    def step_local():
+    def records(k, boxes, res):
+        # frame numbers: step k of rank r covers frames [(k * world + r) * batch, ... + batch) of the job
+        base = (k * world + rank) * args.batch
+        return [(base + f, np.asarray(boxes[f], np.float32).reshape(-1, 4, 2), res[f]) for f in range(args.batch)]
+
+    def step_local(k=0):
         maps = det_maps()
         db = ctx.db_postprocess(maps, args.height, args.width, **pipe.db)
         boxes = [pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads
         res = pipe.recognize(frames, boxes)
-        return [(lo + f, np.asarray(boxes[f], np.float32).reshape(-1, 4, 2), res[f]) for f in range(args.batch)]
-
-    def step():
-        return parallel.gather_records(step_local(), device=coll_dev)     # the one collective of the path (all ranks)
+        return records(k, boxes, res)
 
     # Streaming form of the same work: the detector of batch k+1 (its own HIP stream and workspace slot) runs while batch k
     # goes through DB post-processing, the host-side box logic, the recogniser launches and the record gather — what a
@@ -243,32 +251,33 @@ def main():
         return maps, ev
 
     def stage2(handle):
-        maps, ev = handle
+        maps, ev = handle[:2]
         main = torch.cuda.current_stream(ctx.tdev)
         main.wait_event(ev)
         maps.record_stream(main)
         db = ctx.db_postprocess(maps, args.height, args.width, **pipe.db)
         boxes = [pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads
         res = pipe.recognize(frames, boxes)
-        recs = [(lo + f, np.asarray(boxes[f], np.float32).reshape(-1, 4, 2), res[f]) for f in range(args.batch)]
-        return parallel.gather_records(recs, device=coll_dev)
+        return records(handle[2], boxes, res)
 
     def run_steps(n):
+        """n complete det + rec passes over this rank's batch, then THE collective of the path: one variable-length gather of
+        every rank's (frame, boxes, texts) records to rank 0 (north_star: "RCCL ... only for the final box/text gather")."""
+        local = []
         if args.no_overlap:
-            out = None
-            for _ in range(n):
-                out = step()
-            return out
-        for st in det_streams:
-            st.wait_stream(torch.cuda.current_stream(ctx.tdev))
-        out, queue = None, []
-        for k in range(n):
-            queue.append(stage1(k))
-            if len(queue) > depth:
-                out = stage2(queue.pop(0))
-        while queue:
-            out = stage2(queue.pop(0))
-        return out
+            for k in range(n):
+                local += step_local(k)
+        else:
+            for st in det_streams:
+                st.wait_stream(torch.cuda.current_stream(ctx.tdev))
+            queue = []
+            for k in range(n):
+                queue.append(stage1(k) + (k,))
+                if len(queue) > depth:
+                    local += stage2(queue.pop(0))
+            while queue:
+                local += stage2(queue.pop(0))
+        return parallel.gather_records(local, device=coll_dev)
 
     def sync():
         if world > 1:
@@ -290,7 +299,7 @@ def main():
 
     out, dt = timed(args.warmup, args.steps)
     log(f"timed region ({args.rec_mode} rec batching): {args.warmup} warmup + {args.steps} steps in {dt:.3f}s")
-    n_boxes = sum(len(r[1]) for r in out) if out is not None else 0
+    n_boxes = sum(len(r[1]) for r in out[-world * args.batch:]) if out is not None else 0
     # the other recogniser batching mode on the same workload, timed the same way (fewer steps: the reference grouping runs
     # one launch sequence per <= 6 crops of ONE frame and is launch-bound)
     rec_modes = {args.rec_mode: {"value": round(world * args.batch * args.steps / dt, 2), "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -314,7 +323,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{args.batch}x{args.height}p frames/GPU/step, precise mode: {det_id} @544x960 + "
+            "config": {"workload": f"{args.batch}x{args.height}p frames/GPU/step, precise mode: {det_id} @{'x'.join(str(v) for v in pipeline.det_resize_shape(args.height, args.width, args.limit_side))} + "
                                    f"{rec_id}, {n_lines} text lines/batch, rec boxes={args.boxes}, rec batching="
                                    + {"bucketed": f"bucketed({args.bucket}px, min group {args.min_rec_group}): crops padded to their bucket, NOT "
                                                   "the reference's padding",
@@ -325,13 +334,14 @@ def main():
                        "det_map": ("detector output" if overlay is None else
                                    f"stand-in detector output (head bias -8) max-overlaid inside the step with the text-kernel map of the "
                                    f"generator's lines: {100.0 * float((overlay_np > pipe.db['thresh']).mean()):.2f} % of pixels > thresh"),
-                       "boxes_from_db_last_step": n_boxes,
+                       "boxes_last_step": n_boxes,
                        "rec_modes": rec_modes,
                        "streaming": "sequential batches" if args.no_overlap else
                                     f"detectors of the next {depth} batch(es) in flight (own HIP streams / workspace slots) while batch k is "
                                     "post-processed and recognised; all K batches start and finish inside the timed region",
                        "frames_per_gpu_step": args.batch, "det_model": det_id, "rec_model": rec_id,
                        "weights": "real" if modelzoo.has_real_weights(det_id) else "seeded random (reference blobs missing)",
+                       "gather": "one variable-length gather of all ranks' records to rank 0 at the end of the timed region",
                        "records_gathered": len(out) if out is not None else 0},
         }
         if not args.no_roofline:
@@ -346,32 +356,6 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return result
-
-
-def variant_kernel_name(code):
-    """vse_plan_op_variant() code -> the kernel instantiation rocprofv3 reports (see csrc/vse_runtime.hip)."""
-    code = int(code)
-    tiles = {128: "128, 128, 2, 2", 64: "256, 64, 4, 1", 32: "256, 32, 4, 1"}
-    if code >= 800000:
-        return f"conv_pw_kernel<{code - 800000}>"
-    if code >= 700000:
-        return f"conv_c3_kernel<{code - 700000}, {8 // (code - 700000)}>"
-    if code >= 600000:
-        return f"conv_col_kernel<{(code - 600000) // 100}, {code % 100}>"
-    if code >= 500000:
-        return "conv_stem_kernel"
-    if code >= 400000:
-        return "conv_head_up2_kernel"
-    if 1000 <= code < 300000 and code % 1000 in (32, 64, 128) and (code // 1000) % 100 in (8, 16):      # before the gemm range: mode 2 = 2xxxxx
-        return f"conv_patch_kernel<{(code // 1000) % 100}, {code % 1000}, {code // 100000}>"
-    if code >= 200000:
-        cfg = {0: "128, 128, 2, 2, 32, 3", 1: "256, 64, 4, 1, 32, 3", 2: "256, 32, 4, 1, 32, 3", 6: "256, 128, 4, 2, 32, 3",
-               16: "256, 256, 4, 4, 32, 3", 17: "256, 192, 8, 2, 32, 3", 18: "256, 256, 4, 4, 64, 2",
-               19: "256, 192, 8, 2, 64, 2"}.get((code - 200000) // 10)
-        return f"conv_gemm_kernel<{cfg}, {code % 10}>" if cfg else f"conv_gemm_kernel<cfg {(code - 200000) // 10}>"
-    if code >= 1000 and code % 1000 in (32, 64, 128) and (code // 1000) % 100 in (8, 16):
-        return f"conv_patch_kernel<{(code // 1000) % 100}, {code % 1000}, {code // 100000}>"
-    return f"conv_mfma_kernel<{tiles[code % 1000]}, {'true' if code >= 10000 else 'false'}>"
 
 
 def roofline(pipe, step, repeats=2):
@@ -395,7 +379,7 @@ def roofline(pipe, step, repeats=2):
         pipe_last_sink = pipe.profile_sink
         pipe.profile_sink = None
     bn, (tms, gmac, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
-    kname = variant_kernel_name(bn)
+    kname = bn
     achieved = 2.0 * gmac / tms          # GMAC/ms*2 = TFLOP/s
     # HBM bytes per launch of that kernel from the newest committed PMC summary that has it (separate rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE passes over this same command, tools/collect_profiles.sh; FETCH_SIZE doubled as the gfx950 guide prescribes)
@@ -424,7 +408,7 @@ def roofline(pipe, step, repeats=2):
             "all_conv_tflops": round(2.0 * sum(v[1] for v in agg.values()) / all_ms, 2),
             "conv_ms_per_step": round(all_ms / repeats, 3),
             # the other conv kernel instantiations by share of conv time (same definition of `achieved` for each)
-            "kernels": [{"kernel": variant_kernel_name(v), "share": round(t / all_ms, 3), "launches_per_step": c // repeats,
+            "kernels": [{"kernel": v, "share": round(t / all_ms, 3), "launches_per_step": c // repeats,
                          "achieved": round(2.0 * g / t, 1), "frac": round(2.0 * g / t / MFMA_PEAK_TFLOPS, 3)}
                         for v, (t, g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:6]]}
 

@@ -95,15 +95,22 @@ int vse_plan_width_levels(vse_plan* plan);
  * vse_plan_run_ragged (NULL for an ordinary plan). */
 int vse_plan_profile(vse_plan* plan, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream, float* ms);
 
-/* Which kernel instantiation op `i` dispatches to: for conv ops the BN of conv_mfma_kernel<BM,BN,..> (128/64/32),
- * 0 for every other op kind.  Lets the bench attribute measured time to the kernel names rocprofv3 reports. */
+/* Which kernel instantiation op `i` dispatches to, as the name rocprofv3 reports ("conv_c3_kernel<4, 2>",
+ * "conv_gemm_kernel<256, 256, 4, 4, 64, 2, 0>", "dwconv_kernel" ...): lets bench.py attribute the time vse_plan_profile
+ * measures to the kernels of the committed rocprof summaries.  The string is thread-local and valid until the next call. */
+const char* vse_plan_op_kernel_name(vse_plan* plan, int i);
+/* The same as an integer key (kernel family x template parameters; 0 for non-conv ops) for per-layer A/B tools
+ * (tools/bench_conv.py); the encoding is private to csrc/vse_runtime.hip — use vse_plan_op_kernel_name for anything shown. */
 int vse_plan_op_variant(vse_plan* plan, int i);
 
 /* ---- det pre-processing ----------------------------------------------------------------------------- */
 /* uint8 BGR frames [n, src_h, src_w, 3] (row pitch `pitch` bytes, frame stride `frame_stride` bytes) ->
  * bilinear resize to [dst_h, dst_w] with OpenCV's fixed-point INTER_LINEAR arithmetic -> (x/255-mean)/std ->
  * fp16 NHWC with 8 physical channels (3 real).  Replaces paddleocr DetResizeForTest + NormalizeImage +
- * ToCHWImage behind backend/tools/subtitle_detect.py:25. */
+ * ToCHWImage behind backend/tools/subtitle_detect.py:25.
+ * mean3 == std3 == NULL: RAW mode — channels 0..2 hold the resized uint8 values themselves (exact in fp16) and channel 3
+ * the constant 1; a detector plan compiled with the normalisation folded into its stem conv (compiler input_norm) takes
+ * this input and computes on exactly the reference's normalised values instead of their fp16 roundings. */
 int vse_det_preprocess(vse_ctx* ctx, const void* d_bgr, int n, int src_h, int src_w, int64_t pitch,
                        int64_t frame_stride, void* d_out_f16, int dst_h, int dst_w, const float* mean3,
                        const float* std3, void* stream);

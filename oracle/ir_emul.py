@@ -357,12 +357,21 @@ class Emulator:
         if int(r["out2"]["n"]) > 0:
             self.write(r["out2"], pr)
 
-    def _op12(self, r):  # LSTM (one direction of one layer); in0 = fp32 gate pre-activations [B,1,T,4H]
+    def _op12(self, r):  # LSTM recurrence; in0 (/ in1) = fp32 gate pre-activations [B,1,T,4H] of one (/ the reverse) direction
         H = int(r["p"][ir.P_HID])
-        rev = bool(r["p"][ir.P_REVERSE])
-        whh = torch.from_numpy(self.wread(int(r["w_off"]), H * 4 * H, np.float16).astype(np.float32).reshape(H, 4 * H))
+        mode = int(r["p"][ir.P_REVERSE])
+        if int(r["flags"]) & ir.F_LSTM_MFMA:
+            # W_hh^T in MFMA fragment order [dir][wave 8][gate 4][slice 16][k-half 2][row 32][8] -> [H, 4H] per direction
+            assert H == 256
+            ndir = 2 if mode == 2 else 1
+            wt = self.wread(int(r["w_off"]), ndir * 4 * H * H, np.float16).astype(np.float32).reshape(ndir, 8, 4, 16, 2, 32, 8)
+            whhs = [torch.from_numpy(np.ascontiguousarray(wt[d].transpose(1, 0, 4, 2, 3, 5)).reshape(4 * H, H).T.copy()) for d in range(ndir)]
+            dirs = [(r["in0"], whhs[0], mode == 1)] + ([(r["in1"], whhs[1], True)] if ndir == 2 else [])
+        else:
+            whh = torch.from_numpy(self.wread(int(r["w_off"]), H * 4 * H, np.float16).astype(np.float32).reshape(H, 4 * H))
+            dirs = [(r["in0"], whh, bool(mode))]
 
-        def lstm(g):
+        def lstm(g, whh, rev):
             B, _, T, _ = g.shape
             h = torch.zeros(B, H)
             c = torch.zeros(B, H)
@@ -372,11 +381,12 @@ class Emulator:
                 i, f_, gg, o = z.chunk(4, dim=1)
                 c = torch.sigmoid(f_) * c + torch.sigmoid(i) * torch.tanh(gg)
                 h = torch.sigmoid(o) * torch.tanh(c)
-                if self.round:
-                    h = h.half().float()
+                if self.round and not (int(r["flags"]) & ir.F_LSTM_MFMA):
+                    h = h.half().float()            # (the MFMA kernel carries h as fp16 hi + lo: fp32-grade state)
                 out[:, 0, t] = h
             return out
-        self.write(r["out"], self.per_sample(self.read(r["in0"]), lstm))
+        outs = [self.per_sample(self.read(v), lambda g, w=w, rv=rv: lstm(g, w, rv)) for v, w, rv in dirs]
+        self.write(r["out"], torch.cat(outs, dim=3))
 
     def _op13(self, r):  # WSCALE: per-image 1x1 weights = tiled weight blob x SE gate over k, rounded to fp16 once
         p = r["p"]

@@ -191,8 +191,22 @@ def run_graph(desc, weights, x, return_all=False, _calibrate=False):
     env = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
     x = torch.as_tensor(x, dtype=torch.float32)
     fetch = {}
+    # activations are dropped after their last reader (unless the caller wants them all): the 2176 x 3840 detector input of
+    # the 4K stress configuration would otherwise keep ~100 GB of fp32 intermediates alive
+    last = {}
+    for oi, op in enumerate(desc["ops"]):
+        for names in op["in"].values():
+            for nm in names:
+                last[nm] = oi
+    dead = {}
+    for nm, oi in last.items():
+        if nm not in weights:
+            dead.setdefault(oi + 1, []).append(nm)
     with torch.no_grad():
-        for op in desc["ops"]:
+        for oi, op in enumerate(desc["ops"]):
+            if not return_all:
+                for nm in dead.get(oi, ()):
+                    env.pop(nm, None)
             t = op["type"]
             a = op["attrs"]
             I = {k: [env[n] for n in v] for k, v in op["in"].items()} if t != "feed" else {}

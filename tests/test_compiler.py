@@ -336,3 +336,32 @@ def test_ragged_plan_refuses_detector_graphs():
     desc, w = net_ref.get_weights("V4_ch_det_fast")
     with pytest.raises(compiler.UnsupportedGraph):
         compiler.compile_model(desc, w, 1, 64, 96, ragged=True)
+
+
+@pytest.mark.parametrize("mid,hilo", [("V3_ch_det_fast", True), ("V4_ch_det_fast", False), ("V4_ch_det", False), ("V2_ch_det", False)])
+def test_input_norm_folded_into_the_stem(mid, hilo):
+    """compile_model(input_norm=(mean, std)): the plan takes the RAW resized pixels (integers, exact in fp16) + a ones channel
+    and computes what the oracle computes on (u/255 - mean)/std in fp32 (paddleocr NormalizeImage, App. C.1) — closer than
+    the plan fed the fp16-rounded normalised image."""
+    from oracle import pipeline_ref
+    from vse_amd import synth
+    desc, w = net_ref.get_weights(mid)
+    frame = synth.make_frames(1, 96, 160, seed=5)[0]
+    x, _ = pipeline_ref.det_preprocess(frame)                 # fp32 normalised, what the reference feeds
+    ref = net_ref.run_graph(desc, w, x)[0].numpy()[:, 0]
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    raw = np.zeros((1, 96, 160, 8), np.float32)
+    raw[..., :3] = frame[None].astype(np.float32)             # no resize at this size: det_preprocess is the identity on pixels
+    raw[..., 3] = 1.0
+    chk = (raw[0, ..., :3] / 255.0 - np.asarray(mean, np.float32)) / np.asarray(std, np.float32)
+    assert np.abs(chk.transpose(2, 0, 1) - x[0]).max() < 1e-5
+    prog = compiler.compile_model(desc, w, 1, 96, 160, hilo=hilo, input_norm=(mean, std))
+    got = ir_emul.Emulator(prog).run(raw)[0][..., 0]
+    prog0 = compiler.compile_model(desc, w, 1, 96, 160, hilo=hilo)
+    got0 = ir_emul.Emulator(prog0).run(ir_emul.to_nhwc8(x))[0][..., 0]
+    e, e0 = np.abs(got - ref).max(), np.abs(got0 - ref).max()
+    assert e < 5e-3, e
+    if hilo:                           # with ~22-bit weights the fp16 rounding of the INPUT is the error that is left: gone
+        assert e < 0.5 * e0 + 1e-6, (e, e0)
+    # compiling twice from the same descriptor must not see the first compile's rewritten stem
+    compiler.compile_model(desc, w, 1, 96, 160, hilo=hilo, input_norm=(mean, std))

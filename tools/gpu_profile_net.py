@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-op timing of one model on the GPU (HIP events inside vse_plan_profile).
-usage: python tools/gpu_profile_net.py MODEL N H W [--top K]"""
+usage: python tools/gpu_profile_net.py MODEL N H W [--top K] [--hilo] [--ragged [--wmin W0]]
+--ragged: a recogniser plan for ragged batches; sample widths are spread evenly over [W0 (default 320), W]."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -25,14 +26,22 @@ def main():
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 25
     desc, wts = modelzoo.get_model(mid)
     ctx = engine.Context(0)
-    net = engine.Net(ctx, desc, wts, want_probs=False, hilo="--hilo" in sys.argv)
+    ragged = "--ragged" in sys.argv
+    net = engine.Net(ctx, desc, wts, want_probs=False, hilo="--hilo" in sys.argv, ragged=ragged)
     x = (torch.rand((n, h, w, 8), device="cuda") * 2 - 1).half()
     x[..., 3:] = 0
+    widths = None
+    if ragged:
+        w0 = int(sys.argv[sys.argv.index("--wmin") + 1]) if "--wmin" in sys.argv else 320
+        widths = np.linspace(w0, w, n).astype(np.int32)
+        for i, wi in enumerate(widths):
+            x[i, :, int(wi):] = 0
+        print("sample widths:", widths.tolist())
     for _ in range(2):
-        net.run(x)
+        net.run(x, widths=widths)
     torch.cuda.synchronize()
-    ms, prog, _ = net.profile(x)
-    ms2, _, _ = net.profile(x)
+    ms, prog, names = net.profile(x, widths=widths)
+    ms2, _, _ = net.profile(x, widths=widths)
     ms = np.minimum(ms, ms2)
     tot = ms.sum()
     print(f"{mid} N={n} {h}x{w}: {len(ms)} ops, total {tot:.3f} ms, algorithmic {prog.gmacs:.2f} GMAC -> "
@@ -54,7 +63,7 @@ def main():
             extra = (f"k{p[0]}x{p[1]} s{p[2]} cin{p[ir.P_CINP]} N{p[ir.P_COUT]} K{p[ir.P_KTOT]} "
                      f"{2 * macs / ms[k] / 1e9:.0f} TF/s(padded)")
         print(f"  op{k:3d} kind={int(r['kind']):2d} {ms[k]:8.3f} ms {100 * ms[k] / tot:5.1f}%  out[{o['n']},{o['h']},{o['w']},{o['c']}] "
-              f"{prog.names[k][:28]:28s} {extra}")
+              f"{prog.names[k][:28]:28s} {names[k]:44s} {extra}")
 
 
 if __name__ == "__main__":

@@ -6,4 +6,6 @@ run --no-overlap
 run --det-depth 1
 run --height 2160 --width 3840 --batch 32
 run --height 720 --width 1280 --models fast
-run --models fast-real --boxes db
+run --models fast-real
+run --models v2
+run --height 2160 --width 3840 --batch 8 --limit-side 3840

@@ -191,6 +191,7 @@ PW_MAX_COUT = int(os.environ.get("VSE_PW_MAXCOUT", "64"))
 COL3_MIN_K = int(os.environ.get("VSE_COL3_MINK", "250"))   # 3x3 32->32 @136x240 (K = 288): 0.180 ms on the implicit GEMM, 0.115 ms here
 COL3_WIDE_MIN_CIN = 128    # layers with more than 64 couts (two+ cout tiles refetch the patch) only from 128 input channels on
 COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
+LSTM_MFMA = os.environ.get("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
 
 
 def c3_tile_eff(oh, ow):
@@ -258,6 +259,7 @@ class Compiler:
         self.wlevels = [None]                 # level 0 = the input width
         self.wlevel_index = {}
         self.sel_w0 = 320                     # kernel selection of a ragged plan looks at THIS input width, never at the batch's
+        self.input_norm = None                # (mean3, std3): see fold_input_norm
         self._merge_parallel_convs()
         self.N, self.H, self.Wd = batch, height, width
         self.fetch_cols = tuple(fetch_cols)
@@ -490,6 +492,34 @@ class Compiler:
         r["n"], r["h"], r["w"] = v.n, v.src_h, v.src_w
         r["c"], r["ld"], r["esize"] = v.span, b.ld, b.esize
         return r
+
+    # -------------------------------------------------------------------------------------------- exact detector input
+    def fold_input_norm(self):
+        """The reference feeds the detector (u/255 - mean)/std in fp32 (paddleocr NormalizeImage); rounding
+        that to fp16 alone moves the real detector's map by up to 4e-3.  The resized pixels u are integers <= 255, exact in
+        fp16: feed THEM (vse_det_preprocess raw mode: channels 0..2 = u, channel 3 = 1 inside the image) and let every conv
+        that reads the feed carry the normalisation in its weights:
+            w'[co, c, tap] = w[co, c, tap] / (255 std_c)   (c < 3),      w'[co, 3, tap] = - sum_c w[co, c, tap] mean_c / std_c.
+        Zero padding of the 4-channel raw input is then the reference's zero padding of the normalised image, exactly (the ones
+        channel is 0 outside the image too).  Returns the feed's logical channel count (4)."""
+        mean, std = (np.asarray(v, np.float64).reshape(3) for v in self.input_norm)
+        feeds = {op["out"]["Out"][0] for op in self.ops if op["type"] == "feed"}
+        for k, op in enumerate(self.ops):
+            if not any(nm in feeds for names in op["in"].values() for nm in names):
+                continue
+            if op["type"] != "conv2d" or op["attrs"].get("groups", 1) != 1 or op["in"]["Input"][0] not in feeds:
+                raise UnsupportedGraph(f"input_norm: the feed is read by a {op['type']} (only a dense conv can carry the normalisation)")
+            wname = op["in"]["Filter"][0]
+            w = self.W[wname].astype(np.float64)
+            if w.shape[1] != 3:
+                raise UnsupportedGraph("input_norm: the stem conv does not take 3 input channels")
+            aug = np.zeros((w.shape[0], 4) + w.shape[2:], np.float64)
+            aug[:, :3] = w / (255.0 * std).reshape(1, 3, 1, 1)
+            aug[:, 3] = -(w * (mean / std).reshape(1, 3, 1, 1)).sum(1)
+            new = wname + ":input_norm"
+            self.W[new] = aug                                   # fp64: BN folding and the hi + lo split work on it
+            self.ops[k] = dict(op, **{"in": dict(op["in"], Filter=[new])})      # (the descriptor's own op record stays untouched)
+        return 4
 
     # -------------------------------------------------------------------------------------------- ragged widths
     def wl_after(self, lvl, k, s, p, ceil=False):
@@ -1537,6 +1567,16 @@ class Compiler:
         self.env[name] = iv
         self._fetched = name
 
+    @staticmethod
+    def lstm_fragments(w_hh):
+        """W_hh [4H, H] (gate order i, f, g, o; H = 256) -> fp16 in the order lstm_mfma_kernel streams it: wave w owns hidden
+        units 32w .. 32w+31; per (wave, gate, 16-deep k slice) one MFMA A fragment = [lane 64][8]: row = lane & 31 (unit
+        32w + row of that gate), k = 16 s + 8 (lane >> 5) + j."""
+        H = w_hh.shape[1]
+        assert w_hh.shape == (4 * H, H) and H == 256
+        w5 = w_hh.reshape(4, 8, 32, 16, 2, 8)                     # [gate][wave][row][slice][k-half][j]
+        return np.ascontiguousarray(w5.transpose(1, 0, 3, 4, 2, 5)).astype(np.float16).reshape(-1)       # [wave][gate][slice][k-half][row][j]
+
     def lower_rnn(self, i):
         op = self.ops[i]
         a = op["attrs"]
@@ -1551,8 +1591,10 @@ class Compiler:
         ncell = L * ndir
         cur = x
         name = op["out"]["Out"][0]
+        mfma = LSTM_MFMA and H == 256
         for layer in range(L):
             outb = self.new_buf(cur.n, 1, cur.w, ndir * H)
+            gate_views, frag = [], []
             for d in range(ndir):
                 c = layer * ndir + d
                 w_ih = self.W[wl[2 * c]].astype(np.float64)       # [4H,in]
@@ -1572,10 +1614,22 @@ class Compiler:
                              ir.P_RESSHIFT: 0, ir.P_CINP: cur.span},
                           f={ir.FS_POST_A: 1.0}, w_off=w_off, b_off=b_off)
                 self.add_gmacs(cur.n * cur.w * cur.c * 4 * H / 1e9)
+                if mfma:
+                    gate_views.append(gates)
+                    frag.append((wl[2 * c + 1], w_hh))
+                    continue
                 whh_off = self.add_weights(("lstm_hh", wl[2 * c + 1]), w_hh.T.copy().astype(np.float16))  # [H][4H]
                 ov = View(outb, d * H, cur.n, 1, cur.w, [(0, H)], H)
                 self.emit(ir.OP_LSTM, key, [gates], ov, p={ir.P_HID: H, ir.P_REVERSE: d}, w_off=whh_off)
                 self.add_gmacs(cur.n * cur.w * H * 4 * H / 1e9)
+            if mfma:
+                # the recurrence of every direction of the layer in ONE launch (csrc/lstm.hip): batch-shared MFMA GEMM per step
+                whh_off = self.add_weights(("lstm_hh_mfma",) + tuple(nm for nm, _ in frag),
+                                           lambda: np.concatenate([self.lstm_fragments(w) for _, w in frag]))
+                ov = View(outb, 0, cur.n, 1, cur.w, [(0, ndir * H)], ndir * H)
+                self.emit(ir.OP_LSTM, f"{name}:l{layer}", gate_views, ov, flags=ir.F_LSTM_MFMA,
+                          p={ir.P_HID: H, ir.P_REVERSE: 2 if ndir == 2 else 0}, w_off=whh_off)
+                self.add_gmacs(ndir * cur.n * cur.w * H * 4 * H / 1e9)
             cur = View(outb, 0, cur.n, 1, cur.w, [(0, ndir * H)], ndir * H, 0, "tbc")
         self.env[name] = cur
 
@@ -1585,12 +1639,13 @@ class Compiler:
         inb = self.new_buf(N, H, Wd, 8, ext=0)
         if self.ragged:
             inb.wl = 0
+        feed_c = self.fold_input_norm() if self.input_norm is not None else 3
         for i, op in enumerate(self.ops):
             if i in self.done or not self.live[i]:
                 continue
             t = op["type"]
             if t == "feed":
-                self.env[op["out"]["Out"][0]] = View(inb, 0, N, H, Wd, [(0, 3)], 8)
+                self.env[op["out"]["Out"][0]] = View(inb, 0, N, H, Wd, [(0, feed_c)], 8)
             elif t == "fetch":
                 self._lower_fetch(i)
             elif t in ("conv2d", "depthwise_conv2d", "conv2d_transpose"):
@@ -1699,7 +1754,7 @@ class Compiler:
 
 
 def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True, hilo=False,
-                  ragged=False):
+                  ragged=False, input_norm=None):
     """reuse=False gives every buffer its own workspace range (debugging: all intermediates stay readable).
     hilo=True stores every conv / depthwise / transposed-conv weight as an fp16 hi + lo pair (F_HILO): ~22-bit weights for
     twice the MFMA work — for nets whose boxes must track an fp32 reference closely.
@@ -1708,6 +1763,7 @@ def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_pro
     c = Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse)
     c.ragged = bool(ragged)
     c.hilo = bool(hilo)
+    c.input_norm = input_norm      # (mean3, std3): the plan takes RAW resized pixels + a ones channel (Compiler.fold_input_norm)
     if c.hilo:
         c.use_patch = False          # conv_patch_kernel has no two-pass K walk (the implicit-GEMM, stem and column kernels do)
     return c.compile()

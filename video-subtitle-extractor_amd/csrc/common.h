@@ -13,6 +13,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_SWISH = 3, ACT_SIGMOID = 4, ACT_HSIGMOID = 5 };
 enum { OP_CONV = 1, OP_DWCONV, OP_POOL, OP_GAP, OP_SCALE, OP_BINARY, OP_RESIZE, OP_UNARY, OP_LAYERNORM, OP_ATTN,
        OP_SOFTMAX, OP_LSTM, OP_WSCALE };
+enum { F_LSTM_MFMA = 16384 };   // OP_LSTM: W_hh^T in MFMA fragment order, H = 256 (lstm.hip); p[P_REVERSE] = 2: both directions, in1 = reverse gates
 enum { F_RES = 1, F_PIXSHUF = 2, F_OUT_F32 = 4, F_PATCH = 8, F_DOT1 = 16, F_SRC2 = 32, F_UP2HEAD = 64, F_WK32 = 128, F_GATE = 256, F_STEM = 512, F_HILO = 1024, F_COL = 2048, F_PW = 4096, F_IMGW = 8192 };
 // p[] slots (keep in sync with ir.py)
 enum { P_KH = 0, P_KW, P_SH, P_SW, P_PH, P_PW, P_ACT, P_ACT2, P_COUT, P_KTOT, P_INSHIFT, P_RESSHIFT, P_CINP, P_DOTACT, P_IN2SHIFT };
@@ -60,5 +61,7 @@ struct ConvArgs {
 int launch_conv(const ConvArgs& a, hipStream_t st);
 int conv_tile_bn(int Np);   // which conv_mfma_kernel instantiation (BN = 128 / 64 / 32) serves Np output channels
 // wl_in / wl_out: per-sample widths of in0 / of the output in a ragged plan (device, [n]), else nullptr
+int launch_lstm_mfma(const TView& gf, const TView& gr, const TView& out, const half_t* whh, int rev_single, int ndir, const int* tl,
+                     hipStream_t st);
 int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const TView& in2, const TView& out,
                      const TView& out2, const char* wbase, const int* wl_in, const int* wl_out, hipStream_t st);

@@ -1,0 +1,118 @@
+// BiLSTM recurrence of the CRNN recogniser (V2/ch_rec: two bidirectional layers, 256 hidden units; the reference reaches it
+// through paddleocr's TextRecognizer behind backend/tools/ocr.py:27, graph op `rnn` of backend/models/V2/ch_rec).
+//
+// The input projection x.W_ih^T + b of ALL time steps is one MFMA GEMM upstream (OP_CONV, fp32 out).  What is left per time step is
+//     z[b, 4H] = gates_x[b, t] + h[b, H] . W_hh^T[H, 4H]
+// — an MFMA GEMM over the BATCH (the round-2 kernel ran it per sample with scalar FMAs and re-read the 512 KiB W_hh per sample
+// and step).  Design:
+//   * one block per (direction, tile of 32 samples), 8 waves; wave w owns hidden units 32w .. 32w+31 and ALL FOUR gates of them
+//     (four 32 x 32 accumulator tiles), so the cell update i/f/g/o -> c -> h is lane-local: the four gate values of (unit, sample)
+//     sit in the same lane and register index of the four tiles.  c stays in registers for the whole sequence.
+//   * W_hh^T is the MFMA A operand, packed by the compiler in fragment order [wave][gate][k-slice][lane][8]: a wave streams its own
+//     64 KiB per step straight from L2 into VGPRs with contiguous 1 KiB wave loads (no wave shares rows with another, so there is
+//     nothing to stage in LDS); the step time is that stream (~512 KiB per block and step), shared by the 32 samples of the tile.
+//   * h is the B operand, kept in LDS as fp16 hi + lo (h = hi + lo to ~22 bits: two MFMAs per weight fragment, which is free
+//     next to the weight stream) — the recurrence then carries fp32-grade state like the oracle, not fp16 roundings over T steps.
+//   * the accumulators are INITIALISED with gates_x (16-byte fp32 loads), so the projection is never held twice.
+//   * both directions in one launch (blockIdx.y); a sample's length may be its own (ragged batches): the reverse pass starts at
+//     ITS last step, finished samples idle, outputs behind a sample's end are zeros.
+// A sample's column of the product depends on that sample alone -> results do not depend on the batch composition.
+#include "common.h"
+
+#define LSTM_H 256
+#define LSTM_LDH (LSTM_H + 8)      // padded LDS row (halfs)
+
+__global__ __launch_bounds__(512, 2) void lstm_mfma_kernel(TView gates_f, TView gates_r, TView out, const half_t* __restrict__ whh,
+                                                           int rev_single, int ndir, const int* __restrict__ tl) {
+    __shared__ half_t hbuf[2][32][LSTM_LDH];      // [hi / lo][sample][hidden unit]
+    __shared__ int s_tmax;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = lane & 31, kq = lane >> 5;
+    const int dir = blockIdx.y;
+    const int rev = ndir == 2 ? dir : rev_single;
+    const int B = gates_f.n, Tfull = gates_f.w, gld = gates_f.ld;       // (the launcher checks that both directions agree)
+    const int b = blockIdx.x * 32 + n;
+    const int T = b < B ? (tl != nullptr ? min(max(tl[b], 0), Tfull) : Tfull) : 0;
+    if (threadIdx.x == 0) s_tmax = 0;
+    for (int i = threadIdx.x; i < 2 * 32 * LSTM_LDH; i += blockDim.x) (&hbuf[0][0][0])[i] = (half_t)0.f;
+    __syncthreads();
+    if (wave == 0 && kq == 0) atomicMax(&s_tmax, T);
+    __syncthreads();
+    const int tmax = s_tmax;
+    const half8* wfrag = reinterpret_cast<const half8*>(whh) + (size_t)dir * (8 * 4 * 16 * 64) + (size_t)wave * (4 * 16 * 64) + lane;
+    const float* gbase = reinterpret_cast<const float*>((ndir == 2 && dir == 1) ? gates_r.ptr : gates_f.ptr);
+    half_t* obase = reinterpret_cast<half_t*>(out.ptr) + (ndir == 2 ? dir * LSTM_H : 0);
+    const int u0 = 32 * wave + 4 * kq;            // this lane's units: u0 + 8q + e
+    float c[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    for (int step = 0; step < tmax; ++step) {
+        const bool active = step < T;
+        const int t = rev ? T - 1 - step : step;
+        float16v acc[4];
+        {
+            const float* gx = gbase + ((long)b * Tfull + t) * gld + u0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4v v = {0.f, 0.f, 0.f, 0.f};
+                    if (active) v = *reinterpret_cast<const float4v*>(gx + g * LSTM_H + 8 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[g][4 * q + e] = v[e];
+                }
+        }
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const half8 bh = *reinterpret_cast<const half8*>(&hbuf[0][n][s * 16 + kq * 8]);
+            const half8 bl = *reinterpret_cast<const half8*>(&hbuf[1][n][s * 16 + kq * 8]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const half8 a = wfrag[(size_t)(g * 16 + s) * 64];
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[g], 0, 0, 0);
+            }
+        }
+        __syncthreads();                          // every wave has read h(t-1)
+        if (active) {
+            half_t* orow = obase + ((long)b * Tfull + t) * out.ld + u0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                half4 o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    const float i_ = 1.f / (1.f + __expf(-acc[0][i])), f_ = 1.f / (1.f + __expf(-acc[1][i])),
+                                o_ = 1.f / (1.f + __expf(-acc[3][i]));
+                    c[i] = f_ * c[i] + i_ * tanhf(acc[2][i]);
+                    const float h = o_ * tanhf(c[i]);
+                    const half_t hi = (half_t)h;
+                    hbuf[0][n][u0 + 8 * q + e] = hi;
+                    hbuf[1][n][u0 + 8 * q + e] = (half_t)(h - (float)hi);
+                    o4[e] = hi;
+                }
+                *reinterpret_cast<half4*>(orow + 8 * q) = o4;
+            }
+        }
+        __syncthreads();                          // h(t) complete
+    }
+    if (b < B) {
+        // ragged batch: steps behind the sample's own end hold zeros (what the next layer's masked producer would have written)
+        for (int t = T; t < Tfull; ++t) {
+            half_t* orow = obase + ((long)b * Tfull + t) * out.ld + u0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<half4*>(orow + 8 * q) = half4{0, 0, 0, 0};
+        }
+    }
+}
+
+// in0 = forward (or the only) direction's gate pre-activations fp32 [B,1,T,4H], in1 = the reverse direction's when ndir == 2;
+// out = [B,1,T,ndir*H] fp16; whh = fragment-ordered W_hh^T of direction 0 then direction 1.
+int launch_lstm_mfma(const TView& gf, const TView& gr, const TView& out, const half_t* whh, int rev_single, int ndir, const int* tl,
+                     hipStream_t st) {
+    if (gf.esize != 4 || gf.c != 4 * LSTM_H || out.esize != 2 || (out.ld & 3) || (gf.ld & 3) || out.c != ndir * LSTM_H) return VSE_E_INVAL;
+    if (ndir == 2 && (gr.esize != 4 || gr.c != 4 * LSTM_H || gr.n != gf.n || gr.w != gf.w || gr.ld != gf.ld)) return VSE_E_INVAL;
+    if ((reinterpret_cast<uintptr_t>(out.ptr) & 7) || (reinterpret_cast<uintptr_t>(gf.ptr) & 15)) return VSE_E_INVAL;
+    hipLaunchKernelGGL(lstm_mfma_kernel, dim3((gf.n + 31) / 32, ndir), dim3(512), 0, st, gf, gr, out, whh, rev_single, ndir, tl);
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}

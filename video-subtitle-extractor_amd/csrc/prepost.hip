@@ -44,7 +44,7 @@ __device__ __forceinline__ int cv_bilinear_u8(int p00, int p01, int p10, int p11
 __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __restrict__ src, int n, int sh, int sw,
                                                              long pitch, long fstride, half_t* __restrict__ dst, int dh,
                                                              int dw, float m0, float m1, float m2, float sd0, float sd1,
-                                                             float sd2) {
+                                                             float sd2, int raw) {
     const long total = (long)n * dh * dw;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int x = (int)(i % dw);
@@ -62,10 +62,12 @@ __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __re
             int u;
             if (sw == dw && sh == dh) u = r0[cx.s0 * 3 + c];
             else u = cv_bilinear_u8(r0[cx.s0 * 3 + c], r0[x1 * 3 + c], r1[cx.s0 * 3 + c], r1[x1 * 3 + c], cx, cy);
-            // paddleocr NormalizeImage: (img * (1/255) - mean) / std in float32
-            v[c] = ((float)u * (1.f / 255.f) - mean[c]) / sd[c];
+            // paddleocr NormalizeImage: (img * (1/255) - mean) / std in float32; raw: the resized u8 value itself (exact in fp16)
+            v[c] = raw ? (float)u : ((float)u * (1.f / 255.f) - mean[c]) / sd[c];
         }
-        half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], 0, 0, 0, 0, 0};
+        // raw: channel 3 is the constant 1 inside the image — the stem conv's weights for it carry -mean/std per tap, and the
+        // conv's zero padding then stands for a NORMALISED zero exactly as in the reference (compiler input_norm)
+        half8 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)(raw ? 1.f : 0.f), 0, 0, 0, 0};
         *reinterpret_cast<half8*>(dst + i * 8) = o;
     }
 }
@@ -73,13 +75,16 @@ __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __re
 extern "C" int vse_det_preprocess(vse_ctx*, const void* d_bgr, int n, int src_h, int src_w, int64_t pitch,
                                   int64_t frame_stride, void* d_out, int dst_h, int dst_w, const float* mean3,
                                   const float* std3, void* stream) {
-    if (!d_bgr || !d_out || n <= 0 || !mean3 || !std3) return VSE_E_INVAL;
+    if (!d_bgr || !d_out || n <= 0 || (!mean3) != (!std3)) return VSE_E_INVAL;
+    const int raw = mean3 == nullptr;
+    static const float zero3[3] = {0.f, 0.f, 0.f}, one3[3] = {1.f, 1.f, 1.f};
+    if (raw) { mean3 = zero3; std3 = one3; }
     const long total = (long)n * dst_h * dst_w;
     int grid = (int)std::min<long>((total + 255) / 256, 65536);
     hipLaunchKernelGGL(det_preprocess_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const uint8_t*>(d_bgr), n, src_h, src_w, (long)pitch, (long)frame_stride,
                        reinterpret_cast<half_t*>(d_out), dst_h, dst_w, mean3[0], mean3[1], mean3[2], std3[0],
-                       std3[1], std3[2]);
+                       std3[1], std3[2], raw);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }
 

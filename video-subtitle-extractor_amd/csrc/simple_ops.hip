@@ -739,7 +739,12 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
         }
         case OP_LSTM: {
             const int H = p[0];
-            if (H > 256) return VSE_E_UNSUPPORTED;
+            if (op.flags & F_LSTM_MFMA) {
+                if (H != 256) return VSE_E_UNSUPPORTED;
+                return launch_lstm_mfma(in0, in1, out, reinterpret_cast<const half_t*>(wbase + op.w_off), p[1] == 1 ? 1 : 0,
+                                        p[1] == 2 ? 2 : 1, wl_in, st);
+            }
+            if (H > 256 || p[1] > 1) return VSE_E_UNSUPPORTED;
             hipLaunchKernelGGL(lstm_kernel, dim3(in0.n), dim3(256), H * sizeof(float), st, in0, out,
                                reinterpret_cast<const half_t*>(wbase + op.w_off), H, p[1], wl_in);
             break;

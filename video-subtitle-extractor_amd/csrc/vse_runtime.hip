@@ -266,6 +266,39 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     return (o.p[P_INSHIFT] ? 10000 : 0) + conv_tile_bn(o.p[P_COUT]);
 }
 
+// The kernel instantiation op `i` dispatches to, spelled the way rocprofv3 reports it (thread-local storage).
+const char* vse_plan_op_kernel_name(vse_plan* p, int i) {
+    static thread_local char buf[96];
+    buf[0] = 0;
+    if (!p || i < 0 || i >= (int)p->ops.size()) return buf;
+    const vse_op& o = p->ops[i];
+    static const char* simple[] = {"", "", "dwconv_kernel", "pool_kernel", "gap_kernel", "scale_kernel", "binary_kernel", "resize_kernel",
+                                   "unary_kernel", "layernorm_kernel", "attn_kernel", "softmax_kernel", "lstm_kernel", "wscale_kernel"};
+    if (o.kind != OP_CONV) {
+        snprintf(buf, sizeof buf, "%s", (o.kind >= 2 && o.kind <= OP_WSCALE) ? simple[o.kind] : "?");
+        return buf;
+    }
+    const int code = vse_plan_op_variant(p, i);
+    if (code >= 800000) snprintf(buf, sizeof buf, "conv_pw_kernel<%d>", code - 800000);
+    else if (code >= 700000) snprintf(buf, sizeof buf, "conv_c3_kernel<%d, %d>", code - 700000, 8 / (code - 700000));
+    else if (code >= 600000) snprintf(buf, sizeof buf, "conv_col_kernel<%d, %d>", (code - 600000) / 100, code % 100);
+    else if (code >= 500000) snprintf(buf, sizeof buf, "conv_stem_kernel");
+    else if (code >= 400000) snprintf(buf, sizeof buf, "conv_head_up2_kernel");
+    else if (o.flags & F_PATCH) snprintf(buf, sizeof buf, "conv_patch_kernel<%d, %d, %d>", (code / 1000) % 100, code % 1000, code / 100000);
+    else if (code >= 200000) {
+        static const char* cfg[] = {"128, 128, 2, 2, 32, 3", "256, 64, 4, 1, 32, 3", "256, 32, 4, 1, 32, 3", "", "", "", "256, 128, 4, 2, 32, 3",
+                                    "", "", "", "", "", "", "", "", "", "256, 256, 4, 4, 32, 3", "256, 192, 8, 2, 32, 3",
+                                    "256, 256, 4, 4, 64, 2", "256, 192, 8, 2, 64, 2"};
+        const int c = (code - 200000) / 10;
+        snprintf(buf, sizeof buf, "conv_gemm_kernel<%s, %d>", (c >= 0 && c < 20) ? cfg[c] : "?", code % 10);
+    } else {
+        const int bn = code % 1000;
+        snprintf(buf, sizeof buf, "conv_mfma_kernel<%s, %s>", bn == 128 ? "128, 128, 2, 2" : (bn == 64 ? "256, 64, 4, 1" : "256, 32, 4, 1"),
+                 code >= 10000 ? "true" : "false");
+    }
+    return buf;
+}
+
 int vse_plan_profile(vse_plan* p, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream, float* ms) {
     if (!ms) return VSE_E_INVAL;
     int rc0 = check_run(p, ws, ext, n_ext, d_widths, "vse_plan_profile");

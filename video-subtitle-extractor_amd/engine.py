@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libvse_hip.so")
 EXPORTS = [
     "vse_init", "vse_destroy", "vse_last_error", "vse_sizeof_op", "vse_sizeof_view", "vse_abi_version",
     "vse_weights_upload", "vse_weights_free", "vse_plan_create", "vse_plan_destroy", "vse_plan_run", "vse_plan_run_ragged",
-    "vse_plan_width_levels", "vse_plan_profile", "vse_plan_op_variant", "vse_det_preprocess", "vse_db_workspace_bytes",
+    "vse_plan_width_levels", "vse_plan_profile", "vse_plan_op_variant", "vse_plan_op_kernel_name", "vse_det_preprocess", "vse_db_workspace_bytes",
     "vse_db_postprocess", "vse_rec_preprocess", "vse_rec_preprocess_scratch_bytes", "vse_ctc_collapse", "vse_ctc_collapse_ragged",
 ]
 
@@ -84,6 +84,8 @@ def load_library(path=None):
     lib.vse_plan_profile.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p,
                                      C.POINTER(C.c_float)]
     lib.vse_plan_op_variant.argtypes = [C.c_void_p, C.c_int]
+    lib.vse_plan_op_kernel_name.argtypes = [C.c_void_p, C.c_int]
+    lib.vse_plan_op_kernel_name.restype = C.c_char_p
     lib.vse_det_preprocess.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                        C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        C.c_void_p]
@@ -137,15 +139,16 @@ class Context:
             self.handle = C.c_void_p()
 
     # ---- stand-alone stages ---------------------------------------------------------------------------
-    def det_preprocess(self, frames_u8, dst_h, dst_w, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
-        """frames_u8: cuda uint8 [N,H,W,3] (contiguous or row-pitched view) -> fp16 [N,dst_h,dst_w,8]."""
+    def det_preprocess(self, frames_u8, dst_h, dst_w, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), raw=False):
+        """frames_u8: cuda uint8 [N,H,W,3] (contiguous or row-pitched view) -> fp16 [N,dst_h,dst_w,8].
+        raw=True: resized uint8 values + a ones channel for a net built with input_norm (see vse_det_preprocess)."""
         t = self.torch
         assert frames_u8.dtype == t.uint8 and frames_u8.dim() == 4 and frames_u8.shape[3] == 3
         assert frames_u8.stride(3) == 1 and frames_u8.stride(2) == 3
         n, h, w, _ = frames_u8.shape
         out = t.empty((n, dst_h, dst_w, 8), dtype=t.float16, device=self.tdev)
-        m = (C.c_float * 3)(*mean)
-        s = (C.c_float * 3)(*std)
+        m = None if raw else (C.c_float * 3)(*mean)
+        s = None if raw else (C.c_float * 3)(*std)
         _check(self.lib.vse_det_preprocess(self.handle, C.c_void_p(frames_u8.data_ptr()), n, h, w,
                                            frames_u8.stride(1), frames_u8.stride(0), C.c_void_p(out.data_ptr()),
                                            dst_h, dst_w, m, s, self.stream()), "vse_det_preprocess")
@@ -230,12 +233,13 @@ class Context:
 class Net:
     """One model (descriptor + fp32 weights) with plans compiled per static input shape."""
 
-    def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True, hilo=False, ragged=False):
+    def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True, hilo=False, ragged=False, input_norm=None):
         """hilo=True: conv weights as fp16 hi + lo pairs (compiler.compile_model): ~22-bit weights, twice the MFMA work.
         ragged=True (recognisers): every plan takes a per-sample width vector (run(x, widths=...)); a sample's outputs do
         not depend on the batch it rides in (compiler.compile_model(ragged=True))."""
         self.ctx = ctx
         self.ragged = bool(ragged)
+        self.input_norm = input_norm          # (mean3, std3): the net takes det_preprocess(raw=True) input (compiler.compile_model)
         self.desc = desc
         self.weights = weights
         self.fetch_cols = fetch_cols
@@ -252,7 +256,7 @@ class Net:
         key = (n, h, w)
         if key not in self.plans:
             prog = compiler.compile_model(self.desc, self.weights, n, h, w, self.fetch_cols, self.want_probs,
-                                          self.store, hilo=self.hilo, ragged=self.ragged)
+                                          self.store, hilo=self.hilo, ragged=self.ragged, input_norm=self.input_norm)
             self.plans[key] = [prog, None]
         return self.plans[key][0]
 
@@ -338,7 +342,7 @@ class Net:
         return outs
 
     def profile(self, x, slot=0, widths=None):
-        """Per-op milliseconds (HIP events) for one run; returns (ms ndarray, program)."""
+        """Per-op milliseconds (HIP events) for one run; returns (ms ndarray, program, kernel name per op)."""
         n, h, w, _ = x.shape
         self.program(n, h, w)
         prog, handle = self._ensure((n, h, w))
@@ -349,5 +353,5 @@ class Net:
         _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(ws.data_ptr()), ptrs, len(ptrs),
                                              C.c_void_p(wt.data_ptr()) if wt is not None else None, self.ctx.stream(), ms),
                "vse_plan_profile")
-        variants = [self.ctx.lib.vse_plan_op_variant(handle, i) for i in range(len(prog.ops))]
+        variants = [self.ctx.lib.vse_plan_op_kernel_name(handle, i).decode() for i in range(len(prog.ops))]
         return np.array(ms[:], dtype=np.float32), prog, variants

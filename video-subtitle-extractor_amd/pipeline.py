@@ -25,6 +25,9 @@ import numpy as np
 from . import engine
 
 
+DET_NORM = ((0.485, 0.456, 0.406), (0.229, 0.224, 0.225))      # paddleocr NormalizeImage of the DB detectors (mean, std; scale 1/255)
+
+
 def det_resize_shape(h, w, limit_side_len=960):
     """paddleocr DetResizeForTest type0, limit_type='max' (SURVEY App. C.1)."""
     ratio = float(limit_side_len) / max(h, w) if max(h, w) > limit_side_len else 1.0
@@ -64,15 +67,22 @@ def resolve_det_weights(det_weights, weights):
 class OcrPipeline:
     def __init__(self, ctx, det_model, rec_model, charset, rec_batch_num=6, rec_h=48, rec_base_w=320,
                  limit_side_len=960, db_thresh=0.3, db_box_thresh=0.6, db_unclip_ratio=1.5, drop_score=0.0,
-                 rec_mode="ragged", bucket=64, batch_round=1, max_rec_batch=64, det_weights="auto", min_rec_group=0):
+                 rec_mode="ragged", bucket=64, batch_round=1, max_rec_batch=64, det_weights="auto", min_rec_group=0,
+                 det_input="raw"):
         """det_model / rec_model: (descriptor, weights dict).
         det_weights: "fp16" | "fp16x2" | "auto".  fp16x2 stores the detector's conv weights as fp16 hi + lo pairs (two K
         passes into the same fp32 accumulators): the rounding of BN-folded weights to fp16 is what moves box borders against
         an fp32 reference.  "auto" uses it for the mobile detectors (< 4 M parameters), where the second pass
-        hides behind the memory traffic, and plain fp16 for the server models."""
+        hides behind the memory traffic, and plain fp16 for the server models.
+        det_input: "raw" — the detector is fed the resized uint8 pixels themselves (+ a ones channel) and its stem conv carries
+        paddleocr's (x/255 - mean)/std, so it computes on the reference's exact input values; "normalized" — the fp16 rounding
+        of the normalised image (rounds 1-2; moves the real detector's map by up to 4e-3)."""
         self.ctx = ctx
+        assert det_input in ("raw", "normalized")
+        self.det_input = det_input
         self.det_weights = det_weights = resolve_det_weights(det_weights, det_model[1])
-        self.det = engine.Net(ctx, det_model[0], det_model[1], fetch_cols=(0,), hilo=det_weights == "fp16x2")
+        self.det = engine.Net(ctx, det_model[0], det_model[1], fetch_cols=(0,), hilo=det_weights == "fp16x2",
+                              input_norm=DET_NORM if det_input == "raw" else None)
         # ragged plans for every mode: "reference" runs them with uniform widths, so the modes share kernels and summation orders
         self.rec = engine.Net(ctx, rec_model[0], rec_model[1], want_probs=False, ragged=True)
         self.charset = charset
@@ -101,7 +111,7 @@ class OcrPipeline:
         batches may be in flight on different streams when they use different slots."""
         n, h, w, _ = frames.shape
         rh, rw = det_resize_shape(h, w, self.limit)
-        x = self.ctx.det_preprocess(frames, rh, rw)
+        x = self.ctx.det_preprocess(frames, rh, rw, raw=getattr(self, "det_input", "normalized") == "raw")
         out = self._run(self.det, x, slot)[0]     # [N,rh,rw,1] fp32
         return out.view(n, rh, rw)
 
