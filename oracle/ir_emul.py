@@ -361,11 +361,11 @@ class Emulator:
         H = int(r["p"][ir.P_HID])
         mode = int(r["p"][ir.P_REVERSE])
         if int(r["flags"]) & ir.F_LSTM_MFMA:
-            # W_hh^T in MFMA fragment order [dir][wave 8][gate 4][slice 16][k-half 2][row 32][8] -> [H, 4H] per direction
+            # W_hh^T in MFMA fragment order [dir][wave 8][slice 16][gate 4][k-half 2][row 32][8] -> [H, 4H] per direction
             assert H == 256
             ndir = 2 if mode == 2 else 1
-            wt = self.wread(int(r["w_off"]), ndir * 4 * H * H, np.float16).astype(np.float32).reshape(ndir, 8, 4, 16, 2, 32, 8)
-            whhs = [torch.from_numpy(np.ascontiguousarray(wt[d].transpose(1, 0, 4, 2, 3, 5)).reshape(4 * H, H).T.copy()) for d in range(ndir)]
+            wt = self.wread(int(r["w_off"]), ndir * 4 * H * H, np.float16).astype(np.float32).reshape(ndir, 8, 16, 4, 2, 32, 8)
+            whhs = [torch.from_numpy(np.ascontiguousarray(wt[d].transpose(2, 0, 4, 1, 3, 5)).reshape(4 * H, H).T.copy()) for d in range(ndir)]
             dirs = [(r["in0"], whhs[0], mode == 1)] + ([(r["in1"], whhs[1], True)] if ndir == 2 else [])
         else:
             whh = torch.from_numpy(self.wread(int(r["w_off"]), H * 4 * H, np.float16).astype(np.float32).reshape(H, 4 * H))

@@ -191,6 +191,10 @@ PW_MAX_COUT = int(os.environ.get("VSE_PW_MAXCOUT", "64"))
 COL3_MIN_K = int(os.environ.get("VSE_COL3_MINK", "250"))   # 3x3 32->32 @136x240 (K = 288): 0.180 ms on the implicit GEMM, 0.115 ms here
 COL3_WIDE_MIN_CIN = 128    # layers with more than 64 couts (two+ cout tiles refetch the patch) only from 128 input channels on
 COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
+# nominal sample width for the kernel selection of ragged (recogniser) plans: subtitle lines are several hundred pixels wide at
+# 48 px height; every plan of a model selects as if its maps were this wide (the choice only steers efficiency, never results
+# ACROSS plans of one process; a different value is a different set of summation orders)
+RAGGED_SEL_W = int(os.environ.get("VSE_RAGGED_SELW", "768"))
 LSTM_MFMA = os.environ.get("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
 
 
@@ -258,7 +262,7 @@ class Compiler:
         self.ragged = False
         self.wlevels = [None]                 # level 0 = the input width
         self.wlevel_index = {}
-        self.sel_w0 = 320                     # kernel selection of a ragged plan looks at THIS input width, never at the batch's
+        self.sel_w0 = RAGGED_SEL_W            # kernel selection of a ragged plan looks at THIS input width, never at the batch's
         self.input_norm = None                # (mean3, std3): see fold_input_norm
         self._merge_parallel_convs()
         self.N, self.H, self.Wd = batch, height, width
@@ -1570,12 +1574,12 @@ class Compiler:
     @staticmethod
     def lstm_fragments(w_hh):
         """W_hh [4H, H] (gate order i, f, g, o; H = 256) -> fp16 in the order lstm_mfma_kernel streams it: wave w owns hidden
-        units 32w .. 32w+31; per (wave, gate, 16-deep k slice) one MFMA A fragment = [lane 64][8]: row = lane & 31 (unit
+        units 32w .. 32w+31; per (wave, 16-deep k slice, gate) — the order of the stream — one MFMA A fragment = [lane 64][8]: row = lane & 31 (unit
         32w + row of that gate), k = 16 s + 8 (lane >> 5) + j."""
         H = w_hh.shape[1]
         assert w_hh.shape == (4 * H, H) and H == 256
         w5 = w_hh.reshape(4, 8, 32, 16, 2, 8)                     # [gate][wave][row][slice][k-half][j]
-        return np.ascontiguousarray(w5.transpose(1, 0, 3, 4, 2, 5)).astype(np.float16).reshape(-1)       # [wave][gate][slice][k-half][row][j]
+        return np.ascontiguousarray(w5.transpose(1, 3, 0, 4, 2, 5)).astype(np.float16).reshape(-1)       # [wave][slice][gate][k-half][row][j]
 
     def lower_rnn(self, i):
         op = self.ops[i]

@@ -8,7 +8,7 @@
 //   * one block per (direction, tile of 32 samples), 8 waves; wave w owns hidden units 32w .. 32w+31 and ALL FOUR gates of them
 //     (four 32 x 32 accumulator tiles), so the cell update i/f/g/o -> c -> h is lane-local: the four gate values of (unit, sample)
 //     sit in the same lane and register index of the four tiles.  c stays in registers for the whole sequence.
-//   * W_hh^T is the MFMA A operand, packed by the compiler in fragment order [wave][gate][k-slice][lane][8]: a wave streams its own
+//   * W_hh^T is the MFMA A operand, packed by the compiler in fragment order [wave][k-slice][gate][lane][8]: a wave streams its own
 //     64 KiB per step straight from L2 into VGPRs with contiguous 1 KiB wave loads (no wave shares rows with another, so there is
 //     nothing to stage in LDS); the step time is that stream (~512 KiB per block and step), shared by the 32 samples of the tile.
 //   * h is the B operand, kept in LDS as fp16 hi + lo (h = hi + lo to ~22 bits: two MFMAs per weight fragment, which is free
@@ -46,31 +46,50 @@ __global__ __launch_bounds__(512, 2) void lstm_mfma_kernel(TView gates_f, TView 
     float c[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    // The weight stream is the same 64 fragments (k-slice major, gate minor) every step and does not depend on h: a rolling
+    // queue of WQ fragments stays in flight ACROSS the step boundary, so the loads of the next step's first slices overlap
+    // this step's cell arithmetic and barriers (round-3 first version, loads issued 4 slices at a time inside the step: 17 us
+    // per step; the stream itself needs ~3.5 us).
+    constexpr int WQ = 8;                         // two k-slices x four gates
+    half8 wq[WQ];
+#pragma unroll
+    for (int f = 0; f < WQ; ++f) wq[f] = wfrag[(size_t)f * 64];
+    auto fast_tanh = [](float x) { return 2.f / (1.f + __expf(-2.f * x)) - 1.f; };
     for (int step = 0; step < tmax; ++step) {
         const bool active = step < T;
         const int t = rev ? T - 1 - step : step;
-        float16v acc[4];
+        // gate pre-activations of this step (x . W_ih^T + b, fp32): issued now, consumed after the MFMAs
+        float4v gx[4][4];
         {
-            const float* gx = gbase + ((long)b * Tfull + t) * gld + u0;
+            const float* gp = gbase + ((long)b * Tfull + t) * gld + u0;
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float4v v = {0.f, 0.f, 0.f, 0.f};
-                    if (active) v = *reinterpret_cast<const float4v*>(gx + g * LSTM_H + 8 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[g][4 * q + e] = v[e];
+                    gx[g][q] = float4v{0.f, 0.f, 0.f, 0.f};
+                    if (active) gx[g][q] = *reinterpret_cast<const float4v*>(gp + g * LSTM_H + 8 * q);
                 }
         }
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const half8 bh = *reinterpret_cast<const half8*>(&hbuf[0][n][s * 16 + kq * 8]);
-            const half8 bl = *reinterpret_cast<const half8*>(&hbuf[1][n][s * 16 + kq * 8]);
+        float16v acc[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const half8 a = wfrag[(size_t)(g * 16 + s) * 64];
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[g], 0, 0, 0);
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+#pragma unroll 1
+        for (int s2 = 0; s2 < 8; ++s2) {          // (not unrolled: hipcc would hoist the whole step's loads and spill)
+            const half8* wnext = wfrag + (size_t)(((s2 + 1) & 7) * 8) * 64;      // wraps into the next step's stream
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int s = 2 * s2 + u;
+                const half8 bh = *reinterpret_cast<const half8*>(&hbuf[0][n][s * 16 + kq * 8]);
+                const half8 bl = *reinterpret_cast<const half8*>(&hbuf[1][n][s * 16 + kq * 8]);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const half8 a = wq[u * 4 + g];
+                    wq[u * 4 + g] = wnext[(size_t)(u * 4 + g) * 64];
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bh, acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bl, acc[g], 0, 0, 0);
+                }
             }
         }
         __syncthreads();                          // every wave has read h(t-1)
@@ -82,10 +101,11 @@ __global__ __launch_bounds__(512, 2) void lstm_mfma_kernel(TView gates_f, TView 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int i = 4 * q + e;
-                    const float i_ = 1.f / (1.f + __expf(-acc[0][i])), f_ = 1.f / (1.f + __expf(-acc[1][i])),
-                                o_ = 1.f / (1.f + __expf(-acc[3][i]));
-                    c[i] = f_ * c[i] + i_ * tanhf(acc[2][i]);
-                    const float h = o_ * tanhf(c[i]);
+                    const float zi = acc[0][i] + gx[0][q][e], zf = acc[1][i] + gx[1][q][e], zg = acc[2][i] + gx[2][q][e],
+                                zo = acc[3][i] + gx[3][q][e];
+                    const float i_ = 1.f / (1.f + __expf(-zi)), f_ = 1.f / (1.f + __expf(-zf)), o_ = 1.f / (1.f + __expf(-zo));
+                    c[i] = f_ * c[i] + i_ * fast_tanh(zg);
+                    const float h = o_ * fast_tanh(c[i]);
                     const half_t hi = (half_t)h;
                     hbuf[0][n][u0 + 8 * q + e] = hi;
                     hbuf[1][n][u0 + 8 * q + e] = (half_t)(h - (float)hi);

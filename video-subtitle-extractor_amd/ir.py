@@ -96,7 +96,7 @@ P_HEADS, P_HDIM = 0, 1
 P_NCLS = 0
 # OP_LSTM p[]
 P_HID, P_REVERSE = 0, 1          # P_REVERSE: 0 forward, 1 reverse, 2 = BOTH directions in one launch (in0 = forward gates, in1 = reverse gates)
-F_LSTM_MFMA = 16384              # OP_LSTM: W_hh^T packed in MFMA fragment order [dir][wave 8][gate 4][k-slice 16][lane 64][8] (H = 256, csrc/lstm.hip)
+F_LSTM_MFMA = 16384              # OP_LSTM: W_hh^T packed in MFMA fragment order [dir][wave 8][k-slice 16][gate 4][lane 64][8] (H = 256, csrc/lstm.hip)
 
 
 # ragged recogniser batches (every op kind): 1 + width level of in0 / of the output, 0 = the tensor has no per-sample width.
