@@ -56,6 +56,8 @@ def parse():
                     help="rec width buckets with fewer crops absorb the next narrower bucket (0 = off); 8: the 4-crop 1280-px bucket of "
                          "the default workload joins the 1024-px one - 6 %% less GPU time in conv kernels at the same frames/s")
     ap.add_argument("--rec-streams", type=int, default=2)
+    ap.add_argument("--ragged-floor", type=int, default=None, help="ragged grouping: crop-pixels below which a launch sequence stops getting faster")
+    ap.add_argument("--ragged-launch-cost", type=int, default=None, help="ragged grouping: fixed cost of one launch sequence in crop-pixels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="finish batch k before the detector of batch k+1 starts")
@@ -200,6 +202,10 @@ def main():
                                 rec_h=32 if args.models == "v2" else 48, limit_side_len=args.limit_side)
 
     pipe.rec_streams = args.rec_streams
+    if args.ragged_floor is not None:
+        pipe.ragged_floor = args.ragged_floor
+    if args.ragged_launch_cost is not None:
+        pipe.ragged_launch_cost = args.ragged_launch_cost
     frames_np, truth = synth.make_frames(args.batch, args.height, args.width, seed=100 + rank, return_truth=True)
     frames = torch.from_numpy(frames_np).to(ctx.tdev)          # inputs resident in HBM before the timed region
     quads = gt_quads(truth)

@@ -121,5 +121,6 @@ def test_ragged_groups_keep_every_crop_at_its_reference_width():
     groups = p._groups(specs)
     assert sorted(i for idx, _, _ in groups for i in idx) == list(range(len(specs)))
     assert {i: wi for idx, _, ws in groups for i, wi in zip(idx, ws)} == want          # same width as in the reference
-    assert all(max(ws) <= w and w % 256 == 0 for _, w, ws in groups)                    # the tensor covers its widest sample
+    assert all(max(ws) <= w < max(ws) + 64 and w % 64 == 0 for _, w, ws in groups)     # the tensor just covers its widest sample
+    assert all(len(idx) <= 64 for idx, _, _ in groups)
     assert len(groups) <= 8 and len(ref_groups) >= 30                                  # ... in a handful of launches

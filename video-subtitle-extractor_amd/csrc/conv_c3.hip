@@ -77,6 +77,7 @@ __global__ __launch_bounds__(512, 4) void conv_c3_kernel(const ConvParams p) {
     const int ty = t % p.tiles_h;
     const long img = t / p.tiles_h;
     const int oy0 = ty * TH, ox0 = tx * TW, n0 = nt * BN;
+    if (conv_tile_right_of_sample<TH, TW>(p, img, oy0, ox0, n0, BN)) return;      // ragged batch: nothing to compute here
     const int nch1 = p.cinp >> 4;                        // 16-channel chunks of one pass over the input
     // F_HILO: fp16 hi + lo weight pairs — the lo stream follows the hi stream, the patch chunks are walked a second time into
     // the same accumulators (the implicit-GEMM kernels' two-pass K walk)

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(512, 2) void conv_col_kernel(const ConvParams p) {
     const int ty = t % p.tiles_h;
     const long img = t / p.tiles_h;
     const int oy0 = ty * CTH, ox0 = tx * CTW, n0 = nt * BN;
+    if (conv_tile_right_of_sample<CTH, CTW>(p, img, oy0, ox0, n0, BN)) return;    // ragged batch: nothing to compute here
 
     const int kw = p.kw;
     const int nch1 = p.cinp >> 4;

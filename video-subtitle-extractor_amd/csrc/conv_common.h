@@ -252,6 +252,23 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
     }
 }
 
+// Ragged batches: an output tile that lies entirely right of its sample's width holds zeros by definition — the block writes
+// them (one 16-byte store per pixel and 8-channel group) and skips its prologue, K loop and epilogue.  Call before the first
+// DMA / barrier; the decision is block-uniform.  TH x TW = the tile, bn = couts of the block's tile.
+template <int TH, int TW>
+__device__ __forceinline__ bool conv_tile_right_of_sample(const ConvParams& p, long img, int oy0, int ox0, int n0, int bn) {
+    if (p.wl_out == nullptr || p.out_f32 || (p.flags & (F_DOT1 | F_PIXSHUF)) || !p.vec16) return false;
+    if (ox0 < p.wl_out[img]) return false;
+    const int c1 = min(n0 + bn, p.Np);
+    for (int i = threadIdx.x; i < TH * TW; i += blockDim.x) {
+        const int oy = oy0 + i / TW, ox = ox0 + i % TW;
+        if (oy >= p.OH || ox >= p.OW) continue;
+        half_t* op = reinterpret_cast<half_t*>(p.out) + ((img * p.OH + oy) * p.OW + ox) * (long)p.out_ld;
+        for (int c = n0; c < c1; c += 8) *reinterpret_cast<half8*>(op + c) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    return true;
+}
+
 // F_DOT1 variant: returns this lane's partial  sum_c y[c] * dotw[c]  over the couts it owns in one accumulator tile
 // (y = the full epilogue value); nothing is stored.  Padded couts carry zero weights.
 __device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const float16v& acc, const float (&bias)[16],
