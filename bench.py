@@ -56,6 +56,8 @@ def parse():
                     help="rec width buckets with fewer crops absorb the next narrower bucket (0 = off); 8: the 4-crop 1280-px bucket of "
                          "the default workload joins the 1024-px one - 6 %% less GPU time in conv kernels at the same frames/s")
     ap.add_argument("--rec-streams", type=int, default=2)
+    ap.add_argument("--rec-span", type=int, default=2, help="streaming form, ragged mode: the crops of this many consecutive batches are "
+                    "recognised together (results do not depend on the grouping; larger launches fill the chip on the recogniser's small maps)")
     ap.add_argument("--ragged-floor", type=int, default=None, help="ragged grouping: crop-pixels below which a launch sequence stops getting faster")
     ap.add_argument("--ragged-launch-cost", type=int, default=None, help="ragged grouping: fixed cost of one launch sequence in crop-pixels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -256,15 +258,26 @@ def main():
             ev.record(st)
         return maps, ev
 
-    def stage2(handle):
-        maps, ev = handle[:2]
+    def stage2_boxes(handle):
+        maps, ev, k = handle
         main = torch.cuda.current_stream(ctx.tdev)
         main.wait_event(ev)
         maps.record_stream(main)
         db = ctx.db_postprocess(maps, args.height, args.width, **pipe.db)
-        boxes = [pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads
-        res = pipe.recognize(frames, boxes)
-        return records(handle[2], boxes, res)
+        return k, ([pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads)
+
+    def stage2_recognise(ready):
+        """ready: [(step, boxes per frame)] of consecutive batches -> their records (every batch reads the same resident frames)."""
+        if len(ready) == 1:
+            res = [pipe.recognize(frames, ready[0][1])]
+        else:
+            res = pipe.recognize_multi([frames] * len(ready), [b for _, b in ready])
+        out = []
+        for (k, boxes), r in zip(ready, res):
+            out += records(k, boxes, r)
+        return out
+
+    span = max(1, args.rec_span) if args.rec_mode == "ragged" else 1
 
     def run_steps(n):
         """n complete det + rec passes over this rank's batch, then THE collective of the path: one variable-length gather of
@@ -276,13 +289,19 @@ def main():
         else:
             for st in det_streams:
                 st.wait_stream(torch.cuda.current_stream(ctx.tdev))
-            queue = []
+            queue, ready = [], []
             for k in range(n):
                 queue.append(stage1(k) + (k,))
                 if len(queue) > depth:
-                    local += stage2(queue.pop(0))
+                    ready.append(stage2_boxes(queue.pop(0)))
+                    if len(ready) >= (span if pipe.rec_mode == "ragged" else 1):
+                        local += stage2_recognise(ready)
+                        ready = []
             while queue:
-                local += stage2(queue.pop(0))
+                ready.append(stage2_boxes(queue.pop(0)))
+                if len(ready) >= (span if pipe.rec_mode == "ragged" else 1) or not queue:
+                    local += stage2_recognise(ready)
+                    ready = []
         return parallel.gather_records(local, device=coll_dev)
 
     def sync():
@@ -345,13 +364,21 @@ def main():
                        "streaming": "sequential batches" if args.no_overlap else
                                     f"detectors of the next {depth} batch(es) in flight (own HIP streams / workspace slots) while batch k is "
                                     "post-processed and recognised; all K batches start and finish inside the timed region",
+                       "rec_span": f"crops of {span} consecutive batch(es) share the recogniser's launch sequences" if not args.no_overlap else "1 (sequential)",
                        "frames_per_gpu_step": args.batch, "det_model": det_id, "rec_model": rec_id,
                        "weights": "real" if modelzoo.has_real_weights(det_id) else "seeded random (reference blobs missing)",
                        "gather": "one variable-length gather of all ranks' records to rank 0 at the end of the timed region",
                        "records_gathered": len(out) if out is not None else 0},
         }
         if not args.no_roofline:
-            result["roofline"] = roofline(pipe, step_local)     # rank 0 only: must not enter a collective
+            def profile_pass():                                  # the work of `span` steps, sequential, every op timed
+                ready = []
+                for k in range(span if not args.no_overlap else 1):
+                    maps = det_maps()
+                    db = ctx.db_postprocess(maps, args.height, args.width, **pipe.db)
+                    ready.append((k, [pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads))
+                stage2_recognise(ready)
+            result["roofline"] = roofline(pipe, profile_pass, steps_per_call=span if not args.no_overlap else 1)     # rank 0 only: no collective
             log("roofline pass done")
         if not args.no_cpu_baseline and world == 1:
             from oracle import pipeline_ref as P
@@ -364,11 +391,14 @@ def main():
     return result
 
 
-def roofline(pipe, step, repeats=2):
+def roofline(pipe, step, repeats=2, steps_per_call=1):
     """Dominant kernel = the conv_mfma_kernel instantiation with the largest total time over one whole step
     (detector + every recogniser launch).  Every op of every plan is bracketed by HIP events recorded on the stream
     the kernels are launched on (vse_plan_profile); achieved = algorithmic conv FLOPs routed to that kernel / its
-    summed launch durations; avg_launch_us is directly comparable with rocprofv3 --stats' AverageNs for it."""
+    summed launch durations; avg_launch_us is directly comparable with rocprofv3 --stats' AverageNs for it.
+    steps_per_call: `step` covers that many 64-frame steps (the streaming form recognises the crops of `--rec-span` consecutive
+    batches together); every per-step figure is divided accordingly."""
+    nsteps = repeats * steps_per_call
     from vse_amd import ir
     agg = {}
     for _ in range(repeats):
@@ -403,18 +433,20 @@ def roofline(pipe, step, repeats=2):
     for ms, prog, _v in pipe_last_sink:
         key = "det" if prog.outputs and prog.outputs[0]["kind"] == "map" else f"rec[{prog.in_shape[0]}x{prog.in_shape[2]}]"
         per_net[key] = per_net.get(key, 0.0) + float(ms.sum())
-    print("[bench] per-net GPU ms (profiled step):", {k: round(v, 2) for k, v in per_net.items()}, file=sys.stderr)
+    rec_ms = sum(v for k, v in per_net.items() if k != "det") / steps_per_call
+    print(f"[bench] per-net GPU ms (profiled pass over {steps_per_call} step(s)):", {k: round(v, 2) for k, v in per_net.items()},
+          f"-> per step: det {per_net.get('det', 0.0) / steps_per_call:.2f}, rec {rec_ms:.2f}", file=sys.stderr)
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_source": f"{tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
-            "kernel": kname, "launches_per_step": cnt // repeats,
+            "kernel": kname, "launches_per_step": round(cnt / nsteps, 1),
             "avg_launch_us": round(1e3 * tms / cnt, 2),
             "algorithmic_gflop_per_launch": round(2 * gmac / cnt, 2),
             "share_of_conv_time": round(tms / all_ms, 3),
             "all_conv_tflops": round(2.0 * sum(v[1] for v in agg.values()) / all_ms, 2),
-            "conv_ms_per_step": round(all_ms / repeats, 3),
+            "conv_ms_per_step": round(all_ms / nsteps, 3),
             # the other conv kernel instantiations by share of conv time (same definition of `achieved` for each)
-            "kernels": [{"kernel": v, "share": round(t / all_ms, 3), "launches_per_step": c // repeats,
+            "kernels": [{"kernel": v, "share": round(t / all_ms, 3), "launches_per_step": round(c / nsteps, 1),
                          "achieved": round(2.0 * g / t, 1), "frac": round(2.0 * g / t / MFMA_PEAK_TFLOPS, 3)}
                         for v, (t, g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:6]]}
 

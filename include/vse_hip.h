@@ -91,6 +91,20 @@ int vse_plan_run_ragged(vse_plan* plan, void* ws, void* const* ext, int n_ext, c
 /* Number of width levels a ragged plan expects in d_widths (0 for an ordinary plan). */
 int vse_plan_width_levels(vse_plan* plan);
 
+/* ---- model-level calls ------------------------------------------------------------------------------------
+ * One call per network invocation, composed of the entry points of this header over a compiled plan.
+ * vse_det_forward = vse_det_preprocess + vse_plan_run: uint8 BGR frames -> DB probability maps d_prob fp32 [n, dst_h, dst_w]
+ * (what paddleocr TextDetector computes before its post-processing, behind backend/tools/subtitle_detect.py:25).  d_in_f16 is
+ * caller-owned scratch [n, dst_h, dst_w, 8] fp16; raw_input != 0 for a plan compiled with the normalisation in its stem.
+ * vse_rec_forward = vse_plan_run(_ragged) + vse_ctc_collapse(_ragged): recogniser input fp16 [b, h, w, 8] (vse_rec_preprocess)
+ * -> arg-max / max-probability pairs d_idx_maxp [b, t, 2] and the CTC-collapsed class ids, lengths and mean confidences (what
+ * paddleocr TextRecognizer computes behind backend/tools/ocr.py:27).  d_widths / out_level: the ragged plan's width table and
+ * the level of its output sequence (NULL / 0 for an ordinary plan). */
+int vse_det_forward(vse_ctx* ctx, vse_plan* det_plan, void* ws, const void* d_bgr, int n, int src_h, int src_w, int64_t pitch,
+                    int64_t frame_stride, int dst_h, int dst_w, int raw_input, void* d_in_f16, float* d_prob, void* stream);
+int vse_rec_forward(vse_ctx* ctx, vse_plan* rec_plan, void* ws, const void* d_rec_in_f16, const int32_t* d_widths, int out_level,
+                    void* d_idx_maxp, int b, int t, int32_t* d_out_idx, int32_t* d_out_len, float* d_out_conf, void* stream);
+
 /* Per-op timing of one run with HIP events on `stream` (synchronises); ms[n_ops] filled.  d_widths as for
  * vse_plan_run_ragged (NULL for an ordinary plan). */
 int vse_plan_profile(vse_plan* plan, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream, float* ms);

@@ -402,3 +402,26 @@ def test_ragged_recognition_is_bit_identical_to_the_reference_grouping(ctx):
             got = pipe.recognize(dev, quads)
             assert got == want, (rec_id, bucket, rnd, mg, streams)
         pipe.rec_streams = 1
+
+
+def test_crops_of_several_batches_recognised_together(ctx):
+    """recognize_multi / ocr_stream(rec_span=2): the crops of consecutive frame batches share the recogniser's launch
+    sequences (ragged mode) — every (text, score) equals the per-batch run, and the streamed results keep their order."""
+    import torch
+    from vse_amd import pipeline, synth
+    det = net_ref.get_weights("V3_ch_det_fast")
+    rec = net_ref.get_weights("V4_en_rec_fast")
+    pipe = pipeline.OcrPipeline(ctx, det, rec, P.en_charset(), bucket=256, batch_round=4)
+    batches = [torch.from_numpy(synth.make_frames(5, 720, 1280, seed=60 + k, p_two_lines=0.6)).cuda() for k in range(5)]
+    want = [pipe.ocr(b) for b in batches]
+    assert sum(len(r[1]) for w in want for r in w) >= 25
+    for span in (2, 3):
+        got = list(pipe.ocr_stream(iter(batches), depth=2, rec_span=span))
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert len(g) == len(w)
+            for (gb, gr), (wb, wr) in zip(g, w):
+                assert gr == wr and all(np.array_equal(a, b) for a, b in zip(gb, wb))
+    boxes = [[b for b, _ in w] for w in want]
+    multi = pipe.recognize_multi(batches[:3], boxes[:3])
+    assert multi == [[r for _, r in w] for w in want[:3]]

@@ -235,6 +235,39 @@ int vse_plan_run_ragged(vse_plan* p, void* ws, void* const* ext, int n_ext, cons
 
 int vse_plan_width_levels(vse_plan* p) { return p ? p->n_levels : VSE_E_INVAL; }
 
+// ---- model-level calls: one call per network invocation over a compiled plan ---------------------------------
+int vse_det_forward(vse_ctx* c, vse_plan* det_plan, void* ws, const void* d_bgr, int n, int src_h, int src_w, int64_t pitch,
+                    int64_t frame_stride, int dst_h, int dst_w, int raw_input, void* d_in_f16, float* d_prob, void* stream) {
+    if (!c || !det_plan || !d_bgr || !d_in_f16 || !d_prob) return VSE_E_INVAL;
+    if (det_plan->batch != n || det_plan->ops[0].in0.h != dst_h || det_plan->ops[0].in0.w != dst_w) {
+        set_err("vse_det_forward: the plan was compiled for %d x %d x %d, called with %d x %d x %d", det_plan->batch,
+                det_plan->ops[0].in0.h, det_plan->ops[0].in0.w, n, dst_h, dst_w);
+        return VSE_E_INVAL;
+    }
+    static const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};      // paddleocr NormalizeImage (DB detectors)
+    int rc = vse_det_preprocess(c, d_bgr, n, src_h, src_w, pitch, frame_stride, d_in_f16, dst_h, dst_w, raw_input ? nullptr : mean,
+                                raw_input ? nullptr : sd, stream);
+    if (rc != VSE_OK) return rc;
+    void* ext[2] = {d_in_f16, d_prob};
+    return vse_plan_run(det_plan, ws, ext, 2, stream);
+}
+
+int vse_rec_forward(vse_ctx* c, vse_plan* rec_plan, void* ws, const void* d_rec_in_f16, const int32_t* d_widths, int out_level,
+                    void* d_idx_maxp, int b, int t, int32_t* d_out_idx, int32_t* d_out_len, float* d_out_conf, void* stream) {
+    if (!c || !rec_plan || !d_rec_in_f16 || !d_idx_maxp) return VSE_E_INVAL;
+    if (rec_plan->batch != b || rec_plan->max_ext != 1) {
+        set_err("vse_rec_forward: the plan takes %d crops and %d external buffers (compile it with want_probs=False)", rec_plan->batch,
+                rec_plan->max_ext + 1);
+        return VSE_E_INVAL;
+    }
+    if (d_widths && (out_level < 0 || out_level >= rec_plan->n_levels)) return VSE_E_INVAL;
+    void* ext[2] = {const_cast<void*>(d_rec_in_f16), d_idx_maxp};
+    int rc = vse_plan_run_ragged(rec_plan, ws, ext, 2, d_widths, stream);
+    if (rc != VSE_OK) return rc;
+    return vse_ctc_collapse_ragged(c, d_idx_maxp, b, t, d_widths ? d_widths + (size_t)out_level * b : nullptr, d_out_idx, d_out_len,
+                                   d_out_conf, stream);
+}
+
 int vse_plan_op_variant(vse_plan* p, int i) {
     if (!p || i < 0 || i >= (int)p->ops.size()) return VSE_E_INVAL;
     const vse_op& o = p->ops[i];

@@ -18,6 +18,7 @@ EXPORTS = [
     "vse_weights_upload", "vse_weights_free", "vse_plan_create", "vse_plan_destroy", "vse_plan_run", "vse_plan_run_ragged",
     "vse_plan_width_levels", "vse_plan_profile", "vse_plan_op_variant", "vse_plan_op_kernel_name", "vse_det_preprocess", "vse_db_workspace_bytes",
     "vse_db_postprocess", "vse_rec_preprocess", "vse_rec_preprocess_scratch_bytes", "vse_ctc_collapse", "vse_ctc_collapse_ragged",
+    "vse_det_forward", "vse_rec_forward",
 ]
 
 
@@ -81,6 +82,10 @@ def load_library(path=None):
     lib.vse_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
     lib.vse_plan_run_ragged.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p]
     lib.vse_plan_width_levels.argtypes = [C.c_void_p]
+    lib.vse_det_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.vse_rec_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vse_plan_profile.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p,
                                      C.POINTER(C.c_float)]
     lib.vse_plan_op_variant.argtypes = [C.c_void_p, C.c_int]
@@ -189,8 +194,10 @@ class Context:
                 out.append((sel["pts"].copy(), sel["score"].copy()))
         return out
 
-    def rec_preprocess(self, frames_u8, crops, rec_h, rec_w):
-        """crops: list of dict(quad[4][2], frame, crop_w, crop_h, resized_w, rotate) -> fp16 [n,rec_h,rec_w,8]."""
+    def rec_preprocess(self, frames_u8, crops, rec_h, rec_w, out=None):
+        """crops: list of dict(quad[4][2], frame, crop_w, crop_h, resized_w, rotate) -> fp16 [n,rec_h,rec_w,8].
+        out: write into this contiguous fp16 [n,rec_h,rec_w,8] tensor (rows of a larger batch whose other rows are cut from
+        another frame tensor) instead of allocating one."""
         t = self.torch
         n = len(crops)
         # the vse_crop records are filled through a numpy view of the ctypes array (same bytes, no per-field Python loop:
@@ -204,7 +211,9 @@ class Context:
         mh = max(1, int(rec["crop_h"].max())) if n else 1
         nbytes = self.lib.vse_rec_preprocess_scratch_bytes(n, mw, mh)
         crop_ws = t.empty(nbytes, dtype=t.uint8, device=self.tdev)     # per call: groups may run on different streams
-        out = t.empty((n, rec_h, rec_w, 8), dtype=t.float16, device=self.tdev)
+        if out is None:
+            out = t.empty((n, rec_h, rec_w, 8), dtype=t.float16, device=self.tdev)
+        assert out.dtype == t.float16 and out.is_contiguous() and tuple(out.shape) == (n, rec_h, rec_w, 8)
         nf, h, w, _ = frames_u8.shape
         _check(self.lib.vse_rec_preprocess(self.handle, C.c_void_p(frames_u8.data_ptr()), nf, h, w,
                                            frames_u8.stride(1), frames_u8.stride(0), arr, n,
@@ -341,6 +350,45 @@ class Net:
                "vse_plan_run")
         return outs
 
+    def det_forward(self, frames_u8, dst_h, dst_w, slot=0):
+        """Model-level call of a detector net (vse_det_forward): cuda uint8 [N,H,W,3] -> cuda fp32 probability maps [N,dst_h,dst_w]."""
+        t = self.ctx.torch
+        assert frames_u8.dtype == t.uint8 and frames_u8.dim() == 4 and frames_u8.shape[3] == 3
+        assert frames_u8.stride(3) == 1 and frames_u8.stride(2) == 3
+        n, h, w, _ = frames_u8.shape
+        self.program(n, dst_h, dst_w)
+        prog, handle = self._ensure((n, dst_h, dst_w))
+        assert len(prog.outputs) == 1 and prog.outputs[0]["kind"] == "map" and prog.outputs[0]["ld"] == 1, "not a one-map detector plan"
+        x = t.empty((n, dst_h, dst_w, 8), dtype=t.float16, device=self.ctx.tdev)
+        prob = t.empty((n, dst_h, dst_w), dtype=t.float32, device=self.ctx.tdev)
+        ws = self._workspace((n, dst_h, dst_w), prog, slot)
+        _check(self.ctx.lib.vse_det_forward(self.ctx.handle, handle, C.c_void_p(ws.data_ptr()), C.c_void_p(frames_u8.data_ptr()), n, h, w,
+                                            frames_u8.stride(1), frames_u8.stride(0), dst_h, dst_w, 1 if self.input_norm is not None else 0,
+                                            C.c_void_p(x.data_ptr()), C.c_void_p(prob.data_ptr()), self.ctx.stream()), "vse_det_forward")
+        return prob
+
+    def rec_forward(self, x, widths=None, slot=0):
+        """Model-level call of a recogniser net built with want_probs=False (vse_rec_forward): fp16 [B,h,w,8] (+ per-sample widths of
+        a ragged net) -> (class ids int32 [B,T], lengths int32 [B], mean confidences fp32 [B]) cuda tensors."""
+        t = self.ctx.torch
+        assert x.dtype == t.float16 and x.is_contiguous() and x.shape[3] == 8
+        n, h, w, _ = x.shape
+        self.program(n, h, w)
+        prog, handle = self._ensure((n, h, w))
+        assert len(prog.outputs) == 1 and prog.outputs[0]["kind"] == "idx_maxp"
+        tt = prog.outputs[0]["w"]
+        wt = self._width_table(prog, widths, n, w)
+        idx_maxp = t.empty((n, 1, tt, 2), dtype=t.float32, device=self.ctx.tdev)
+        oi = t.zeros((n, tt), dtype=t.int32, device=self.ctx.tdev)
+        ol = t.empty((n,), dtype=t.int32, device=self.ctx.tdev)
+        oc = t.empty((n,), dtype=t.float32, device=self.ctx.tdev)
+        ws = self._workspace((n, h, w), prog, slot)
+        _check(self.ctx.lib.vse_rec_forward(self.ctx.handle, handle, C.c_void_p(ws.data_ptr()), C.c_void_p(x.data_ptr()),
+                                            C.c_void_p(wt.data_ptr()) if wt is not None else None, prog.out_level,
+                                            C.c_void_p(idx_maxp.data_ptr()), n, tt, C.c_void_p(oi.data_ptr()), C.c_void_p(ol.data_ptr()),
+                                            C.c_void_p(oc.data_ptr()), self.ctx.stream()), "vse_rec_forward")
+        return oi, ol, oc
+
     def profile(self, x, slot=0, widths=None):
         """Per-op milliseconds (HIP events) for one run; returns (ms ndarray, program, kernel name per op)."""
         n, h, w, _ = x.shape
@@ -350,6 +398,8 @@ class Net:
         ms = (C.c_float * len(prog.ops))()
         ws = self._workspace((n, h, w), prog, slot)
         wt = self._width_table(prog, widths, n, w)
+        self.last_tlen = wt[prog.out_level] if wt is not None else None
+        self.last_outs = outs                 # the profiled run's outputs (same values as run())
         _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(ws.data_ptr()), ptrs, len(ptrs),
                                              C.c_void_p(wt.data_ptr()) if wt is not None else None, self.ctx.stream(), ms),
                "vse_plan_profile")

@@ -102,7 +102,10 @@ class OcrPipeline:
 
     def _run(self, net, x, slot=0, widths=None):
         if getattr(self, "profile_sink", None) is not None:
+            # the profiled run IS the run (a second, asynchronous run would overlap the next group's profile on another stream
+            # and inflate its per-op times: rec groups read 1.5x too long in round 3's first bench lines)
             self.profile_sink.append(net.profile(x, slot, widths=widths))
+            return net.last_outs
         return net.run(x, slot, widths=widths)
 
     # ---- detection ---------------------------------------------------------------------------------------
@@ -111,6 +114,8 @@ class OcrPipeline:
         batches may be in flight on different streams when they use different slots."""
         n, h, w, _ = frames.shape
         rh, rw = det_resize_shape(h, w, self.limit)
+        if getattr(self, "profile_sink", None) is None:
+            return self.det.det_forward(frames, rh, rw, slot)          # vse_det_forward: pre-process + network in one call
         x = self.ctx.det_preprocess(frames, rh, rw, raw=getattr(self, "det_input", "normalized") == "raw")
         out = self._run(self.det, x, slot)[0]     # [N,rh,rw,1] fp32
         return out.view(n, rh, rw)
@@ -157,7 +162,7 @@ class OcrPipeline:
         base = self.rec_base_w / float(self.rec_h)
         by_frame = {}
         for i, s in enumerate(specs):
-            by_frame.setdefault(s.get("gframe", s["frame"]), []).append(i)
+            by_frame.setdefault(s.get("gframe", (s.get("src", 0), s["frame"])), []).append(i)
         for f in sorted(by_frame):
             idx = by_frame[f]
             order = [idx[j] for j in np.argsort(np.array([specs[i]["ratio"] for i in idx]), kind="stable")]
@@ -243,6 +248,22 @@ class OcrPipeline:
             results[s["frame"]][s["slot"]] = r
         return results
 
+    def recognize_multi(self, frames_list, boxes_list):
+        """recognize() over SEVERAL frame tensors at once: frames_list[k] = cuda uint8 [N_k,H,W,3], boxes_list[k] = its boxes per
+        frame.  In the ragged mode results do not depend on how crops are grouped, so the crops of consecutive frame batches of a
+        video share launch sequences: the small maps of the recogniser (12 / 6 / 3 rows) fill the chip only when a launch carries
+        many crops (MI355X: 64 frames' crops in their own sequences 9.4 ms, together with the next batch's 6 ms per batch).
+        -> list (per tensor) of list (per frame) of [(text, score)]."""
+        specs = []
+        for k, boxes_per_frame in enumerate(boxes_list):
+            for s in self._crop_specs(boxes_per_frame):
+                s["src"] = k
+                specs.append(s)
+        results = [[[("", 0.0)] * len(b) for b in boxes_per_frame] for boxes_per_frame in boxes_list]
+        for s, r in zip(specs, self._recognize_specs(list(frames_list), specs)):
+            results[s["src"]][s["frame"]][s["slot"]] = r
+        return results
+
     def recognize_crops(self, crops):
         """paddleocr TextRecognizer.__call__(img_list): crops = list of uint8 BGR [h,w,3] arrays of any sizes ->
         [(text, score)] in input order.  The whole list is ONE grouping unit (sorted by w/h, chunks of rec_batch_num, each
@@ -268,8 +289,10 @@ class OcrPipeline:
         return self._recognize_specs(t.from_numpy(canvas).to(self.ctx.tdev), specs)
 
     def _recognize_specs(self, frames, specs):
-        """-> [(text, score)] per spec."""
+        """-> [(text, score)] per spec.  frames: one cuda uint8 [N,H,W,3] tensor, or a list of them with spec["src"] naming the
+        tensor a crop is cut from."""
         t = self.ctx.torch
+        frames_list = list(frames) if isinstance(frames, (list, tuple)) else [frames]
         out = [("", 0.0)] * len(specs)
         if not specs:
             return out
@@ -290,21 +313,39 @@ class OcrPipeline:
             for gi, (idx, img_w, widths) in enumerate(groups):
                 if nstreams > 1:
                     t.cuda.set_stream(self._streams[gi % nstreams])
-                crops = []
+                if len(frames_list) > 1:                 # rows of one source tensor next to each other: one crop launch per tensor
+                    order = sorted(range(len(idx)), key=lambda k: specs[idx[k]].get("src", 0))
+                    idx, widths = [idx[k] for k in order], [widths[k] for k in order]
+                crops, srcs = [], []
                 for i, wi in zip(idx, widths):
                     s = specs[i]
                     rw = min(wi, int(math.ceil(self.rec_h * s["ratio"])))
                     crops.append(dict(quad=s["quad"], frame=s["frame"], crop_w=s["crop_w"], crop_h=s["crop_h"],
                                       resized_w=max(rw, 1), rotate=s["rotate"]))
+                    srcs.append(s.get("src", 0))
                 widths = list(widths)
                 if self.rec_mode != "reference" and self.batch_round > 1:
                     while len(crops) % self.batch_round:
                         crops.append(crops[-1])           # dummy rows; their results are never read
                         widths.append(widths[-1])
-                x = self.ctx.rec_preprocess(frames, crops, self.rec_h, img_w)
+                        srcs.append(srcs[-1])
+                if len(frames_list) == 1:
+                    x = self.ctx.rec_preprocess(frames_list[0], crops, self.rec_h, img_w)
+                else:
+                    x = t.empty((len(crops), self.rec_h, img_w, 8), dtype=t.float16, device=self.ctx.tdev)
+                    a = 0
+                    while a < len(crops):
+                        b = a
+                        while b < len(crops) and srcs[b] == srcs[a]:
+                            b += 1
+                        self.ctx.rec_preprocess(frames_list[srcs[a]], crops[a:b], self.rec_h, img_w, out=x[a:b])
+                        a = b
                 slot = gi % nstreams if nstreams > 1 else 0
-                idx_maxp = self._run(self.rec, x, slot=slot, widths=np.asarray(widths, np.int32))[-1]          # [B,1,T,2]
-                oi, ol, oc = self.ctx.ctc_collapse(idx_maxp, self.rec.last_tlen)
+                if getattr(self, "profile_sink", None) is None:
+                    oi, ol, oc = self.rec.rec_forward(x, np.asarray(widths, np.int32), slot)      # vse_rec_forward: network + CTC collapse
+                else:
+                    idx_maxp = self._run(self.rec, x, slot=slot, widths=np.asarray(widths, np.int32))[-1]          # [B,1,T,2]
+                    oi, ol, oc = self.ctx.ctc_collapse(idx_maxp, self.rec.last_tlen)
                 pending.append((idx, oi, ol, oc))
         finally:
             if nstreams > 1:
@@ -324,18 +365,32 @@ class OcrPipeline:
         det = self.detect(frames)
         return self._finish(frames, det)
 
-    def ocr_stream(self, batches, depth=2):
+    def ocr_stream(self, batches, depth=2, rec_span=1):
         """Generator over an iterable of frame batches (cuda uint8 [N,H,W,3]): yields ocr(batch) for each, in order, with
         the detectors of the next `depth` batches in flight (own HIP streams, own workspace slots) while batch k is
         post-processed and recognised — the steady state of a whole-video extraction.  Two detector batches in flight fill each
         other's launch tails (MI355X, 64 x 1080p: +3.6 % over one, three: +1.6 %).  Results are identical to calling ocr() per
-        batch."""
+        batch.  rec_span > 1 (ragged mode): the crops of that many consecutive batches are recognised together
+        (recognize_multi) — same results, larger launches."""
         t = self.ctx.torch
         depth = max(1, int(depth))
+        rec_span = max(1, int(rec_span)) if self.rec_mode == "ragged" else 1
         if len(getattr(self, "_det_streams", [])) < depth:
             self._det_streams = [t.cuda.Stream(device=self.ctx.tdev) for _ in range(depth)]
         main = t.cuda.current_stream(self.ctx.tdev)
-        queue = []
+        queue, ready = [], []
+
+        def boxes_of(frames, maps, ev):
+            main.wait_event(ev)
+            maps.record_stream(main)
+            n, h, w, _ = frames.shape
+            return frames, [sorted_boxes(r[0]) for r in self.ctx.db_postprocess(maps, h, w, **self.db)]
+
+        def flush():
+            rec = self.recognize_multi([f for f, _ in ready], [b for _, b in ready])
+            outs = [self._filter(b, r) for (_, b), r in zip(ready, rec)]
+            ready.clear()
+            return outs
         for k, frames in enumerate(batches):
             # the iterator may have produced this batch asynchronously on the main stream (GPU decode, crop, non-blocking
             # upload): order the detector stream after it for EVERY batch
@@ -348,9 +403,13 @@ class OcrPipeline:
             frames.record_stream(st)
             queue.append((frames, maps, ev))
             if len(queue) > depth:
-                yield self._finish_maps(*queue.pop(0))
+                ready.append(boxes_of(*queue.pop(0)))
+                if len(ready) >= rec_span:
+                    yield from flush()
         while queue:
-            yield self._finish_maps(*queue.pop(0))
+            ready.append(boxes_of(*queue.pop(0)))
+            if len(ready) >= rec_span or not queue:
+                yield from flush()
 
     def detect_stream(self, batches, depth=2):
         """ocr_stream()'s detector half: yields detect(batch) for each batch, in order, with the detectors of the next `depth`
@@ -396,7 +455,10 @@ class OcrPipeline:
 
     def _finish(self, frames, det):
         ordered = [sorted_boxes(b) for b in det]
-        rec = self.recognize(frames, ordered)
+        return self._filter(ordered, self.recognize(frames, ordered))
+
+    def _filter(self, ordered, rec):
+        """TextSystem's drop_score filter over ordered boxes + their recognition results -> per frame (boxes, results)."""
         out = []
         for boxes, res in zip(ordered, rec):
             fb, fr = [], []
