@@ -235,13 +235,6 @@ def main():
         base = (k * world + rank) * args.batch
         return [(base + f, np.asarray(boxes[f], np.float32).reshape(-1, 4, 2), res[f]) for f in range(args.batch)]
 
-    def step_local(k=0):
-        maps = det_maps()
-        db = ctx.db_postprocess(maps, args.height, args.width, **pipe.db)
-        boxes = [pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads
-        res = pipe.recognize(frames, boxes)
-        return records(k, boxes, res)
-
     # Streaming form of the same work: the detector of batch k+1 (its own HIP stream and workspace slot) runs while batch k
     # goes through DB post-processing, the host-side box logic, the recogniser launches and the record gather — what a
     # whole-video extraction does with consecutive frame batches.  Every batch started inside the timed region is also
@@ -283,9 +276,13 @@ def main():
         """n complete det + rec passes over this rank's batch, then THE collective of the path: one variable-length gather of
         every rank's (frame, boxes, texts) records to rank 0 (north_star: "RCCL ... only for the final box/text gather")."""
         local = []
-        if args.no_overlap:
-            for k in range(n):
-                local += step_local(k)
+        if args.no_overlap:                   # one kernel at a time: same launches as the streamed form, nothing concurrent
+            for k0 in range(0, n, span):
+                ready = []
+                for k in range(k0, min(n, k0 + span)):
+                    db = ctx.db_postprocess(det_maps(), args.height, args.width, **pipe.db)
+                    ready.append((k, [pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads))
+                local += stage2_recognise(ready)
         else:
             for st in det_streams:
                 st.wait_stream(torch.cuda.current_stream(ctx.tdev))
@@ -364,7 +361,7 @@ def main():
                        "streaming": "sequential batches" if args.no_overlap else
                                     f"detectors of the next {depth} batch(es) in flight (own HIP streams / workspace slots) while batch k is "
                                     "post-processed and recognised; all K batches start and finish inside the timed region",
-                       "rec_span": f"crops of {span} consecutive batch(es) share the recogniser's launch sequences" if not args.no_overlap else "1 (sequential)",
+                       "rec_span": f"crops of {span} consecutive batch(es) share the recogniser's launch sequences",
                        "frames_per_gpu_step": args.batch, "det_model": det_id, "rec_model": rec_id,
                        "weights": "real" if modelzoo.has_real_weights(det_id) else "seeded random (reference blobs missing)",
                        "gather": "one variable-length gather of all ranks' records to rank 0 at the end of the timed region",
@@ -373,12 +370,12 @@ def main():
         if not args.no_roofline:
             def profile_pass():                                  # the work of `span` steps, sequential, every op timed
                 ready = []
-                for k in range(span if not args.no_overlap else 1):
+                for k in range(span):
                     maps = det_maps()
                     db = ctx.db_postprocess(maps, args.height, args.width, **pipe.db)
                     ready.append((k, [pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads))
                 stage2_recognise(ready)
-            result["roofline"] = roofline(pipe, profile_pass, steps_per_call=span if not args.no_overlap else 1)     # rank 0 only: no collective
+            result["roofline"] = roofline(pipe, profile_pass, steps_per_call=span)     # rank 0 only: no collective
             log("roofline pass done")
         if not args.no_cpu_baseline and world == 1:
             from oracle import pipeline_ref as P

@@ -8,4 +8,5 @@ python tools/fuzz_graph.py --gpu --hilo --cases 100 --seed $((S + 1)) | tail -3 
 python tools/fuzz_prepost.py --cases 400 --seed $S | tail -3 || rc=1
 python tools/fuzz_db.py --cases 400 --seed $S | tail -3 || rc=1
 python tools/fuzz_shapes.py --gpu --cases 60 --seed $S | tail -3 || rc=1
+python tools/fuzz_ragged.py --cases 60 --seed $S | tail -3 || rc=1
 exit $rc

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the ragged recogniser plans on the GPU: random model family, batch size, per-sample widths
+(any integer, as the reference's chunk widths are) and tensor width; every sample is compared
+  (a) bit for bit (arg-max index + max-probability bits of every time step) with the same sample run ALONE in a tensor of exactly
+      its width — what the reference's own chunk gives it when it is the widest crop of its chunk —, and
+  (b) for every `--oracle-every`-th case, with the CPU oracle run on a batch of exactly its width (softmax within the tolerance of
+      the net tests, arg-max equal where the oracle's margin is clear).
+usage: python tools/fuzz_ragged.py [--cases 60] [--seed 0] [--oracle-every 4] [--models V4_ch_rec,...]"""
+import argparse
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from oracle import ir_emul, net_ref
+from vse_amd import engine
+
+DEFAULT = "V4_ch_rec,V4_en_rec_fast,V4_ch_rec_fast,V3_ch_rec_fast,V3_korean_rec_fast,V2_ch_rec"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--oracle-every", type=int, default=4)
+    ap.add_argument("--models", default=DEFAULT)
+    a = ap.parse_args()
+    rng = np.random.default_rng(a.seed)
+    models = a.models.split(",")
+    ctx = engine.Context(0)
+    nets, alone_cache = {}, {}
+    bad = []
+    for case in range(a.cases):
+        mid = models[case % len(models)]
+        desc, w = net_ref.get_weights(mid)
+        h = 32 if mid.startswith("V2") else 48
+        n = int(rng.integers(1, 13))
+        lo = int(rng.choice([40, 320, 320, 320, 500]))
+        widths = [int(v) for v in rng.integers(lo, lo + int(rng.choice([8, 200, 900])), n)]
+        wt = max(widths) + int(rng.choice([0, 0, 7, 64, 300]))
+        x = np.zeros((n, 3, h, wt), np.float32)
+        for i, wi in enumerate(widths):
+            x[i, :, :, :wi] = rng.uniform(-1, 1, (3, h, wi))
+        x = x.astype(np.float16).astype(np.float32)
+        if mid not in nets:
+            nets[mid] = engine.Net(ctx, desc, w, want_probs=True, ragged=True)
+        net = nets[mid]
+
+        def run(xs, ws):
+            xt = torch.from_numpy(ir_emul.to_nhwc8(xs).astype(np.float16)).cuda()
+            outs = [o.cpu().numpy() for o in net.run(xt, widths=np.asarray(ws, np.int32))]
+            return outs, net.last_tlen.cpu().numpy()
+        outs, tl = run(x, widths)
+        for i, wi in enumerate(widths):
+            o1, t1 = run(x[i:i + 1, :, :, :wi], [wi])
+            ti = int(tl[i])
+            if int(t1[0]) != ti or not np.array_equal(outs[-1][i, 0, :ti].view(np.int32), o1[-1][0, 0, :ti].view(np.int32)):
+                bad.append((case, mid, "bits", n, wi, wt))
+                break
+        if a.oracle_every and case % a.oracle_every == 0:
+            i = int(rng.integers(n))
+            ref = net_ref.run_graph(desc, w, x[i:i + 1, :, :, :widths[i]])[0].numpy()[0]
+            ti = int(tl[i])
+            err = np.abs(outs[0][i, 0, :ti] - ref)
+            okp = np.all((err < 1e-3) | (err < 1e-1 * ref)) and (mid.startswith("V3_") or err.max() < 1e-3) and ref.shape[0] == ti
+            srt = np.sort(ref, -1)
+            clear = (srt[..., -1] - srt[..., -2]) > 0.05 * srt[..., -1]
+            oki = np.array_equal(outs[-1].view(np.int32)[i, 0, :ti, 0][clear], ref.argmax(-1)[clear])
+            if not (okp and oki):
+                bad.append((case, mid, "oracle", n, widths[i], wt, float(err.max())))
+    print(f"fuzz_ragged: {a.cases} cases, seed {a.seed}: {len(bad)} failures", bad[:10])
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
