@@ -364,8 +364,9 @@ class PaddleOCR:
 
     def stream(self, batches):
         """iterable of frame batches -> generator of batch() results, the detectors of the next batches already in flight
-        (OcrPipeline.ocr_stream)."""
-        return self.pipe.ocr_stream(batches)
+        (OcrPipeline.ocr_stream) and — in the ragged mode, where grouping never changes a result — the crops of two consecutive
+        batches sharing the recogniser's launch sequences."""
+        return self.pipe.ocr_stream(batches, rec_span=2)
 
 
 class OcrRecogniser:
