@@ -364,9 +364,17 @@ class Emulator:
             # W_hh^T in MFMA fragment order [dir][wave 8][slice 16][gate 4][k-half 2][row 32][8] -> [H, 4H] per direction
             assert H == 256
             ndir = 2 if mode == 2 else 1
-            wt = self.wread(int(r["w_off"]), ndir * 4 * H * H, np.float16).astype(np.float32).reshape(ndir, 8, 16, 4, 2, 32, 8)
-            whhs = [torch.from_numpy(np.ascontiguousarray(wt[d].transpose(2, 0, 4, 1, 3, 5)).reshape(4 * H, H).T.copy()) for d in range(ndir)]
+            wt = self.wread(int(r["w_off"]), ndir * 4 * H * H, np.float16).astype(np.float32)
+            if int(r["p"][2]) == 16:    # [dir][wave 16][slice 16][tile 2][k-half 2][gate-in-tile 2][unit 16][8]; gate = 2 * tile + gate-in-tile
+                wt = wt.reshape(ndir, 16, 16, 2, 2, 2, 16, 8)
+                whhs = [torch.from_numpy(np.ascontiguousarray(wt[d].transpose(2, 4, 0, 5, 1, 3, 6)).reshape(4 * H, H).T.copy()) for d in range(ndir)]
+            else:
+                wt = wt.reshape(ndir, 8, 16, 4, 2, 32, 8)
+                whhs = [torch.from_numpy(np.ascontiguousarray(wt[d].transpose(2, 0, 4, 1, 3, 5)).reshape(4 * H, H).T.copy()) for d in range(ndir)]
             dirs = [(r["in0"], whhs[0], mode == 1)] + ([(r["in1"], whhs[1], True)] if ndir == 2 else [])
+            waves = int(r["p"][2]) or 8
+            gorder = np.arange(4 * H).reshape(4, waves, H // waves).transpose(1, 0, 2).reshape(-1)      # stored channel -> (gate, unit)
+            unperm = np.argsort(gorder)
         else:
             whh = torch.from_numpy(self.wread(int(r["w_off"]), H * 4 * H, np.float16).astype(np.float32).reshape(H, 4 * H))
             dirs = [(r["in0"], whh, bool(mode))]
@@ -385,7 +393,10 @@ class Emulator:
                     h = h.half().float()            # (the MFMA kernel carries h as fp16 hi + lo: fp32-grade state)
                 out[:, 0, t] = h
             return out
-        outs = [self.per_sample(self.read(v), lambda g, w=w, rv=rv: lstm(g, w, rv)) for v, w, rv in dirs]
+        def gates_of(v):
+            g = self.read(v)
+            return g[..., torch.from_numpy(unperm)] if int(r["flags"]) & ir.F_LSTM_MFMA else g        # back to [gate][unit]
+        outs = [self.per_sample(gates_of(v), lambda g, w=w, rv=rv: lstm(g, w, rv)) for v, w, rv in dirs]
         self.write(r["out"], torch.cat(outs, dim=3))
 
     def _op13(self, r):  # WSCALE: per-image 1x1 weights = tiled weight blob x SE gate over k, rounded to fp16 once

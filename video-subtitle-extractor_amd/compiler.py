@@ -196,6 +196,7 @@ COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
 # ACROSS plans of one process; a different value is a different set of summation orders)
 RAGGED_SEL_W = int(os.environ.get("VSE_RAGGED_SELW", "768"))
 LSTM_MFMA = os.environ.get("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
+LSTM_WAVES = int(os.environ.get("VSE_LSTM_WAVES", "16"))    # 8: lstm_mfma_kernel, 16: lstm_mfma16_kernel (twice the loads in flight)
 
 
 def c3_tile_eff(oh, ow):
@@ -1572,6 +1573,22 @@ class Compiler:
         self._fetched = name
 
     @staticmethod
+    def lstm_gate_order(H, waves):
+        """Channel order of the gate pre-activations handed to the MFMA LSTM kernels: new[w * 4U + g * U + u] = old[g * H + w * U + u],
+        U = H / waves hidden units per wave."""
+        U = H // waves
+        return np.arange(4 * H).reshape(4, waves, U).transpose(1, 0, 2).reshape(-1)
+
+    @staticmethod
+    def lstm_fragments16(w_hh):
+        """The 16-wave form of lstm_fragments (lstm_mfma16_kernel): wave w owns units 16w .. 16w+15; tile 0 = [gate i | gate f],
+        tile 1 = [gate g | gate o] (rows 0-15 | 16-31); stream order [wave 16][k-slice 16][tile 2][k-half 2][row 32][8]."""
+        H = w_hh.shape[1]
+        assert w_hh.shape == (4 * H, H) and H == 256
+        w6 = w_hh.reshape(2, 2, 16, 16, 16, 2, 8)                 # [tile][gate-in-tile][wave][unit][slice][k-half][j]
+        return np.ascontiguousarray(w6.transpose(2, 4, 0, 5, 1, 3, 6)).astype(np.float16).reshape(-1)    # [wave][slice][tile][k-half][(gate, unit) = row][j]
+
+    @staticmethod
     def lstm_fragments(w_hh):
         """W_hh [4H, H] (gate order i, f, g, o; H = 256) -> fp16 in the order lstm_mfma_kernel streams it: wave w owns hidden
         units 32w .. 32w+31; per (wave, 16-deep k slice, gate) — the order of the stream — one MFMA A fragment = [lane 64][8]: row = lane & 31 (unit
@@ -1605,13 +1622,19 @@ class Compiler:
                 w_hh = self.W[wl[2 * c + 1]].astype(np.float32)   # [4H,H]
                 b = (self.W[wl[2 * ncell + 2 * c]].astype(np.float64) +
                      self.W[wl[2 * ncell + 2 * c + 1]].astype(np.float64))
+                if mfma:
+                    # the gate pre-activations leave the projection GEMM in the order the recurrent kernel reads them: the four
+                    # gates of a wave's hidden units side by side ([wave][gate][unit in wave]: two whole cache lines per (wave,
+                    # sample) instead of four half lines a kilobyte apart) — a permutation of the GEMM's output channels
+                    gperm = self.lstm_gate_order(H, LSTM_WAVES)
+                    w_ih, b = w_ih[gperm], b[gperm]
                 # input projection for all T as one GEMM (fp32 output to keep gate pre-activations exact-ish)
                 mat, coutp, Kp = self.pack_conv_weights(w_ih.reshape(4 * H, -1, 1, 1), np.ones(4 * H), cur)
                 gb = self.new_buf(cur.n, 1, cur.w, 4 * H, esize=4)
                 gates = View(gb, 0, cur.n, 1, cur.w, [(0, 4 * H)], 4 * H)
                 key = f"{name}:l{layer}d{d}"
-                w_off = self.add_weights(("lstm_ih", wl[2 * c]), self.tile_weights(mat))
-                b_off = self.add_weights(("lstm_b", wl[2 * c]), b.astype(np.float32))
+                w_off = self.add_weights(("lstm_ih", wl[2 * c], LSTM_WAVES if mfma else 0), self.tile_weights(mat))
+                b_off = self.add_weights(("lstm_b", wl[2 * c], LSTM_WAVES if mfma else 0), b.astype(np.float32))
                 self.emit(ir.OP_CONV, key + ":proj", [cur], gates, flags=ir.F_OUT_F32,
                           p={ir.P_KH: 1, ir.P_KW: 1, ir.P_SH: 1, ir.P_SW: 1, ir.P_PH: 0, ir.P_PW: 0,
                              ir.P_ACT: 0, ir.P_ACT2: 0, ir.P_COUT: coutp, ir.P_KTOT: Kp, ir.P_INSHIFT: 0,
@@ -1628,11 +1651,12 @@ class Compiler:
                 self.add_gmacs(cur.n * cur.w * H * 4 * H / 1e9)
             if mfma:
                 # the recurrence of every direction of the layer in ONE launch (csrc/lstm.hip): batch-shared MFMA GEMM per step
-                whh_off = self.add_weights(("lstm_hh_mfma",) + tuple(nm for nm, _ in frag),
-                                           lambda: np.concatenate([self.lstm_fragments(w) for _, w in frag]))
+                whh_off = self.add_weights(("lstm_hh_mfma", LSTM_WAVES) + tuple(nm for nm, _ in frag),
+                                           lambda: np.concatenate([(self.lstm_fragments16 if LSTM_WAVES == 16 else self.lstm_fragments)(w)
+                                                                   for _, w in frag]))
                 ov = View(outb, 0, cur.n, 1, cur.w, [(0, ndir * H)], ndir * H)
                 self.emit(ir.OP_LSTM, f"{name}:l{layer}", gate_views, ov, flags=ir.F_LSTM_MFMA,
-                          p={ir.P_HID: H, ir.P_REVERSE: 2 if ndir == 2 else 0}, w_off=whh_off)
+                          p={ir.P_HID: H, ir.P_REVERSE: 2 if ndir == 2 else 0, 2: LSTM_WAVES}, w_off=whh_off)
                 self.add_gmacs(ndir * cur.n * cur.w * H * 4 * H / 1e9)
             cur = View(outb, 0, cur.n, 1, cur.w, [(0, ndir * H)], ndir * H, 0, "tbc")
         self.env[name] = cur

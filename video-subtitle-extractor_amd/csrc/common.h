@@ -61,7 +61,7 @@ struct ConvArgs {
 int launch_conv(const ConvArgs& a, hipStream_t st);
 int conv_tile_bn(int Np);   // which conv_mfma_kernel instantiation (BN = 128 / 64 / 32) serves Np output channels
 // wl_in / wl_out: per-sample widths of in0 / of the output in a ragged plan (device, [n]), else nullptr
-int launch_lstm_mfma(const TView& gf, const TView& gr, const TView& out, const half_t* whh, int rev_single, int ndir, const int* tl,
-                     hipStream_t st);
+int launch_lstm_mfma(const TView& gf, const TView& gr, const TView& out, const half_t* whh, int rev_single, int ndir, int waves,
+                     const int* tl, hipStream_t st);
 int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const TView& in2, const TView& out,
                      const TView& out2, const char* wbase, const int* wl_in, const int* wl_out, hipStream_t st);

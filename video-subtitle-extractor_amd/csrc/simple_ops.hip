@@ -742,7 +742,7 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             if (op.flags & F_LSTM_MFMA) {
                 if (H != 256) return VSE_E_UNSUPPORTED;
                 return launch_lstm_mfma(in0, in1, out, reinterpret_cast<const half_t*>(wbase + op.w_off), p[1] == 1 ? 1 : 0,
-                                        p[1] == 2 ? 2 : 1, wl_in, st);
+                                        p[1] == 2 ? 2 : 1, p[2] ? p[2] : 8, wl_in, st);
             }
             if (H > 256 || p[1] > 1) return VSE_E_UNSUPPORTED;
             hipLaunchKernelGGL(lstm_kernel, dim3(in0.n), dim3(256), H * sizeof(float), st, in0, out,

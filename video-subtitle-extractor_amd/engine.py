@@ -11,7 +11,7 @@ import numpy as np
 from . import compiler, ir
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvse_hip.so")
+LIB_PATH = os.environ.get("VSE_LIB_PATH") or os.path.join(_HERE, "libvse_hip.so")      # (VSE_LIB_PATH: ablation builds of tools/)
 
 EXPORTS = [
     "vse_init", "vse_destroy", "vse_last_error", "vse_sizeof_op", "vse_sizeof_view", "vse_abi_version",
