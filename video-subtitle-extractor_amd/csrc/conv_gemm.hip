@@ -20,6 +20,10 @@
 #include <type_traits>
 #include "conv_common.h"
 
+#ifndef VSE_GEMM_NT_A
+#define VSE_GEMM_NT_A 0   // 1: non-temporal hint (aux = 2) on the ACTIVATION stream of the implicit GEMM (read once per launch by one block,
+                          // while the weight tiles are re-read by every block and should keep the L2); A/B: tools/ab.sh conv_gemm VSE_GEMM_NT_A
+#endif
 #ifndef VSE_GEMM_ASM
 #define VSE_GEMM_ASM 0    // 1: LDS-DMAs as asm statements (counted lgkmcnt waits survive; measured 1-3 % SLOWER here: the kernel is bound by the DMA stream, the asm form adds issue slots); 0: builtins.  A/B on one box: tools/ab.sh
 #endif
@@ -162,7 +166,7 @@ void conv_gemm_kernel(const ConvParams p) {
 #if VSE_GEMM_ASM
             bufdma16_asm(rsA, off, soffA, base + (j * NW + wave) * RPI * BKT);
 #else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsv_t)(base + (j * NW + wave) * RPI * BKT), 16, (int)off, soffA, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (ldsv_t)(base + (j * NW + wave) * RPI * BKT), 16, (int)off, soffA, 0, VSE_GEMM_NT_A ? 2 : 0);
 #endif
         }
         const int soffW = wk32 ? (int)((unsigned)kt * (BKT / 32) * wstep)
