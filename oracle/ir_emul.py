@@ -190,8 +190,12 @@ class Emulator:
             self.write(r["out2"], z if oc2 == 1 else F.pad(z, (0, oc2 - 1)))
             return
         if int(r["flags"]) & ir.F_PW:
-            assert (kh, kw) == (1, 1) and Kp == cinp
+            assert (kh, kw) == (1, 1) and Kp == (cinp + 15) // 16 * 16
             wmat = self.wread(int(r["w_off"]), Np * Kp, np.float16).astype(np.float32).reshape(Np, Kp)
+            if int(r["flags"]) & ir.F_HILO:           # w = hi + lo (the lo table follows the hi table)
+                wmat = wmat + self.wread(int(r["w_off"]) + 2 * Np * Kp, Np * Kp, np.float16).astype(np.float32).reshape(Np, Kp)
+            assert not wmat[:, cinp:].any()
+            wmat = wmat[:, :cinp]
         elif int(r["flags"]) & ir.F_COL:
             assert cinp % 16 == 0 and Kp == kh * kw * cinp
             npass = 2 if int(r["flags"]) & ir.F_HILO else 1          # w = hi + lo (the lo stream follows the hi stream)

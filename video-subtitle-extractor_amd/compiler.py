@@ -816,6 +816,14 @@ class Compiler:
         return mat, coutp, Kp
 
     @staticmethod
+    def pw_weights(mat, hilo=False):
+        """conv_pw_kernel: plain [Np][cinp] fp16; hilo: the table of lo = fp16(w - hi) follows the table of hi = fp16(w)."""
+        hi = np.asarray(mat, np.float64).astype(np.float16)
+        if not hilo:
+            return hi.reshape(-1)
+        return np.concatenate([hi.reshape(-1), (np.asarray(mat, np.float64) - hi.astype(np.float64)).astype(np.float16).reshape(-1)])
+
+    @staticmethod
     def tile_weights(mat, kt=ir.KT, hilo=False):
         """[Np][Kp] -> [Kp/kt][Np][kt] fp16; hilo: the tiles of hi = fp16(w) followed by the tiles of lo = fp16(w - hi)."""
         npad, kp = mat.shape
@@ -1032,11 +1040,12 @@ class Compiler:
             oh, ow = inv.h * 2, inv.w * 2
             out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
             tflags = ir.F_PIXSHUF | (ir.F_HILO if self.hilo else 0)
-            if PW and inv.span % 16 == 0 and inv.span <= 64 and 4 * coutp <= 256 and inv.up == 0 and not self.hilo:
-                # few input channels: conv_pw_kernel streams the pixels straight from global memory (pixel-shuffle store as ever)
+            if PW and inv.span % 8 == 0 and inv.span <= 64 and 4 * coutp <= (128 if self.hilo else 256) and inv.up == 0:
+                # few input channels: conv_pw_kernel streams the pixels straight from global memory (pixel-shuffle store as ever);
+                # hi + lo weights: two tables, the K slices walked twice over the same activation fragments
                 tflags |= ir.F_PW
-                Kp = inv.span
-                w_off = self.add_weights(("convTpw", wname, tuple(inv.segs), ep["out_name"]), w2.astype(np.float16).reshape(-1))
+                Kp = rup(inv.span, 16)
+                w_off = self.add_weights(("convTpw", wname, tuple(inv.segs), ep["out_name"], self.hilo), self.pw_weights(mat[:, :Kp], self.hilo))
             else:
                 w_off = self.add_weights(("convT", wname, tuple(inv.segs), ep["out_name"], self.hilo),
                                          self.tile_weights(mat, hilo=self.hilo))
@@ -1150,11 +1159,13 @@ class Compiler:
             w_off = self.add_weights(("convh", wname, tuple(inv.segs), ep["out_name"]),
                                      lambda: self.head_up2_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], inv.span))
         elif (PW and (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and inv.parts is None and inv_main.up == 0 and dot is None
-              and inv.span % 16 == 0 and inv.span <= 64 and coutp <= PW_MAX_COUT and not self.hilo and flags in (0, ir.F_RES)):
-            flags |= ir.F_PW
-            Kp = inv.span
-            w_off = self.add_weights(("convpw", wname, tuple(inv.segs), ep["out_name"]),
-                                     lambda: self.pack_conv_weights(w, ep["scale"], inv)[0][:, :inv.span].astype(np.float16).reshape(-1))
+              and inv.span % 8 == 0 and inv.span <= 64 and coutp <= (128 if self.hilo else PW_MAX_COUT) and flags in (0, ir.F_RES)):
+            # (hi + lo nets: the alternative is the generic kernel with K padded to 64 and walked twice — any cout count it can hold
+            # is faster here)
+            flags |= ir.F_PW | (ir.F_HILO if self.hilo else 0)
+            Kp = rup(inv.span, 16)          # weight rows are whole 16-channel K slices (zero columns behind the channels)
+            w_off = self.add_weights(("convpw", wname, tuple(inv.segs), ep["out_name"], self.hilo),
+                                     lambda: self.pw_weights(self.pack_conv_weights(w, ep["scale"], inv)[0][:, :rup(inv.span, 16)], self.hilo))
         elif col:
             Kp = kh * kw * inv.span
             if self.hilo:

@@ -10,14 +10,19 @@
 //           (rows padded by 16 bytes: conflict-free fragment reads) and read per 32-cout tile
 //   K order: slices of 16 channels in order — the accumulation order of the implicit-GEMM kernels (bit-identical results)
 // Weights: plain [Np][cinp] fp16, bias fp32 [Np].  Same epilogue as every conv kernel (conv_epilogue_tile, F_PIXSHUF included).
+// F_HILO (round 3; the mobile detectors run with fp16 hi + lo weight pairs and used to fall back to the generic kernel for all their
+// 1x1 layers): the lo table [Np][cinp] follows the hi table; both are staged (Np <= 128) and the K slices are walked twice over the
+// SAME activation fragments — hi slices, then lo slices, the order of the implicit-GEMM kernels' two-pass K walk.
 #include "conv_common.h"
 
 #define PW_MAXN 256
+#define PW_MAXN_HILO 128
 
-template <int KS>       // 16-channel K slices
+template <int KS, bool HILO = false>       // 16-channel K slices
 __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
     constexpr int ROWH = KS * 16 + 8;                    // halfs per staged weight row (16 bytes of padding)
-    __shared__ __attribute__((aligned(16))) half_t swt[PW_MAXN * ROWH];
+    constexpr int ROWS = HILO ? PW_MAXN_HILO : PW_MAXN, NT = HILO ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) half_t swt[NT * ROWS * ROWH];
     __shared__ float sbias[PW_MAXN];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -27,8 +32,13 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
     for (int v = tid; v < ntile * 32 * KS * 2; v += 256) {      // 16-byte vectors of the (zero-padded) weight matrix
         const int r = v / (KS * 2), c = v - r * (KS * 2);
         half8 x = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (r < p.Np) x = *reinterpret_cast<const half8*>(p.w + (long)r * (KS * 16) + c * 8);
+        if (r < p.Np) x = *reinterpret_cast<const half8*>(p.w + (long)r * (KS * 16) + c * 8);      // rows are KS * 16 wide (zero columns behind cinp)
         *reinterpret_cast<half8*>(swt + r * ROWH + c * 8) = x;
+        if constexpr (HILO) {
+            half8 y = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (r < p.Np) y = *reinterpret_cast<const half8*>(p.w + (long)(p.Np + r) * (KS * 16) + c * 8);
+            *reinterpret_cast<half8*>(swt + (ROWS + r) * ROWH + c * 8) = y;
+        }
     }
     for (int c = tid; c < ntile * 32; c += 256) sbias[c] = c < p.Np ? p.bias[c] : 0.f;
 
@@ -40,7 +50,11 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
         mm[i] = m0 + i * 32 + fx;
         const half_t* src = p.in + (mm[i] < p.M ? mm[i] : 0) * (long)p.in_ld + fj * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xf[i][ks] = *reinterpret_cast<const half8*>(src + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) {
+            // cinp % 16 == 8 (24 / 40 / 56 channels): the last half slice lies behind the pixel's channels — zeros, not the next pixel
+            xf[i][ks] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (ks * 16 + fj * 8 < p.cinp) xf[i][ks] = *reinterpret_cast<const half8*>(src + ks * 16);
+        }
     }
     int oh[2], ow[2];
     long nn[2];
@@ -67,6 +81,14 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], xf[i][ks], acc[i], 0, 0, 0);
+        if constexpr (HILO) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wf[ks] = *reinterpret_cast<const half8*>(swt + (ROWS + j * 32 + wr) * ROWH + ks * 16 + fj * 8);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], xf[i][ks], acc[i], 0, 0, 0);
+        }
         float bias[16];
         conv_epilogue_consts(sbias, j * 32, lane, bias);
 #pragma unroll
@@ -76,8 +98,8 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
 }
 
 bool conv_pw_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int Np, int inshift, int flags) {
-    return kh == 1 && kw == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && inshift == 0 && (cinp & 15) == 0 && cinp <= 64 && Np <= PW_MAXN
-           && !(flags & (F_SRC2 | F_DOT1 | F_HILO | F_PATCH | F_COL));
+    return kh == 1 && kw == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && inshift == 0 && (cinp & 7) == 0 && cinp <= 64
+           && Np <= ((flags & F_HILO) ? PW_MAXN_HILO : PW_MAXN) && !(flags & (F_SRC2 | F_DOT1 | F_PATCH | F_COL));
 }
 
 int launch_conv_pw(const ConvParams& p, hipStream_t st) {
@@ -85,7 +107,17 @@ int launch_conv_pw(const ConvParams& p, hipStream_t st) {
     const unsigned long long blocks = (unsigned long long)((p.M + 255) / 256);
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
     const dim3 grid((unsigned)blocks), block(256);
-    switch (p.cinp / 16) {
+    if (p.flags & F_HILO) {
+        switch ((p.cinp + 15) / 16) {
+            case 1: hipLaunchKernelGGL((conv_pw_kernel<1, true>), grid, block, 0, st, p); break;
+            case 2: hipLaunchKernelGGL((conv_pw_kernel<2, true>), grid, block, 0, st, p); break;
+            case 3: hipLaunchKernelGGL((conv_pw_kernel<3, true>), grid, block, 0, st, p); break;
+            case 4: hipLaunchKernelGGL((conv_pw_kernel<4, true>), grid, block, 0, st, p); break;
+            default: return VSE_E_UNSUPPORTED;
+        }
+        return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+    }
+    switch ((p.cinp + 15) / 16) {
         case 1: hipLaunchKernelGGL((conv_pw_kernel<1>), grid, block, 0, st, p); break;
         case 2: hipLaunchKernelGGL((conv_pw_kernel<2>), grid, block, 0, st, p); break;
         case 3: hipLaunchKernelGGL((conv_pw_kernel<3>), grid, block, 0, st, p); break;

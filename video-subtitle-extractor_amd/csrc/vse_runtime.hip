@@ -274,7 +274,7 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if (o.kind != OP_CONV) return 0;
     if (o.flags & F_UP2HEAD) return 400000;   // conv_head_up2_kernel
     if (o.flags & F_STEM) return 500000;      // conv_stem_kernel
-    if (o.flags & F_PW) return 800000 + o.p[P_CINP] / 16;   // conv_pw_kernel<KS>
+    if (o.flags & F_PW) return 800000 + (o.p[P_CINP] + 15) / 16;   // conv_pw_kernel<KS>
     if ((o.flags & F_COL) && o.p[P_KH] == 3 && o.p[P_KW] == 3) {   // conv_c3_kernel<RW, 8 / RW>
         int rw;
         conv_c3_plan(o.out.h, o.out.w, &rw);
