@@ -38,9 +38,11 @@
 #define C3RING 4
 #define C3BN 64
 
-template <int RW, int CW>
-__global__ __launch_bounds__(512, 4) void conv_c3_kernel(const ConvParams p) {
-    constexpr int BN = C3BN, TN = 2;
+// BN = 64 couts per block (TN = 2 accumulator tiles per row) or, for layers with <= 32 couts (the mobile detectors' 96 -> 24 neck convs,
+// the server detector's 32 -> 32), BN = 32: half the MFMAs, half the weight stage; everything else is the same code.
+template <int RW, int CW, int BN>
+__device__ __forceinline__ void conv_c3_body(const ConvParams& p) {
+    constexpr int TN = BN / 32;
     constexpr int TH = 2 * RW, TW = 32 * CW;
     constexpr int PW = TW + 8, PH = TH + 2;
     constexpr int PPIX = (PH * PW + 31) / 32 * 32;       // whole wave instructions
@@ -307,6 +309,11 @@ __global__ __launch_bounds__(512, 4) void conv_c3_kernel(const ConvParams p) {
 #endif
 }
 
+template <int RW, int CW>
+__global__ __launch_bounds__(512, 4) void conv_c3_kernel(const ConvParams p) { conv_c3_body<RW, CW, C3BN>(p); }
+template <int RW, int CW>
+__global__ __launch_bounds__(512, 4) void conv_c3n32_kernel(const ConvParams p) { conv_c3_body<RW, CW, 32>(p); }
+
 // Tile shape per map: estimated cost (in full tiles) of covering OH x OW with (2 RW) x (32 CW) tiles when waves outside the
 // map idle (a partial tile costs ~0.35 + 0.65 * live waves / 8 of a full one).  Mirrored by compiler.py (c3_tile_eff).
 static double c3_axis_cost(int n, int unit, int waves) {      // n pixels along an axis covered by tiles of `waves` x `unit`
@@ -340,7 +347,8 @@ int launch_conv_c3(const ConvParams& pin, int n_img, hipStream_t st) {
     static const int force = [] { const char* e = getenv("VSE_C3_RW"); return e && e[0] ? atoi(e) : 0; }();
     if (force == 8 || force == 4 || force == 2) rw = force;
     const int cw = 8 / rw;
-    p.ntn = (unsigned)((p.Np + C3BN - 1) / C3BN);
+    const int bn = p.Np <= 32 ? 32 : C3BN;
+    p.ntn = (unsigned)((p.Np + bn - 1) / bn);
     p.tiles_h = (p.OH + 2 * rw - 1) / (2 * rw);
     p.tiles_w = (p.OW + 32 * cw - 1) / (32 * cw);
     const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w * p.ntn;
@@ -357,7 +365,11 @@ int launch_conv_c3(const ConvParams& pin, int n_img, hipStream_t st) {
     (void)hipMemsetAsync(trace_dev, 0, blocks * 8 * sizeof(unsigned long long), st);
     p.trace = trace_dev;
 #endif
-    if (rw == 8) hipLaunchKernelGGL((conv_c3_kernel<8, 1>), grid, block, 0, st, p);
+    if (bn == 32) {
+        if (rw == 8) hipLaunchKernelGGL((conv_c3n32_kernel<8, 1>), grid, block, 0, st, p);
+        else if (rw == 4) hipLaunchKernelGGL((conv_c3n32_kernel<4, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_c3n32_kernel<2, 4>), grid, block, 0, st, p);
+    } else if (rw == 8) hipLaunchKernelGGL((conv_c3_kernel<8, 1>), grid, block, 0, st, p);
     else if (rw == 4) hipLaunchKernelGGL((conv_c3_kernel<4, 2>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv_c3_kernel<2, 4>), grid, block, 0, st, p);
 #ifdef VSE_TRACE

@@ -278,7 +278,7 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if ((o.flags & F_COL) && o.p[P_KH] == 3 && o.p[P_KW] == 3) {   // conv_c3_kernel<RW, 8 / RW>
         int rw;
         conv_c3_plan(o.out.h, o.out.w, &rw);
-        return 700000 + rw;
+        return 700000 + rw + (o.p[P_COUT] <= 32 ? 50000 : 0);      // + 50000: the 32-cout form conv_c3n32_kernel
     }
     if (o.flags & F_COL) return 600000 + 100 * o.p[P_KH] + conv_col_bn(o.p[P_COUT]);   // conv_col_kernel<KH, BN>
     if (o.flags & F_PATCH) {   // conv_patch_kernel<TH, BN, BIGP> -> 100000*BIGP + 1000*TH + BN
@@ -313,6 +313,7 @@ const char* vse_plan_op_kernel_name(vse_plan* p, int i) {
     }
     const int code = vse_plan_op_variant(p, i);
     if (code >= 800000) snprintf(buf, sizeof buf, "conv_pw_kernel<%d>", code - 800000);
+    else if (code >= 750000) snprintf(buf, sizeof buf, "conv_c3n32_kernel<%d, %d>", code - 750000, 8 / (code - 750000));
     else if (code >= 700000) snprintf(buf, sizeof buf, "conv_c3_kernel<%d, %d>", code - 700000, 8 / (code - 700000));
     else if (code >= 600000) snprintf(buf, sizeof buf, "conv_col_kernel<%d, %d>", (code - 600000) / 100, code % 100);
     else if (code >= 500000) snprintf(buf, sizeof buf, "conv_stem_kernel");
