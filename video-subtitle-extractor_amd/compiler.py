@@ -195,6 +195,7 @@ COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
 # 48 px height; every plan of a model selects as if its maps were this wide (the choice only steers efficiency, never results
 # ACROSS plans of one process; a different value is a different set of summation orders)
 RAGGED_SEL_W = int(os.environ.get("VSE_RAGGED_SELW", "768"))
+ONECH = os.environ.get("VSE_ONECH", "1") != "0"             # DB head: last transposed conv stores the fp32 map directly
 LSTM_MFMA = os.environ.get("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
 LSTM_WAVES = int(os.environ.get("VSE_LSTM_WAVES", "16"))    # 8: lstm_mfma_kernel, 16: lstm_mfma16_kernel (twice the loads in flight)
 
@@ -1038,8 +1039,18 @@ class Compiler:
             for q in range(4):
                 bias[q * coutp:q * coutp + cout] = ep["shift"]
             oh, ow = inv.h * 2, inv.w * 2
-            out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
             tflags = ir.F_PIXSHUF | (ir.F_HILO if self.hilo else 0)
+            cons = self._live_consumers(ep["out_name"])
+            if cout == 1 and len(cons) == 1 and self.ops[cons[0]]["type"] == "fetch" and ONECH:
+                # the DB head's last layer (transposed conv to ONE channel + sigmoid) feeds the fetch: store the fp32 map itself
+                # (one float per output pixel) instead of 8-channel fp16 groups that a copy pass then narrows: 4x fewer bytes
+                # written and no copy (F_ONECH)
+                ob = self.new_buf(inv.n, oh, ow, 1, esize=4, ext=len(self.outputs) + 1)
+                self.outputs.append(dict(name=ep["out_name"], kind="map", n=inv.n, h=oh, w=ow, c=1, ld=1, esize=4))
+                out = View(ob, 0, inv.n, oh, ow, [(0, 1)], 1)
+                tflags |= ir.F_OUT_F32 | ir.F_ONECH
+            else:
+                out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
             if PW and inv.span % 8 == 0 and inv.span <= 64 and 4 * coutp <= (128 if self.hilo else 256) and inv.up == 0:
                 # few input channels: conv_pw_kernel streams the pixels straight from global memory (pixel-shuffle store as ever);
                 # hi + lo weights: two tables, the K slices walked twice over the same activation fragments

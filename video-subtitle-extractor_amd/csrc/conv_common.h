@@ -231,6 +231,13 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = 0.f;
     }
+    if (p.flags & F_ONECH) {
+        // pixel-shuffle conv to ONE channel, fp32 map out (ld = 1): this lane's 8-channel run g is one quad; its first value is the pixel
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            if (live[g]) reinterpret_cast<float*>(p.out)[opix[g]] = v[g * 8];
+        return;
+    }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         if (!live[g]) continue;

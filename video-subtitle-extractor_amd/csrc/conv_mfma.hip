@@ -272,7 +272,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     }
     if (a.in.esize != 2 || (a.in.ld & 7) || (a.cinp & 7)) return VSE_E_INVAL;
     if ((a.flags & F_RES) && (a.res.esize != 2 || (a.res.ld & 3))) return VSE_E_INVAL;
-    if ((!(a.flags & F_DOT1) && (a.out.ld & 3)) || (a.Np & 7)) return VSE_E_INVAL;
+    if ((!(a.flags & (F_DOT1 | F_ONECH)) && (a.out.ld & 3)) || (a.Np & 7)) return VSE_E_INVAL;
+    if ((a.flags & F_ONECH) && (!(a.flags & F_PIXSHUF) || !(a.flags & F_OUT_F32) || a.Np != 32 || a.out.ld != 1 || a.out.esize != 4 || (a.flags & F_RES)))
+        return VSE_E_INVAL;
     // sanity on the output view: [n, OH(*2), OW(*2)]
     const int mul = (a.flags & F_PIXSHUF) ? 2 : 1;
     if (a.out.h != p.OH * mul || a.out.w != p.OW * mul || a.out.n != a.in.n) return VSE_E_INVAL;

@@ -75,6 +75,8 @@ F_WK32 = 128        # weights tiled [Kp/32][Np][32] (one wave DMA = 1 KiB contig
 F_PW = 4096         # pointwise conv over <= 64 input channels / <= 64 couts (conv_pw.hip): weights plain [Np][cinp] fp16
 F_IMGW = 8192       # OP_CONV (1x1 on conv_gemm_kernel): weights differ per image and come from in2 ([N,1,1,Kp*Np], written by
                     # OP_WSCALE): an SE gate folded into its 1x1 consumer; M tiles do not straddle images
+F_ONECH = 32768     # OP_CONV with F_PIXSHUF | F_OUT_F32 and ONE real cout: the output is the 1-channel fp32 map itself (ld = 1); every
+                    # lane's 8-channel run is one pixel-shuffle quad whose first channel is stored
 F_COL = 2048        # column-per-step LDS-patch kernel (conv_col.hip): weights packed [cinp/16][kw][kh][Np][16] + 3 zero stages
 F_UP2HEAD = 64      # F_SRC2 | F_DOT1 3x3 conv over [1-channel full-res map, x2-upsampled 64-channel map] evaluated on the LOW-RES
                     # grid: weights packed [chunk][parity][2x2 tap][Np][32] + [Np][32] for the 1-channel source (conv_head.hip)
