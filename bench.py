@@ -211,7 +211,6 @@ def main():
     frames_np, truth = synth.make_frames(args.batch, args.height, args.width, seed=100 + rank, return_truth=True)
     frames = torch.from_numpy(frames_np).to(ctx.tdev)          # inputs resident in HBM before the timed region
     quads = gt_quads(truth)
-    lo = rank * args.batch
     # stand-in detector weights: the text-kernel overlay of the generator's lines (see the module docstring), resident in HBM
     overlay_np, overlay = None, None
     if not modelzoo.has_real_weights(det_id):
