@@ -31,3 +31,32 @@ run(64, 64, (3, 3), 272, 480, 8, 150)
 run(160, 160, (3, 3), 68, 120, 32, 200)
 run(192, 192, (3, 3), 6, 192, 28, 300)
 run(32, 32, (5, 5), 136, 240, 16, 150)
+run(96, 24, (3, 3), 136, 240, 32, 200)      # conv_c3n32_kernel
+run(32, 32, (3, 3), 136, 240, 32, 200)
+
+
+def run_rec(mid, n, widths_lo, wt, reps):
+    """a ragged recogniser batch beside unrelated work on another stream: identical bits every time"""
+    sys.path.insert(0, os.getcwd())
+    from vse_amd import modelzoo
+    desc, wts = modelzoo.get_model(mid, seed=1)
+    net = engine.Net(ctx, desc, wts, want_probs=False, ragged=True)
+    h = 32 if mid.startswith("V2") else 48
+    rng = np.random.default_rng(3)
+    widths = rng.integers(widths_lo, wt + 1, n).astype(np.int32)
+    x = (torch.rand((n, h, wt, 8), device="cuda") * 2 - 1).half(); x[..., 3:] = 0
+    for i, wi in enumerate(widths):
+        x[i, :, int(wi):] = 0
+    first = net.run(x, widths=widths)[-1].clone()
+    side = torch.cuda.Stream(); junk = torch.rand((4096, 4096), device="cuda"); bad = 0
+    for rep in range(reps):
+        with torch.cuda.stream(side):
+            for _ in range(rep % 4): junk = junk @ junk * 1e-4
+        if not torch.equal(net.run(x, widths=widths)[-1], first): bad += 1
+    torch.cuda.synchronize()
+    print(mid, n, wt, "reps", reps, "mismatches", bad, flush=True)
+
+
+run_rec("V4_ch_rec", 24, 400, 768, 60)
+run_rec("V4_en_rec_fast", 48, 330, 640, 100)
+run_rec("V2_ch_rec", 40, 330, 640, 60)
