@@ -91,11 +91,20 @@ int vse_plan_run_ragged(vse_plan* plan, void* ws, void* const* ext, int n_ext, c
 /* Number of width levels a ragged plan expects in d_widths (0 for an ordinary plan). */
 int vse_plan_width_levels(vse_plan* plan);
 
+/* A detector plan compiled with the pre-processing fused into its stem conv (compiler fuse_preprocess: F_U8SRC) takes the uint8
+ * BGR frames themselves as ext[0]; their geometry (what vse_det_preprocess gets as arguments) is set here before vse_plan_run /
+ * vse_plan_profile, and by vse_det_forward.  Host-side state of the plan: set + run from one thread.  Replaces paddleocr
+ * DetResizeForTest + NormalizeImage + ToCHWImage (App. C.1) behind backend/tools/subtitle_detect.py:25, without the pass. */
+int vse_plan_set_source(vse_plan* plan, int src_h, int src_w, int64_t pitch, int64_t frame_stride);
+/* 1 when the plan takes uint8 frames (above), 0 when it takes the fp16 input of vse_det_preprocess. */
+int vse_plan_takes_frames(vse_plan* plan);
+
 /* ---- model-level calls ------------------------------------------------------------------------------------
  * One call per network invocation, composed of the entry points of this header over a compiled plan.
  * vse_det_forward = vse_det_preprocess + vse_plan_run: uint8 BGR frames -> DB probability maps d_prob fp32 [n, dst_h, dst_w]
  * (what paddleocr TextDetector computes before its post-processing, behind backend/tools/subtitle_detect.py:25).  d_in_f16 is
- * caller-owned scratch [n, dst_h, dst_w, 8] fp16; raw_input != 0 for a plan compiled with the normalisation in its stem.
+ * caller-owned scratch [n, dst_h, dst_w, 8] fp16 (may be NULL for a plan that takes the frames, vse_plan_takes_frames); raw_input
+ * != 0 for a plan compiled with the normalisation in its stem.
  * vse_rec_forward = vse_plan_run(_ragged) + vse_ctc_collapse(_ragged): recogniser input fp16 [b, h, w, 8] (vse_rec_preprocess)
  * -> arg-max / max-probability pairs d_idx_maxp [b, t, 2] and the CTC-collapsed class ids, lengths and mean confidences (what
  * paddleocr TextRecognizer computes behind backend/tools/ocr.py:27).  d_widths / out_level: the ragged plan's width table and

@@ -365,3 +365,11 @@ def test_input_norm_folded_into_the_stem(mid, hilo):
         assert e < 0.5 * e0 + 1e-6, (e, e0)
     # compiling twice from the same descriptor must not see the first compile's rewritten stem
     compiler.compile_model(desc, w, 1, 96, 160, hilo=hilo, input_norm=(mean, std))
+    # fuse_preprocess: the same program with the stem marked to resize the uint8 frames itself (the emulator is fed the resized
+    # pixels either way; the GPU test compares the two routes bit for bit)
+    fused = compiler.compile_model(desc, w, 1, 96, 160, hilo=hilo, input_norm=(mean, std), fuse_preprocess=True)
+    marked = [int(o["flags"]) & ir.F_U8SRC for o in fused.ops]
+    assert sum(1 for m in marked if m) == 1 and marked[0] and int(fused.ops[0]["flags"]) & ir.F_STEM
+    assert np.array_equal(ir_emul.Emulator(fused).run(raw)[0], ir_emul.Emulator(prog).run(raw)[0])
+    with pytest.raises(compiler.UnsupportedGraph):
+        compiler.compile_model(desc, w, 1, 96, 160, hilo=hilo, fuse_preprocess=True)          # needs input_norm

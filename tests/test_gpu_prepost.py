@@ -249,3 +249,31 @@ def test_db_fuzz_sample(ctx, capsys):
     finally:
         sys.argv = argv
     assert rc == 0, capsys.readouterr().out
+
+
+@pytest.mark.parametrize("mid,hilo", [("V3_ch_det_fast", True), ("V4_ch_det_fast", False), ("V4_ch_det", False), ("V2_ch_det", False)])
+def test_stem_with_fused_preprocessing_is_bit_identical(ctx, mid, hilo):
+    """compile_model(fuse_preprocess=True): the detector's stem conv resizes the uint8 frames itself (F_U8SRC, vse_det_forward
+    without a pre-processing pass).  Same integer bilinear arithmetic, same fp16 inputs, same K order -> the probability maps
+    equal those of the pre-processing pass + plan BIT FOR BIT: 1080p -> 544 x 960, 720p, a frame that needs no resize, and a
+    row-pitched view (`frame[cropped:]`, backend/tools/subtitle_ocr.py:283)."""
+    import torch
+    from oracle import net_ref
+    from vse_amd import engine, pipeline, synth
+    desc, w = net_ref.get_weights(mid)
+    nets = {f: engine.Net(ctx, desc, w, fetch_cols=(0,), hilo=hilo, input_norm=pipeline.DET_NORM, fuse_preprocess=f) for f in (False, True)}
+    cases = [synth.make_frames(2, 1080, 1920, seed=4), synth.make_frames(1, 720, 1280, seed=5), synth.make_frames(3, 96, 160, seed=6)]
+    for frames in cases:
+        dev = torch.from_numpy(frames).cuda()
+        views = [dev, dev[:, dev.shape[1] // 2:, :, :]]                       # whole frames; bottom half (non-contiguous frame stride)
+        for v in views:
+            rh, rw = pipeline.det_resize_shape(v.shape[1], v.shape[2])
+            a = nets[False].det_forward(v, rh, rw)
+            b = nets[True].det_forward(v, rh, rw)
+            assert nets[True].fuse_preprocess, "the stem of this detector must take the fused pre-processing"
+            assert torch.equal(a, b), (mid, tuple(v.shape))
+    # the fused plan refuses a pre-processed tensor without a frame geometry
+    fresh = engine.Net(ctx, desc, w, fetch_cols=(0,), hilo=hilo, input_norm=pipeline.DET_NORM, fuse_preprocess=True)
+    x = ctx.det_preprocess(torch.from_numpy(cases[2]).cuda(), 96, 160, raw=True)
+    with pytest.raises(engine.VseError, match="vse_plan_set_source"):
+        fresh.run(x)

@@ -266,6 +266,7 @@ class Compiler:
         self.wlevel_index = {}
         self.sel_w0 = RAGGED_SEL_W            # kernel selection of a ragged plan looks at THIS input width, never at the batch's
         self.input_norm = None                # (mean3, std3): see fold_input_norm
+        self.fuse_preprocess = False          # with input_norm: the stem conv reads the uint8 frames and resizes them itself (F_U8SRC)
         self._merge_parallel_convs()
         self.N, self.H, self.Wd = batch, height, width
         self.fetch_cols = tuple(fetch_cols)
@@ -1193,6 +1194,9 @@ class Compiler:
               and coutp <= 64 and inv.parts is None and inv_main.up == 0 and dot is None and flags in (0, ir.F_RES)):
             # stem over an image-like input (conv_stem.hip)
             flags |= ir.F_STEM | (ir.F_HILO if self.hilo else 0)
+            if self.fuse_preprocess and inv_main.buf.ext == 0:
+                flags |= ir.F_U8SRC              # the detector's pre-processing rides in the stem's patch staging (conv_stem.hip)
+                self._u8_fused = True
             w_off = self.add_weights(("convs", wname, tuple(inv.segs), ep["out_name"], self.hilo),
                                      lambda: self.stem_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], self.hilo))
         else:
@@ -1690,6 +1694,9 @@ class Compiler:
         if self.ragged:
             inb.wl = 0
         feed_c = self.fold_input_norm() if self.input_norm is not None else 3
+        if self.fuse_preprocess and self.input_norm is None:
+            raise UnsupportedGraph("fuse_preprocess needs input_norm (the stem must carry the normalisation)")
+        self._u8_fused = False
         for i, op in enumerate(self.ops):
             if i in self.done or not self.live[i]:
                 continue
@@ -1729,6 +1736,10 @@ class Compiler:
                 assert self._lower_virtual(i), (i, t)
             else:
                 raise NotImplementedError(f"{t} at op {i}")
+        if self.fuse_preprocess:
+            readers = [o for o in self.ir_ops if any(v is not None and v.buf is not None and v.buf.ext == 0 for v in o["ins"])]
+            if not self._u8_fused or len(readers) != 1 or not (readers[0]["flags"] & ir.F_U8SRC):
+                raise UnsupportedGraph("fuse_preprocess: the plan input is not read by exactly one 3x3 stem conv (conv_stem_kernel)")
         return self._finish()
 
     def _lower_fetch(self, i):
@@ -1804,7 +1815,7 @@ class Compiler:
 
 
 def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True, hilo=False,
-                  ragged=False, input_norm=None):
+                  ragged=False, input_norm=None, fuse_preprocess=False):
     """reuse=False gives every buffer its own workspace range (debugging: all intermediates stay readable).
     hilo=True stores every conv / depthwise / transposed-conv weight as an fp16 hi + lo pair (F_HILO): ~22-bit weights for
     twice the MFMA work — for nets whose boxes must track an fp32 reference closely.
@@ -1814,6 +1825,7 @@ def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_pro
     c.ragged = bool(ragged)
     c.hilo = bool(hilo)
     c.input_norm = input_norm      # (mean3, std3): the plan takes RAW resized pixels + a ones channel (Compiler.fold_input_norm)
+    c.fuse_preprocess = bool(fuse_preprocess)    # ... and resizes them itself from the uint8 frames (F_U8SRC): the plan input IS the frames
     if c.hilo:
         c.use_patch = False          # conv_patch_kernel has no two-pass K walk (the implicit-GEMM, stem and column kernels do)
     return c.compile()

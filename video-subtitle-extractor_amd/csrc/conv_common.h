@@ -33,6 +33,9 @@ struct ConvParams {
     long wimg_stride;       // F_IMGW: weight elements per image (Kp * Np); M tiles are then aligned to images
     int hw_img, tiles_img;  // F_IMGW: output pixels per image, M tiles per image
     const int* wl_out;      // ragged plans: per-image output width; pixels at ow >= wl_out[n] are stored as zeros
+    const uint8_t* u8src;   // F_U8SRC (stem): uint8 BGR frames [n][u8_h][u8_w][3], row pitch / frame stride in bytes
+    int u8_h, u8_w;
+    long u8_pitch, u8_fstride;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

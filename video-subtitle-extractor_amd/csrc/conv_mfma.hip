@@ -287,6 +287,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.in2_hs = a.in2.h; p.in2_ws = a.in2.w; p.nv0 = a.in.c >> 3;
     p.wimg_stride = 0; p.hw_img = 0; p.tiles_img = 0;
     p.wl_out = a.wl_out;
+    p.u8src = a.u8src; p.u8_h = a.u8_h; p.u8_w = a.u8_w; p.u8_pitch = a.u8_pitch; p.u8_fstride = a.u8_fstride;
+    if ((a.flags & F_U8SRC) && (!(a.flags & F_STEM) || !a.u8src || a.u8_h <= 0 || a.u8_w <= 0)) return VSE_E_INVAL;
     if (a.wl_out && (a.flags & (F_DOT1 | F_SRC2 | F_UP2HEAD | F_PIXSHUF))) return VSE_E_UNSUPPORTED;   // no per-sample width in these forms
     if (a.flags & F_IMGW) {
         // per-image weights (an SE gate folded into a 1x1 consumer): conv_gemm_kernel only

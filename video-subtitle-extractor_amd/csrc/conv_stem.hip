@@ -14,6 +14,7 @@
 //   channels zero); tap 9 carries zero weights and reads tap 0's pixel.
 // Same epilogue as every other conv kernel (conv_epilogue_tile).  Weights are packed [Np][10 taps][8] by the compiler.
 #include "conv_common.h"
+#include "resize_u8.h"
 
 #define ST_ROWS 8
 #define ST_COLS 32
@@ -22,7 +23,11 @@
 // which plain fp16 nets must not pay.  The weight tables are staged ONCE per block in LDS (<= 10 KiB each, 16 bytes per thread and
 // pass) and the fragments read from there: fetching the 20 fragments per lane straight from global memory moved 40-80 KiB through
 // the L1 / texture path per 256-pixel tile — more than the tile's input patch and output together.
-template <int SH, int SW, bool HILO>
+// U8 (F_U8SRC, round 3): the detector's pre-processing rides in the patch staging — the block resizes the pixels of its input patch
+// from the uint8 BGR frame (cv2 fixed-point INTER_LINEAR, resize_u8.h: the bytes det_preprocess_kernel writes) and stages
+// [u0, u1, u2, 1] as fp16 (exact); the stem's weights carry the normalisation (compiler input_norm).  The 8-channel fp16 detector
+// input (8.4 MB per 544 x 960 frame) is never written or read.
+template <int SH, int SW, bool HILO, bool U8 = false>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
     constexpr int PH_ = (ST_ROWS - 1) * SH + 3, PW_ = (ST_COLS - 1) * SW + 3, NPIX = PH_ * PW_;
     constexpr int NPIX4 = (NPIX * 4 + 7) & ~7;                                   // 16-byte aligned start of the weight tables
@@ -58,13 +63,37 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
     const int iy0 = oy0 * SH - p.ph, ix0 = ox0 * SW - p.pw;
 
     // ---- input patch: channels 0..3 of every pixel, zeros outside the image ---------------------------------------------------
-    const half_t* base = p.in + img * (long)p.Hs * p.Ws * p.in_ld;
-    for (int q = tid; q < NPIX; q += 256) {
-        const int py = q / PW_, px = q - py * PW_;
-        const int iy = iy0 + py, ix = ix0 + px;
-        half4 v = half4{0, 0, 0, 0};
-        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const half4*>(base + ((long)iy * p.Ws + ix) * p.in_ld);
-        *reinterpret_cast<half4*>(patch + q * 4) = v;
+    if constexpr (U8) {
+        const uint8_t* fb = p.u8src + img * p.u8_fstride;
+        const bool same = p.u8_w == p.W && p.u8_h == p.H;
+        for (int q = tid; q < NPIX; q += 256) {
+            const int py = q / PW_, px = q - py * PW_;
+            const int iy = iy0 + py, ix = ix0 + px;
+            half4 v = half4{0, 0, 0, 0};
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                const LinCoef cx = lin_coef(ix, p.W, p.u8_w), cy = lin_coef(iy, p.H, p.u8_h);
+                const int x1 = min(cx.s0 + 1, p.u8_w - 1), y1 = min(cy.s0 + 1, p.u8_h - 1);
+                const uint8_t* r0 = fb + (long)cy.s0 * p.u8_pitch;
+                const uint8_t* r1 = fb + (long)y1 * p.u8_pitch;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int u = same ? (int)r0[cx.s0 * 3 + c]
+                                       : cv_bilinear_u8(r0[cx.s0 * 3 + c], r0[x1 * 3 + c], r1[cx.s0 * 3 + c], r1[x1 * 3 + c], cx, cy);
+                    v[c] = (half_t)(float)u;
+                }
+                v[3] = (half_t)1.f;
+            }
+            *reinterpret_cast<half4*>(patch + q * 4) = v;
+        }
+    } else {
+        const half_t* base = p.in + img * (long)p.Hs * p.Ws * p.in_ld;
+        for (int q = tid; q < NPIX; q += 256) {
+            const int py = q / PW_, px = q - py * PW_;
+            const int iy = iy0 + py, ix = ix0 + px;
+            half4 v = half4{0, 0, 0, 0};
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const half4*>(base + ((long)iy * p.Ws + ix) * p.in_ld);
+            *reinterpret_cast<half4*>(patch + q * 4) = v;
+        }
     }
     __syncthreads();
 
@@ -152,6 +181,14 @@ int launch_conv_stem(const ConvParams& pin, int n_img, hipStream_t st) {
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
     const dim3 grid((unsigned)blocks), block(256);
     const bool hilo = p.flags & F_HILO;
+    if (p.flags & F_U8SRC) {
+        if (!p.u8src || p.u8_h <= 0 || p.u8_w <= 0) return VSE_E_INVAL;
+        if (p.sh == 2 && hilo) hipLaunchKernelGGL((conv_stem_kernel<2, 2, true, true>), grid, block, 0, st, p);
+        else if (p.sh == 2) hipLaunchKernelGGL((conv_stem_kernel<2, 2, false, true>), grid, block, 0, st, p);
+        else if (hilo) hipLaunchKernelGGL((conv_stem_kernel<1, 1, true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_stem_kernel<1, 1, false, true>), grid, block, 0, st, p);
+        return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+    }
     if (p.sh == 2 && hilo) hipLaunchKernelGGL((conv_stem_kernel<2, 2, true>), grid, block, 0, st, p);
     else if (p.sh == 2) hipLaunchKernelGGL((conv_stem_kernel<2, 2, false>), grid, block, 0, st, p);
     else if (hilo) hipLaunchKernelGGL((conv_stem_kernel<1, 1, true>), grid, block, 0, st, p);

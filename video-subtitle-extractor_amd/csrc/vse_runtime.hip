@@ -42,6 +42,9 @@ struct vse_plan {
     int max_ext;
     int n_levels;                     // ragged plans: width levels referenced by the ops (0 = not a ragged plan)
     int batch;                        // images per run (n of the first op's input)
+    bool u8_source;                   // an op pre-processes the uint8 frames itself (F_U8SRC): ext[0] = frames, geometry below
+    int src_h, src_w;
+    long src_pitch, src_fstride;
 };
 
 extern "C" {
@@ -119,6 +122,9 @@ int vse_plan_create(vse_ctx* c, int weights_id, const vse_op* ops, int n_ops, si
     p->max_ext = -1;
     p->n_levels = 0;
     p->batch = ops[0].in0.n;
+    p->u8_source = false;
+    p->src_h = p->src_w = 0;
+    p->src_pitch = p->src_fstride = 0;
     const size_t wbytes = c->weight_bytes[weights_id];
     for (int i = 0; i < n_ops; ++i) {
         const vse_op& o = ops[i];
@@ -133,6 +139,14 @@ int vse_plan_create(vse_ctx* c, int weights_id, const vse_op* ops, int n_ops, si
             return VSE_E_INVAL;
         }
         p->n_levels = std::max(p->n_levels, std::max(o.p[P_WLIN], o.p[P_WLOUT]));
+        if (o.kind == OP_CONV && (o.flags & F_U8SRC)) {
+            if (!(o.flags & F_STEM) || o.in0.arena != 2) {
+                set_err("op %d: F_U8SRC is for a stem conv that reads the plan input", i);
+                delete p;
+                return VSE_E_INVAL;
+            }
+            p->u8_source = true;
+        }
         const vse_view* vs[5] = {&o.in0, &o.in1, &o.in2, &o.out, &o.out2};
         for (const vse_view* v : vs) {
             if (v->n == 0) continue;
@@ -193,6 +207,11 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, const int32_t*
         a.in2 = in2; a.in2shift = o.p[P_IN2SHIFT];
         if (o.flags & F_IMGW) a.w = reinterpret_cast<const half_t*>(in2.ptr);      // per-image weights in the workspace
         a.wl_out = wl_out;
+        a.u8src = nullptr; a.u8_h = a.u8_w = 0; a.u8_pitch = a.u8_fstride = 0;
+        if (o.flags & F_U8SRC) {
+            a.u8src = reinterpret_cast<const uint8_t*>(ext[0]);
+            a.u8_h = p->src_h; a.u8_w = p->src_w; a.u8_pitch = p->src_pitch; a.u8_fstride = p->src_fstride;
+        }
         rc = launch_conv(a, st);
     } else {
         rc = launch_simple_op(o, in0, in1, in2, out, out2, wts, wl_in, wl_out, st);
@@ -215,8 +234,23 @@ static int check_run(vse_plan* p, void* ws, void* const* ext, int n_ext, const i
         set_err("%s: width table given to a plan that was not compiled for ragged batches", who);
         return VSE_E_INVAL;
     }
+    if (p->u8_source && (p->src_h <= 0 || p->src_w <= 0)) {
+        set_err("%s: the plan pre-processes the uint8 frames in its stem: call vse_plan_set_source (or vse_det_forward) first", who);
+        return VSE_E_INVAL;
+    }
     return VSE_OK;
 }
+
+int vse_plan_set_source(vse_plan* p, int src_h, int src_w, int64_t pitch, int64_t frame_stride) {
+    if (!p || src_h <= 0 || src_w <= 0 || pitch < (int64_t)src_w * 3 || frame_stride < 0) return VSE_E_INVAL;
+    if (!p->u8_source) {
+        set_err("vse_plan_set_source: the plan takes a pre-processed fp16 input, not uint8 frames");
+        return VSE_E_INVAL;
+    }
+    p->src_h = src_h; p->src_w = src_w; p->src_pitch = pitch; p->src_fstride = frame_stride;
+    return VSE_OK;
+}
+int vse_plan_takes_frames(vse_plan* p) { return p ? (p->u8_source ? 1 : 0) : VSE_E_INVAL; }
 
 int vse_plan_run(vse_plan* p, void* ws, void* const* ext, int n_ext, void* stream) {
     return vse_plan_run_ragged(p, ws, ext, n_ext, nullptr, stream);
@@ -238,12 +272,20 @@ int vse_plan_width_levels(vse_plan* p) { return p ? p->n_levels : VSE_E_INVAL; }
 // ---- model-level calls: one call per network invocation over a compiled plan ---------------------------------
 int vse_det_forward(vse_ctx* c, vse_plan* det_plan, void* ws, const void* d_bgr, int n, int src_h, int src_w, int64_t pitch,
                     int64_t frame_stride, int dst_h, int dst_w, int raw_input, void* d_in_f16, float* d_prob, void* stream) {
-    if (!c || !det_plan || !d_bgr || !d_in_f16 || !d_prob) return VSE_E_INVAL;
+    if (!c || !det_plan || !d_bgr || !d_prob) return VSE_E_INVAL;
     if (det_plan->batch != n || det_plan->ops[0].in0.h != dst_h || det_plan->ops[0].in0.w != dst_w) {
         set_err("vse_det_forward: the plan was compiled for %d x %d x %d, called with %d x %d x %d", det_plan->batch,
                 det_plan->ops[0].in0.h, det_plan->ops[0].in0.w, n, dst_h, dst_w);
         return VSE_E_INVAL;
     }
+    if (det_plan->u8_source) {
+        // the plan's stem resizes the frames itself: no pre-processing pass, no fp16 input tensor
+        int rc = vse_plan_set_source(det_plan, src_h, src_w, pitch, frame_stride);
+        if (rc != VSE_OK) return rc;
+        void* ext[2] = {const_cast<void*>(d_bgr), d_prob};
+        return vse_plan_run(det_plan, ws, ext, 2, stream);
+    }
+    if (!d_in_f16) return VSE_E_INVAL;
     static const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};      // paddleocr NormalizeImage (DB detectors)
     int rc = vse_det_preprocess(c, d_bgr, n, src_h, src_w, pitch, frame_stride, d_in_f16, dst_h, dst_w, raw_input ? nullptr : mean,
                                 raw_input ? nullptr : sd, stream);

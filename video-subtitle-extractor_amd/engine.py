@@ -18,7 +18,7 @@ EXPORTS = [
     "vse_weights_upload", "vse_weights_free", "vse_plan_create", "vse_plan_destroy", "vse_plan_run", "vse_plan_run_ragged",
     "vse_plan_width_levels", "vse_plan_profile", "vse_plan_op_variant", "vse_plan_op_kernel_name", "vse_det_preprocess", "vse_db_workspace_bytes",
     "vse_db_postprocess", "vse_rec_preprocess", "vse_rec_preprocess_scratch_bytes", "vse_ctc_collapse", "vse_ctc_collapse_ragged",
-    "vse_det_forward", "vse_rec_forward",
+    "vse_det_forward", "vse_rec_forward", "vse_plan_set_source", "vse_plan_takes_frames",
 ]
 
 
@@ -82,6 +82,8 @@ def load_library(path=None):
     lib.vse_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
     lib.vse_plan_run_ragged.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p]
     lib.vse_plan_width_levels.argtypes = [C.c_void_p]
+    lib.vse_plan_set_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64]
+    lib.vse_plan_takes_frames.argtypes = [C.c_void_p]
     lib.vse_det_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.vse_rec_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
@@ -242,13 +244,17 @@ class Context:
 class Net:
     """One model (descriptor + fp32 weights) with plans compiled per static input shape."""
 
-    def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True, hilo=False, ragged=False, input_norm=None):
+    def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True, hilo=False, ragged=False, input_norm=None,
+                 fuse_preprocess=False):
         """hilo=True: conv weights as fp16 hi + lo pairs (compiler.compile_model): ~22-bit weights, twice the MFMA work.
         ragged=True (recognisers): every plan takes a per-sample width vector (run(x, widths=...)); a sample's outputs do
         not depend on the batch it rides in (compiler.compile_model(ragged=True))."""
         self.ctx = ctx
         self.ragged = bool(ragged)
         self.input_norm = input_norm          # (mean3, std3): the net takes det_preprocess(raw=True) input (compiler.compile_model)
+        # the stem conv resizes the uint8 frames itself (needs input_norm): the plans take FRAMES — det_forward / profile_frames;
+        # run(x) with a pre-processed tensor is refused by the library
+        self.fuse_preprocess = bool(fuse_preprocess) and input_norm is not None
         self.desc = desc
         self.weights = weights
         self.fetch_cols = fetch_cols
@@ -264,8 +270,15 @@ class Net:
     def program(self, n, h, w):
         key = (n, h, w)
         if key not in self.plans:
-            prog = compiler.compile_model(self.desc, self.weights, n, h, w, self.fetch_cols, self.want_probs,
-                                          self.store, hilo=self.hilo, ragged=self.ragged, input_norm=self.input_norm)
+            try:
+                prog = compiler.compile_model(self.desc, self.weights, n, h, w, self.fetch_cols, self.want_probs,
+                                              self.store, hilo=self.hilo, ragged=self.ragged, input_norm=self.input_norm,
+                                              fuse_preprocess=self.fuse_preprocess)
+            except compiler.UnsupportedGraph:
+                if not self.fuse_preprocess or self.plans:
+                    raise
+                self.fuse_preprocess = False      # a graph whose feed is not read by one 3x3 stem conv: keep the pre-processing pass
+                return self.program(n, h, w)
             self.plans[key] = [prog, None]
         return self.plans[key][0]
 
@@ -359,13 +372,34 @@ class Net:
         self.program(n, dst_h, dst_w)
         prog, handle = self._ensure((n, dst_h, dst_w))
         assert len(prog.outputs) == 1 and prog.outputs[0]["kind"] == "map" and prog.outputs[0]["ld"] == 1, "not a one-map detector plan"
-        x = t.empty((n, dst_h, dst_w, 8), dtype=t.float16, device=self.ctx.tdev)
+        x = None if self.fuse_preprocess else t.empty((n, dst_h, dst_w, 8), dtype=t.float16, device=self.ctx.tdev)
         prob = t.empty((n, dst_h, dst_w), dtype=t.float32, device=self.ctx.tdev)
         ws = self._workspace((n, dst_h, dst_w), prog, slot)
         _check(self.ctx.lib.vse_det_forward(self.ctx.handle, handle, C.c_void_p(ws.data_ptr()), C.c_void_p(frames_u8.data_ptr()), n, h, w,
                                             frames_u8.stride(1), frames_u8.stride(0), dst_h, dst_w, 1 if self.input_norm is not None else 0,
-                                            C.c_void_p(x.data_ptr()), C.c_void_p(prob.data_ptr()), self.ctx.stream()), "vse_det_forward")
+                                            C.c_void_p(x.data_ptr()) if x is not None else None, C.c_void_p(prob.data_ptr()),
+                                            self.ctx.stream()), "vse_det_forward")
         return prob
+
+    def profile_frames(self, frames_u8, dst_h, dst_w, slot=0):
+        """profile() of a detector net fed FRAMES: pre-processing pass + plan for an ordinary net, the plan alone when its stem
+        pre-processes.  -> (ms per op, program, kernel names); self.last_outs = the outputs."""
+        if not self.fuse_preprocess:
+            return self.profile(self.ctx.det_preprocess(frames_u8, dst_h, dst_w, raw=self.input_norm is not None), slot)
+        t = self.ctx.torch
+        n, h, w, _ = frames_u8.shape
+        self.program(n, dst_h, dst_w)
+        prog, handle = self._ensure((n, dst_h, dst_w))
+        _check(self.ctx.lib.vse_plan_set_source(handle, h, w, frames_u8.stride(1), frames_u8.stride(0)), "vse_plan_set_source")
+        outs = [t.empty((o["n"], o["h"], o["w"], o["ld"]), dtype=t.float32, device=self.ctx.tdev) for o in prog.outputs]
+        ptrs = (C.c_void_p * (1 + len(outs)))(frames_u8.data_ptr(), *[o.data_ptr() for o in outs])
+        ms = (C.c_float * len(prog.ops))()
+        ws = self._workspace((n, dst_h, dst_w), prog, slot)
+        self.last_outs = outs
+        _check(self.ctx.lib.vse_plan_profile(handle, C.c_void_p(ws.data_ptr()), ptrs, len(ptrs), None, self.ctx.stream(), ms),
+               "vse_plan_profile")
+        names = [self.ctx.lib.vse_plan_op_kernel_name(handle, i).decode() for i in range(len(prog.ops))]
+        return np.array(ms[:], dtype=np.float32), prog, names
 
     def rec_forward(self, x, widths=None, slot=0):
         """Model-level call of a recogniser net built with want_probs=False (vse_rec_forward): fp16 [B,h,w,8] (+ per-sample widths of

@@ -75,6 +75,8 @@ F_WK32 = 128        # weights tiled [Kp/32][Np][32] (one wave DMA = 1 KiB contig
 F_PW = 4096         # pointwise conv over <= 64 input channels / <= 64 couts (conv_pw.hip): weights plain [Np][cinp] fp16
 F_IMGW = 8192       # OP_CONV (1x1 on conv_gemm_kernel): weights differ per image and come from in2 ([N,1,1,Kp*Np], written by
                     # OP_WSCALE): an SE gate folded into its 1x1 consumer; M tiles do not straddle images
+F_U8SRC = 65536     # OP_CONV | F_STEM reading the plan input: the input is the uint8 BGR frames and the kernel resizes them itself (cv2
+                    # fixed-point bilinear, the bytes vse_det_preprocess writes in raw mode); frame geometry via vse_plan_set_source
 F_ONECH = 32768     # OP_CONV with F_PIXSHUF | F_OUT_F32 and ONE real cout: the output is the 1-channel fp32 map itself (ld = 1); every
                     # lane's 8-channel run is one pixel-shuffle quad whose first channel is stored
 F_COL = 2048        # column-per-step LDS-patch kernel (conv_col.hip): weights packed [cinp/16][kw][kh][Np][16] + 3 zero stages

@@ -75,14 +75,15 @@ class OcrPipeline:
         an fp32 reference.  "auto" uses it for the mobile detectors (< 4 M parameters), where the second pass
         hides behind the memory traffic, and plain fp16 for the server models.
         det_input: "raw" — the detector is fed the resized uint8 pixels themselves (+ a ones channel) and its stem conv carries
-        paddleocr's (x/255 - mean)/std, so it computes on the reference's exact input values; "normalized" — the fp16 rounding
+        paddleocr's (x/255 - mean)/std, so it computes on the reference's exact input values; the resize itself happens inside
+        the stem kernel's patch staging (no pre-processing pass, no fp16 input tensor); "normalized" — the fp16 rounding
         of the normalised image (rounds 1-2; moves the real detector's map by up to 4e-3)."""
         self.ctx = ctx
         assert det_input in ("raw", "normalized")
         self.det_input = det_input
         self.det_weights = det_weights = resolve_det_weights(det_weights, det_model[1])
         self.det = engine.Net(ctx, det_model[0], det_model[1], fetch_cols=(0,), hilo=det_weights == "fp16x2",
-                              input_norm=DET_NORM if det_input == "raw" else None)
+                              input_norm=DET_NORM if det_input == "raw" else None, fuse_preprocess=det_input == "raw")
         # ragged plans for every mode: "reference" runs them with uniform widths, so the modes share kernels and summation orders
         self.rec = engine.Net(ctx, rec_model[0], rec_model[1], want_probs=False, ragged=True)
         self.charset = charset
@@ -116,9 +117,8 @@ class OcrPipeline:
         rh, rw = det_resize_shape(h, w, self.limit)
         if getattr(self, "profile_sink", None) is None:
             return self.det.det_forward(frames, rh, rw, slot)          # vse_det_forward: pre-process + network in one call
-        x = self.ctx.det_preprocess(frames, rh, rw, raw=getattr(self, "det_input", "normalized") == "raw")
-        out = self._run(self.det, x, slot)[0]     # [N,rh,rw,1] fp32
-        return out.view(n, rh, rw)
+        self.profile_sink.append(self.det.profile_frames(frames, rh, rw, slot))
+        return self.det.last_outs[0].view(n, rh, rw)
 
     def detect(self, frames):
         """-> list per frame of float32 [k,4,2] boxes (paddleocr TextDetector output, unsorted)."""

@@ -281,7 +281,7 @@ class TextDetector:
         self.pipe.det_weights = pipeline.resolve_det_weights(getattr(args, "det_weights", "auto"), model[1])
         self.pipe.det_input = "raw"
         self.pipe.det = engine.Net(ctx, model[0], model[1], fetch_cols=(0,), hilo=self.pipe.det_weights == "fp16x2",
-                                   input_norm=pipeline.DET_NORM)
+                                   input_norm=pipeline.DET_NORM, fuse_preprocess=True)
         self.pipe.limit = getattr(args, "det_limit_side_len", 960)
         self.pipe.db = dict(thresh=getattr(args, "det_db_thresh", 0.3), box_thresh=getattr(args, "det_db_box_thresh", 0.6),
                             unclip_ratio=getattr(args, "det_db_unclip_ratio", 1.5))
