@@ -34,9 +34,13 @@ def _act(x, code, a=0.0, b=0.0):
 
 
 class Emulator:
-    def __init__(self, prog, round_f16=False):
+    def __init__(self, prog, round_f16=False, round_ops=None):
+        """round_ops (with round_f16=False): indices of the ops whose fp16 OUTPUTS are rounded to fp16 while everything else stays
+        fp32 — which stored tensors' rounding moves a result (tools/act_rounding_study.py)."""
         self.prog = prog
         self.round = round_f16
+        self.round_ops = set(round_ops) if round_ops is not None else None
+        self.cur_op = -1
         # round_f16: byte-exact fp16 workspace.  otherwise: fp32 shadow with one float per 2 bytes.
         # poisoned with NaN: pad channels / stale buffers must never leak into results
         if round_f16:
@@ -105,6 +109,8 @@ class Emulator:
         if self._shadow(v):
             st = es // 2
             idx = int(v["off"]) // 2 + (np.arange(n * h * w)[:, None] * ld + np.arange(c)[None, :]) * st
+            if self.round_ops is not None and es == 2 and self.cur_op in self.round_ops:
+                arr = arr.astype(np.float16).astype(np.float32)
             arena[idx] = arr
             return
         dt = np.float16 if es == 2 else np.float32
@@ -132,7 +138,8 @@ class Emulator:
         self.ext[0] = np.ascontiguousarray(x_nhwc8.astype(np.float16)).view(np.uint8).reshape(-1)
         for k, o in enumerate(prog.outputs):
             self.ext[k + 1] = np.zeros(o["n"] * o["h"] * o["w"] * o["ld"] * o["esize"], dtype=np.uint8)
-        for r in prog.ops:
+        for k, r in enumerate(prog.ops):
+            self.cur_op = k
             self.wl_in = self.wl_out = None
             if self.wtab is not None:
                 if int(r["p"][ir.P_WLIN]):
