@@ -292,3 +292,29 @@ def test_run_ocr_tasks_uses_predict_stream_in_batch_order():
     ocr = OcrStreamed()
     b = extractor.run_ocr_tasks(src, tasks, ocr, batch=4, uploader=FakeUploader())
     assert a == b and ocr.seen == [4, 1, 4, 1, 3]          # shape changes close a batch: 5 + 5 + 3 frames of three shapes
+
+
+def test_mjpeg_avi_is_decoded_by_pillow(tmp_path):
+    """Motion-JPEG AVI — the one compressed format with a decoder on these boxes (Pillow / libjpeg): every frame of the file equals
+    Pillow's own decode of that frame's JPEG bytes (BGR order like cv2), random access works, and the stream still refuses other
+    codecs.  (FFmpeg's MJPEG decoder, which the reference reaches through cv2.VideoCapture, may differ by a grey level or two.)"""
+    import io
+    from PIL import Image
+    from vse_amd import ingest, synth
+    frames = synth.make_frames(5, 120, 200, seed=3)
+    p = str(tmp_path / "clip_mjpeg.avi")
+    ingest.write_avi_mjpeg(p, frames, 25.0, quality=92)
+    src = ingest.open_source(p)
+    assert src.mjpeg and (src.frame_count, src.width, src.height) == (5, 200, 120) and abs(src.fps - 25.0) < 1e-9
+    got = list(src.frames())
+    for k, g in enumerate(got):
+        assert g.shape == (120, 200, 3) and g.dtype == np.uint8
+        assert np.abs(g.astype(int) - frames[k].astype(int)).mean() < 8.0            # lossy (noisy synthetic background), but the same picture
+    # equals Pillow's decode of the very bytes stored in the file
+    raw = open(p, "rb").read()
+    off = raw.index(b"00dc")
+    n = int.from_bytes(raw[off + 4:off + 8], "little")
+    ref = np.asarray(Image.open(io.BytesIO(raw[off + 8:off + 8 + n])).convert("RGB"))[:, :, ::-1]
+    assert np.array_equal(got[0], ref) and np.array_equal(src.read(1), ref)
+    assert src.read(6) is None and src.pos_msec(2) == 80.0
+    src.close()

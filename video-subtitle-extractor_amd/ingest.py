@@ -7,6 +7,11 @@ bit-exactly is uncompressed video: AVI with 24-bit BGR DIB frames ('DIB ' / BI_R
 out.avi` writes and cv2 reads back unchanged), and a stack of frames in a .npy file.  Both give the frame-source interface of
 extractor.py: frame_count, fps, read(frame_no) (1-based random access, like CAP_PROP_POS_FRAMES = frame_no - 1 then read()),
 frames() (decode order), pos_msec(frame_no) (what the SRT writer asks for, see AviBgr24Source.pos_msec).
+
+Round 3: Motion-JPEG AVI (`ffmpeg -c:v mjpeg`, what many capture devices write) is the ONE compressed format that can be read here —
+every frame is a stand-alone baseline JPEG, and Pillow (libjpeg-turbo; importable on both boxes) decodes it.  The reference decodes
+the same stream with FFmpeg's own MJPEG decoder through cv2.VideoCapture: its IDCT / chroma up-sampling differ from libjpeg's by
++-1..2 grey levels on some pixels, so this source is NOT bit-identical to the reference's decode (the uncompressed sources are).
 """
 import struct
 
@@ -56,8 +61,41 @@ def write_avi_bgr24(path, frames, fps, riff_frames=None, dropped=()):
             fp.write(b"RIFF" + struct.pack("<I", len(body)) + body)
 
 
+def write_avi_mjpeg(path, frames, fps, quality=90):
+    """Motion-JPEG AVI (one 'vids' stream, fourcc MJPG, every frame a baseline JPEG encoded by Pillow)."""
+    import io
+    from PIL import Image
+    frames = [np.asarray(f) for f in frames]
+    h, w, _ = frames[0].shape
+    rate, scale = int(round(fps * 1000)), 1000
+    blobs = []
+    for f in frames:
+        bio = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(f[:, :, ::-1])).save(bio, format="JPEG", quality=quality)
+        blobs.append(bio.getvalue())
+    big = max(len(b) for b in blobs)
+
+    def chunk(tag, data):
+        return tag + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
+
+    def lst(tag, data):
+        return b"LIST" + struct.pack("<I", len(data) + 4) + tag + data
+    avih = struct.pack("<14I", int(1e6 / fps), big * int(fps + 1), 0, 0x10, len(frames), 0, 1, big, w, h, 0, 0, 0, 0)
+    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, scale, rate, 0, len(frames), big, 0xFFFFFFFF, 0, 0, 0, w, h)
+    strf = struct.pack("<IiiHH4sIiiII", 40, w, h, 1, 24, b"MJPG", w * h * 3, 0, 0, 0, 0)
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    movi, idx = b"", b""
+    for b in blobs:
+        idx += b"00dc" + struct.pack("<III", 0x10, 4 + len(movi), len(b))
+        movi += chunk(b"00dc", b)
+    body = b"AVI " + hdrl + lst(b"movi", movi) + chunk(b"idx1", idx)
+    with open(path, "wb") as fp:
+        fp.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
 class AviBgr24Source:
-    """Random-access reader of the files write_avi_bgr24 (or ffmpeg rawvideo bgr24) produces; anything else is refused."""
+    """Random-access reader of uncompressed BGR24 AVI (write_avi_bgr24 / ffmpeg rawvideo bgr24) and of Motion-JPEG AVI
+    (write_avi_mjpeg / ffmpeg -c:v mjpeg; frames decoded by Pillow); any other codec is refused."""
 
     def __init__(self, path):
         self.path = path
@@ -68,6 +106,7 @@ class AviBgr24Source:
         self._offsets = []
         self.width = self.height = None
         self.fps = None
+        self.mjpeg = False
         # every top-level RIFF chunk: the 'AVI ' one, then the OpenDML 'AVIX' segments a muxer opens about every GiB (170 frames
         # of 1080p bgr24) — a reader that stops after the first would silently see the first seconds of a clip only
         self._fp.seek(0, 2)
@@ -96,15 +135,20 @@ class AviBgr24Source:
             elif tag == b"strh":
                 d = fp.read(n)
                 if d[:4] == b"vids":
-                    if d[4:8] not in (b"DIB ", b"\0\0\0\0", b"RAW "):
-                        raise ValueError(f"{self.path}: compressed video ({d[4:8]!r}) needs a codec; only uncompressed BGR24 AVI "
-                                         "can be read here")
+                    self.fourcc = d[4:8]
+                    if d[4:8].upper() in (b"MJPG", b"JPEG"):
+                        self.mjpeg = True
+                    elif d[4:8] not in (b"DIB ", b"\0\0\0\0", b"RAW "):
+                        raise ValueError(f"{self.path}: compressed video ({d[4:8]!r}) needs a codec; only uncompressed BGR24 and "
+                                         "Motion-JPEG AVI can be read here")
                     scale, rate = struct.unpack("<II", d[20:28])
                     self.fps = rate / float(scale)
             elif tag == b"strf":
                 d = fp.read(n)
                 _sz, w, h, _planes, bits, comp = struct.unpack("<IiiHHI", d[:20])
-                if bits != 24 or comp != 0:
+                if getattr(self, "mjpeg", False):
+                    self.width, self.height, self._bottom_up = w, abs(h), False
+                elif bits != 24 or comp != 0:
                     raise ValueError(f"{self.path}: only BI_RGB 24-bit frames are supported (bits={bits}, compression={comp})")
                 self.width, self.height, self._bottom_up = w, abs(h), h > 0
             elif tag in (b"00db", b"00dc"):
@@ -118,6 +162,17 @@ class AviBgr24Source:
         while n == 0 and frame_no > 1:          # zero-length chunk = dropped frame: the previous picture stays on screen
             frame_no -= 1
             off, n = self._offsets[frame_no - 1]
+        if self.mjpeg:
+            if n == 0:
+                return None
+            import io
+            from PIL import Image
+            self._fp.seek(off)
+            img = Image.open(io.BytesIO(self._fp.read(n)))
+            rgb = np.asarray(img.convert("RGB"))
+            if rgb.shape[:2] != (self.height, self.width):
+                raise ValueError(f"{self.path}: frame {frame_no} is {rgb.shape[1]}x{rgb.shape[0]}, the stream header says {self.width}x{self.height}")
+            return np.ascontiguousarray(rgb[:, :, ::-1])            # BGR like cv2
         if n < self._stride * self.height:
             return None
         self._fp.seek(off)
