@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--rec-streams", type=int, default=2)
     ap.add_argument("--rec-span", type=int, default=2, help="streaming form, ragged mode: the crops of this many consecutive batches are "
                     "recognised together (results do not depend on the grouping; larger launches fill the chip on the recogniser's small maps)")
+    ap.add_argument("--rec-graphs", action="store_true", help="every recogniser invocation (plan + CTC collapse, ~80 launches) as one HIP graph "
+                    "captured against fixed buffers (needs --rec-streams > 1)")
     ap.add_argument("--ragged-floor", type=int, default=None, help="ragged grouping: crop-pixels below which a launch sequence stops getting faster")
     ap.add_argument("--ragged-launch-cost", type=int, default=None, help="ragged grouping: fixed cost of one launch sequence in crop-pixels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -204,6 +206,7 @@ def main():
                                 rec_h=32 if args.models == "v2" else 48, limit_side_len=args.limit_side)
 
     pipe.rec_streams = args.rec_streams
+    pipe.rec_graphs = args.rec_graphs
     if args.ragged_floor is not None:
         pipe.ragged_floor = args.ragged_floor
     if args.ragged_launch_cost is not None:

@@ -114,6 +114,16 @@ int vse_det_forward(vse_ctx* ctx, vse_plan* det_plan, void* ws, const void* d_bg
 int vse_rec_forward(vse_ctx* ctx, vse_plan* rec_plan, void* ws, const void* d_rec_in_f16, const int32_t* d_widths, int out_level,
                     void* d_idx_maxp, int b, int t, int32_t* d_out_idx, int32_t* d_out_len, float* d_out_conf, void* stream);
 
+/* vse_rec_forward captured as ONE HIP graph against fixed buffers (input, width table, workspace, outputs stay at these addresses;
+ * the caller refills input and width table before every vse_graph_launch on the same stream).  `stream` must not be the default
+ * stream.  Replaces ~80 kernel launches per recogniser invocation by one graph launch (backend/tools/ocr.py:27 -> TextRecognizer). */
+typedef struct vse_graph vse_graph;
+int vse_rec_graph_create(vse_ctx* ctx, vse_plan* rec_plan, void* ws, const void* d_rec_in_f16, const int32_t* d_widths, int out_level,
+                         void* d_idx_maxp, int b, int t, int32_t* d_out_idx, int32_t* d_out_len, float* d_out_conf, void* stream,
+                         vse_graph** graph);
+int vse_graph_launch(vse_graph* graph, void* stream);
+void vse_graph_destroy(vse_graph* graph);
+
 /* Per-op timing of one run with HIP events on `stream` (synchronises); ms[n_ops] filled.  d_widths as for
  * vse_plan_run_ragged (NULL for an ordinary plan). */
 int vse_plan_profile(vse_plan* plan, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream, float* ms);

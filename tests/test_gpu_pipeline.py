@@ -437,3 +437,22 @@ def test_crops_of_several_batches_recognised_together(ctx):
     boxes = [[b for b, _ in w] for w in want]
     multi = pipe.recognize_multi(batches[:3], boxes[:3])
     assert multi == [[r for _, r in w] for w in want[:3]]
+
+
+def test_recogniser_as_hip_graph_gives_the_same_results(ctx):
+    """OcrPipeline.rec_graphs: every recogniser invocation (plan + CTC collapse) captured as one HIP graph against fixed buffers
+    (vse_rec_graph_create / vse_graph_launch) — same (text, score) pairs as plain launches, run after run, ragged widths included."""
+    import torch
+    from vse_amd import pipeline, synth
+    det = net_ref.get_weights("V3_ch_det_fast")
+    rec = net_ref.get_weights("V4_en_rec_fast")
+    pipe = pipeline.OcrPipeline(ctx, det, rec, P.en_charset(), bucket=256, batch_round=4)
+    pipe.rec_streams = 2
+    pipe.ragged_floor, pipe.ragged_launch_cost = 0, 300          # several width groups per call: they run on the side streams
+    batches = [torch.from_numpy(synth.make_frames(8, 720, 1280, seed=70 + k, p_two_lines=0.6)).cuda() for k in range(3)]
+    want = [pipe.ocr(b) for b in batches]
+    pipe.rec_graphs = True
+    for _ in range(2):
+        got = [pipe.ocr(b) for b in batches]
+        assert [[r for _, r in g] for g in got] == [[r for _, r in w] for w in want]
+    assert getattr(pipe.rec, "_graphs", {}) and all(v["graph"] is not None for v in pipe.rec._graphs.values())

@@ -310,6 +310,58 @@ int vse_rec_forward(vse_ctx* c, vse_plan* rec_plan, void* ws, const void* d_rec_
                                    d_out_conf, stream);
 }
 
+// ---- a recogniser invocation as ONE HIP graph ---------------------------------------------------------------------------------
+// ~80 launches of a recogniser plan + the CTC collapse, captured once against FIXED buffers (the caller keeps input, width table,
+// workspace and outputs at the same addresses and refills them) and replayed with a single hipGraphLaunch.
+struct vse_graph {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+int vse_rec_graph_create(vse_ctx* c, vse_plan* rec_plan, void* ws, const void* d_rec_in_f16, const int32_t* d_widths, int out_level,
+                         void* d_idx_maxp, int b, int t, int32_t* d_out_idx, int32_t* d_out_len, float* d_out_conf, void* stream,
+                         vse_graph** out) {
+    if (!out) return VSE_E_INVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (!st) {
+        set_err("vse_rec_graph_create: capture needs a non-default stream");
+        return VSE_E_INVAL;
+    }
+    HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = vse_rec_forward(c, rec_plan, ws, d_rec_in_f16, d_widths, out_level, d_idx_maxp, b, t, d_out_idx, d_out_len, d_out_conf, stream);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);
+    if (rc != VSE_OK) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess || !g) {
+        set_err("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+        return VSE_E_HIP;
+    }
+    vse_graph* vg = new vse_graph{g, nullptr};
+    const hipError_t e2 = hipGraphInstantiate(&vg->exec, g, nullptr, nullptr, 0);
+    if (e2 != hipSuccess) {
+        set_err("hipGraphInstantiate failed: %s", hipGetErrorString(e2));
+        (void)hipGraphDestroy(g);
+        delete vg;
+        return VSE_E_HIP;
+    }
+    *out = vg;
+    return VSE_OK;
+}
+int vse_graph_launch(vse_graph* g, void* stream) {
+    if (!g || !g->exec) return VSE_E_INVAL;
+    HIP_TRY(hipGraphLaunch(g->exec, reinterpret_cast<hipStream_t>(stream)));
+    return VSE_OK;
+}
+void vse_graph_destroy(vse_graph* g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+}
+
 int vse_plan_op_variant(vse_plan* p, int i) {
     if (!p || i < 0 || i >= (int)p->ops.size()) return VSE_E_INVAL;
     const vse_op& o = p->ops[i];

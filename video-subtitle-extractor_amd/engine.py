@@ -19,6 +19,7 @@ EXPORTS = [
     "vse_plan_width_levels", "vse_plan_profile", "vse_plan_op_variant", "vse_plan_op_kernel_name", "vse_det_preprocess", "vse_db_workspace_bytes",
     "vse_db_postprocess", "vse_rec_preprocess", "vse_rec_preprocess_scratch_bytes", "vse_ctc_collapse", "vse_ctc_collapse_ragged",
     "vse_det_forward", "vse_rec_forward", "vse_plan_set_source", "vse_plan_takes_frames",
+    "vse_rec_graph_create", "vse_graph_launch", "vse_graph_destroy",
 ]
 
 
@@ -82,6 +83,11 @@ def load_library(path=None):
     lib.vse_plan_run.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
     lib.vse_plan_run_ragged.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p]
     lib.vse_plan_width_levels.argtypes = [C.c_void_p]
+    lib.vse_rec_graph_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.vse_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+    lib.vse_graph_destroy.argtypes = [C.c_void_p]
+    lib.vse_graph_destroy.restype = None
     lib.vse_plan_set_source.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64]
     lib.vse_plan_takes_frames.argtypes = [C.c_void_p]
     lib.vse_det_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64,
@@ -422,6 +428,43 @@ class Net:
                                             C.c_void_p(idx_maxp.data_ptr()), n, tt, C.c_void_p(oi.data_ptr()), C.c_void_p(ol.data_ptr()),
                                             C.c_void_p(oc.data_ptr()), self.ctx.stream()), "vse_rec_forward")
         return oi, ol, oc
+
+    def rec_graph_buffers(self, n, h, w, slot=0):
+        """Fixed buffers of the HIP-graph form of rec_forward for plan key (n, h, w) and workspace slot: the caller fills
+        bufs["x"] (recogniser input, e.g. rec_preprocess(out=bufs["x"])) and calls rec_forward_graph(bufs, widths)."""
+        t = self.ctx.torch
+        key = (n, h, w, slot)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        if key not in self._graphs:
+            self.program(n, h, w)
+            prog, handle = self._ensure((n, h, w))
+            tt = prog.outputs[0]["w"]
+            dev = self.ctx.tdev
+            self._graphs[key] = dict(
+                x=t.zeros((n, h, w, 8), dtype=t.float16, device=dev), wt=t.zeros((len(prog.wlevels), n), dtype=t.int32, device=dev),
+                idx_maxp=t.empty((n, 1, tt, 2), dtype=t.float32, device=dev), oi=t.zeros((n, tt), dtype=t.int32, device=dev),
+                ol=t.zeros((n,), dtype=t.int32, device=dev), oc=t.zeros((n,), dtype=t.float32, device=dev), graph=None, tt=tt,
+                wsbuf=t.zeros(max(prog.ws_bytes, 256), dtype=t.uint8, device=dev), prog=prog, handle=handle)
+        return self._graphs[key]
+
+    def rec_forward_graph(self, bufs, widths):
+        """rec_forward through a HIP graph captured on first use (on the CURRENT stream, which must not be the default one);
+        -> clones of (class ids, lengths, confidences) (the fixed output buffers are overwritten by the next launch)."""
+        t = self.ctx.torch
+        prog = bufs["prog"]
+        bufs["wt"].copy_(t.from_numpy(prog.width_table(widths)))
+        if bufs["graph"] is None:
+            g = C.c_void_p()
+            n = bufs["x"].shape[0]
+            _check(self.ctx.lib.vse_rec_graph_create(self.ctx.handle, bufs["handle"], C.c_void_p(bufs["wsbuf"].data_ptr()),
+                                                     C.c_void_p(bufs["x"].data_ptr()), C.c_void_p(bufs["wt"].data_ptr()), prog.out_level,
+                                                     C.c_void_p(bufs["idx_maxp"].data_ptr()), n, bufs["tt"], C.c_void_p(bufs["oi"].data_ptr()),
+                                                     C.c_void_p(bufs["ol"].data_ptr()), C.c_void_p(bufs["oc"].data_ptr()), self.ctx.stream(),
+                                                     C.byref(g)), "vse_rec_graph_create")
+            bufs["graph"] = g
+        _check(self.ctx.lib.vse_graph_launch(bufs["graph"], self.ctx.stream()), "vse_graph_launch")
+        return bufs["oi"].clone(), bufs["ol"].clone(), bufs["oc"].clone()
 
     def profile(self, x, slot=0, widths=None):
         """Per-op milliseconds (HIP events) for one run; returns (ms ndarray, program, kernel name per op)."""

@@ -331,10 +331,13 @@ class OcrPipeline:
                         crops.append(crops[-1])           # dummy rows; their results are never read
                         widths.append(widths[-1])
                         srcs.append(srcs[-1])
+                slot = gi % nstreams if nstreams > 1 else 0
+                use_graph = (getattr(self, "rec_graphs", False) and nstreams > 1 and getattr(self, "profile_sink", None) is None)
+                bufs = self.rec.rec_graph_buffers(len(crops), self.rec_h, img_w, slot) if use_graph else None
                 if len(frames_list) == 1:
-                    x = self.ctx.rec_preprocess(frames_list[0], crops, self.rec_h, img_w)
+                    x = self.ctx.rec_preprocess(frames_list[0], crops, self.rec_h, img_w, out=bufs["x"] if bufs else None)
                 else:
-                    x = t.empty((len(crops), self.rec_h, img_w, 8), dtype=t.float16, device=self.ctx.tdev)
+                    x = bufs["x"] if bufs else t.empty((len(crops), self.rec_h, img_w, 8), dtype=t.float16, device=self.ctx.tdev)
                     a = 0
                     while a < len(crops):
                         b = a
@@ -342,8 +345,9 @@ class OcrPipeline:
                             b += 1
                         self.ctx.rec_preprocess(frames_list[srcs[a]], crops[a:b], self.rec_h, img_w, out=x[a:b])
                         a = b
-                slot = gi % nstreams if nstreams > 1 else 0
-                if getattr(self, "profile_sink", None) is None:
+                if bufs is not None:
+                    oi, ol, oc = self.rec.rec_forward_graph(bufs, np.asarray(widths, np.int32))     # the same as ONE HIP graph launch
+                elif getattr(self, "profile_sink", None) is None:
                     oi, ol, oc = self.rec.rec_forward(x, np.asarray(widths, np.int32), slot)      # vse_rec_forward: network + CTC collapse
                 else:
                     idx_maxp = self._run(self.rec, x, slot=slot, widths=np.asarray(widths, np.int32))[-1]          # [B,1,T,2]
