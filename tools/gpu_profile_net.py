@@ -20,6 +20,18 @@ def op_macs(r):
     return m * float(p[ir.P_COUT]) * float(p[ir.P_KTOT])   # padded (executed) MACs
 
 
+def view_bytes(v):
+    return float(v["n"]) * float(v["h"]) * float(v["w"]) * float(v["c"]) * float(v["esize"]) if int(v["n"]) > 0 else 0.0
+
+
+def op_sol_ms(r):
+    """Speed-of-light time of one op: max(executed MACs / 2.5 PFLOP/s dense fp16, bytes of its views once / 8 TB/s)."""
+    byts = sum(view_bytes(r[k]) for k in ("in0", "in1", "in2", "out", "out2"))
+    if int(r["kind"]) == ir.OP_CONV:
+        byts += 2.0 * float(r["p"][ir.P_COUT]) * float(r["p"][ir.P_KTOT])
+    return 1e3 * max(2 * op_macs(r) / 2.5e15, byts / 8e12), byts
+
+
 def main():
     mid = sys.argv[1]
     n, h, w = (int(v) for v in sys.argv[2:5])
@@ -67,7 +79,10 @@ def main():
         bykind[int(r["kind"])][0] += ms[k]
         bykind[int(r["kind"])][1] += 1
     print("by kind:", {k: (round(v[0], 3), v[1]) for k, v in sorted(bykind.items())})
-    order = np.argsort(-ms)[:top]
+    sol = np.array([op_sol_ms(r)[0] for r in prog.ops])
+    print(f"speed of light (per op max(MFMA, HBM), summed): {sol.sum():.3f} ms = {100 * sol.sum() / tot:.1f} % of the measured total; "
+          f"MFMA-bound ops {sol[[2 * op_macs(r) / 2.5e15 * 1e3 >= op_sol_ms(r)[0] for r in prog.ops]].sum():.3f} ms")
+    order = np.argsort(-(ms - sol) if "--by-gap" in sys.argv else -ms)[:top]
     for k in order:
         r = prog.ops[k]
         p = r["p"]
@@ -77,7 +92,7 @@ def main():
         if int(r["kind"]) == ir.OP_CONV:
             extra = (f"k{p[0]}x{p[1]} s{p[2]} cin{p[ir.P_CINP]} N{p[ir.P_COUT]} K{p[ir.P_KTOT]} "
                      f"{2 * macs / ms[k] / 1e9:.0f} TF/s(padded)")
-        print(f"  op{k:3d} kind={int(r['kind']):2d} {ms[k]:8.3f} ms {100 * ms[k] / tot:5.1f}%  out[{o['n']},{o['h']},{o['w']},{o['c']}] "
+        print(f"  op{k:3d} kind={int(r['kind']):2d} {ms[k]:8.3f} ms {100 * ms[k] / tot:5.1f}% sol {sol[k]:6.3f} ({100 * sol[k] / max(ms[k], 1e-9):3.0f}%) out[{o['n']},{o['h']},{o['w']},{o['c']}] "
               f"{prog.names[k][:28]:28s} {names[k]:44s} {extra}")
 
 

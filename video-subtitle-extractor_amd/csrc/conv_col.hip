@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512, 2) void conv_col_kernel(const ConvParams p) {
     constexpr int PATCH_BYTES = PATCH_HALFS * 2, WSTAGE_BYTES = WSTAGE_HALFS * 2;
     constexpr int ROWB = CPW * 32;                       // bytes between patch rows
     static_assert(PPIX % 32 == 0 && WROWS % 32 == 0, "whole wave instructions");
-    static_assert((BN == 64 || BN == 32) && (KH == 9 || KH == 7 || KH == 5), "variants");
+    static_assert(((BN == 64 || BN == 32) && (KH == 9 || KH == 7 || KH == 5)) || (KH == 3 && BN == 128), "variants");
     __shared__ __attribute__((aligned(16))) half_t lds[2 * PATCH_HALFS + CRING * WSTAGE_HALFS + 512 + 4 * BN];   // the ONLY LDS object
     half_t* const patch0 = lds;
     half_t* const ring0 = lds + 2 * PATCH_HALFS;
@@ -268,6 +268,18 @@ int conv_col_bn(int Np) { return Np > 32 ? 64 : 32; }
 bool conv_col_ok(int kh, int kw, int sh, int sw, int cinp, int Np, int flags) {
     return sh == 1 && sw == 1 && (kh == 9 || kh == 7 || kh == 5) && kw >= 3 && CTW + kw - 1 <= CPW && (cinp & 15) == 0 && Np <= 64
            && !(flags & (F_SRC2 | F_PIXSHUF | F_DOT1));
+}
+
+// experiment (VSE_C3_WIDE=1): 3x3 layers with 128 couts on this kernel's one-block-per-CU structure, all couts per block
+int launch_conv_col3w(const ConvParams& pin, int n_img, hipStream_t st) {
+    ConvParams p = pin;
+    p.ntn = 1;
+    p.tiles_h = (p.OH + CTH - 1) / CTH;
+    p.tiles_w = (p.OW + CTW - 1) / CTW;
+    const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w;
+    if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
+    hipLaunchKernelGGL((conv_col_kernel<3, 128>), dim3((unsigned)blocks), dim3(512), 0, st, p);
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }
 
 int launch_conv_col(const ConvParams& pin, int n_img, hipStream_t st) {

@@ -21,6 +21,7 @@ struct ConvParams {
     float act_a, act_b, post_a, post_b;
     int flags, coutp;
     unsigned ntn;       // number of cout tiles
+    unsigned ntiles;    // conv_c3w_kernel: pixel tiles of the launch (the persistent blocks share them out)
     int tiles_h, tiles_w;   // patch kernel: output tile grid per image
     const float* dotw;      // F_DOT1: per-cout weights of the fused 1-channel projection
     float dotb;
@@ -299,9 +300,13 @@ __device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const fl
 int launch_conv_patch(const ConvParams& p, int n_img, hipStream_t st);
 // one filter column per step over a 16-channel patch (conv_col.hip, F_COL): 9x9 / 7x7 / 5x5, <= 64 couts
 int launch_conv_col(const ConvParams& p, int n_img, hipStream_t st);
+int launch_conv_col3w(const ConvParams& p, int n_img, hipStream_t st);
 // 3x3 sibling, two blocks per CU (conv_c3.hip, F_COL with kh = kw = 3)
 int launch_conv_c3(const ConvParams& p, int n_img, hipStream_t st);
 double conv_c3_plan(int OH, int OW, int* rw_out);
+// all couts per block, one persistent block per CU (conv_c3w.hip): the 3x3 layers with 128 couts
+int launch_conv_c3w(const ConvParams& p, int n_img, hipStream_t st);
+bool conv_c3w_ok(const ConvParams& p);
 bool conv_c3_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int flags);
 // pointwise conv over <= 64 input channels and <= 64 couts, no LDS staging (conv_pw.hip, F_PW)
 int launch_conv_pw(const ConvParams& p, hipStream_t st);
