@@ -333,3 +333,38 @@ def test_workspace_budget_evicts_least_recently_used(ctx):
     assert len(small.ws) == 1 and list(small.ws)[0][0] == (2, 48, 96)
     for a, b in zip(base, again):
         assert np.array_equal(a, b)
+
+
+_WIDE_SNIPPET = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, {root!r})
+from vse_amd import engine, modelzoo
+from oracle import ir_emul
+ctx = engine.Context(0)
+for mid, shape in (("V4_ch_det", (3, 3, 160, 288)), ("V4_ch_rec", (5, 3, 48, 320))):
+    desc, w = modelzoo.get_model(mid)
+    net = engine.Net(ctx, desc, w, want_probs=False)
+    x = np.random.default_rng(3).uniform(-1, 1, shape).astype(np.float32)
+    xt = torch.from_numpy(ir_emul.to_nhwc8(x).astype(np.float16)).cuda()
+    h = hashlib.sha256()
+    for o in net.run(xt):
+        h.update(np.ascontiguousarray(o.cpu().numpy()).tobytes())
+    print("DIGEST", mid, h.hexdigest())
+"""
+
+
+def test_wide_3x3_route_gives_identical_bits():
+    """conv_c3w_kernel (the experimental persistent one-block-per-CU 3x3 kernel, VSE_C3_WIDE=1) accumulates in conv_c3_kernel's
+    order: whole-network outputs must be identical bit for bit (the launcher reads the switch once per process, hence two
+    child processes)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for wide in ("0", "1"):
+        env = dict(os.environ, VSE_C3_WIDE=wide)
+        r = subprocess.run([sys.executable, "-c", _WIDE_SNIPPET.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[wide] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")]
+        assert len(out[wide]) == 2
+    assert out["0"] == out["1"]
