@@ -3,7 +3,7 @@
 # -D<MACRO>=0 and =1 (twice, alternating) and runs the per-layer microbench on each.
 #   usage: bash tools/ab.sh <conv_gemm|conv_patch|conv_head> <MACRO> <cfg: d|p> <layers,comma,separated>
 R=$GRAFT_REPO_ROOT; cd $R/video-subtitle-extractor_amd/csrc
-OBJS="build/vse_runtime.hip.o build/conv_mfma.hip.o build/conv_gemm.hip.o build/conv_patch.hip.o build/conv_col.hip.o build/conv_c3.hip.o build/conv_pw.hip.o build/conv_head.hip.o build/conv_stem.hip.o build/simple_ops.hip.o build/lstm.hip.o build/prepost.hip.o"
+OBJS=$(ls build/*.hip.o | tr "\n" " ")
 F=$1; M=$2; C=$3; L=$4
 for V in 0 1 0 1; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -D$M=$V -c $F.hip -o build/$F.hip.o 2>/dev/null
