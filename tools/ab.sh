@@ -5,7 +5,7 @@
 R=$GRAFT_REPO_ROOT; cd $R/video-subtitle-extractor_amd/csrc
 OBJS=$(ls build/*.hip.o | tr "\n" " ")
 F=$1; M=$2; C=$3; L=$4
-for V in 0 1 0 1; do
+for V in ${VALS:-0 1 0 1}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -D$M=$V -c $F.hip -o build/$F.hip.o 2>/dev/null
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libvse_hip.so $OBJS
   export $M=$V       # (switches mirrored by the graph compiler read the same name from the environment)
