@@ -16,6 +16,9 @@
 #include "conv_common.h"
 #include "resize_u8.h"
 
+#ifndef VSE_STEM_WIDE
+#define VSE_STEM_WIDE 1
+#endif
 #define ST_ROWS 8
 #define ST_COLS 32
 
@@ -75,11 +78,25 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
                 const int x1 = min(cx.s0 + 1, p.u8_w - 1), y1 = min(cy.s0 + 1, p.u8_h - 1);
                 const uint8_t* r0 = fb + (long)cy.s0 * p.u8_pitch;
                 const uint8_t* r1 = fb + (long)y1 * p.u8_pitch;
+                if (VSE_STEM_WIDE && !same && cx.s0 + 3 < p.u8_w) {
+                    // both source pixels of a row = 6 consecutive bytes: ONE (unaligned) 8-byte load per row instead of six byte
+                    // loads — the kernel was bound by the number of its vector-memory instructions, not by their bytes
+                    unsigned long long q0, q1;
+                    __builtin_memcpy(&q0, r0 + cx.s0 * 3, 8);
+                    __builtin_memcpy(&q1, r1 + cx.s0 * 3, 8);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int u = same ? (int)r0[cx.s0 * 3 + c]
-                                       : cv_bilinear_u8(r0[cx.s0 * 3 + c], r0[x1 * 3 + c], r1[cx.s0 * 3 + c], r1[x1 * 3 + c], cx, cy);
-                    v[c] = (half_t)(float)u;
+                    for (int c = 0; c < 3; ++c) {
+                        const int u = cv_bilinear_u8((int)((q0 >> (8 * c)) & 255), (int)((q0 >> (8 * c + 24)) & 255), (int)((q1 >> (8 * c)) & 255),
+                                                     (int)((q1 >> (8 * c + 24)) & 255), cx, cy);
+                        v[c] = (half_t)(float)u;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int u = same ? (int)r0[cx.s0 * 3 + c]
+                                           : cv_bilinear_u8(r0[cx.s0 * 3 + c], r0[x1 * 3 + c], r1[cx.s0 * 3 + c], r1[x1 * 3 + c], cx, cy);
+                        v[c] = (half_t)(float)u;
+                    }
                 }
                 v[3] = (half_t)1.f;
             }
