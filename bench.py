@@ -424,13 +424,18 @@ def roofline(pipe, step, repeats=2, steps_per_call=1):
     nsteps = repeats * steps_per_call
     from vse_amd import ir
     agg = {}
+    det_conv = [0.0, 0.0]           # the detector's conv ops alone (north_star quotes its MFMA target on "detection convs")
     for _ in range(repeats):
         pipe.profile_sink = []
         step()
         for ms, prog, variants in pipe.profile_sink:
+            is_det = bool(prog.outputs) and prog.outputs[0]["kind"] == "map"
             for k, r in enumerate(prog.ops):
                 if int(r["kind"]) != ir.OP_CONV:
                     continue
+                if is_det:
+                    det_conv[0] += float(ms[k])
+                    det_conv[1] += float(prog.op_gmacs[k])
                 a = agg.setdefault(variants[k], [0.0, 0.0, 0])
                 a[0] += float(ms[k])
                 a[1] += float(prog.op_gmacs[k])
@@ -471,6 +476,8 @@ def roofline(pipe, step, repeats=2, steps_per_call=1):
             "algorithmic_gflop_per_launch": round(2 * gmac / cnt, 2),
             "share_of_conv_time": round(tms / all_ms, 3),
             "all_conv_tflops": round(2.0 * sum(v[1] for v in agg.values()) / all_ms, 2),
+            "detector_convs": {"tflops": round(2.0 * det_conv[1] / det_conv[0], 1), "frac": round(2.0 * det_conv[1] / det_conv[0] / MFMA_PEAK_TFLOPS, 4),
+                               "ms_per_step": round(det_conv[0] / nsteps, 3)} if det_conv[0] > 0 else None,
             "conv_ms_per_step": round(all_ms / nsteps, 3),
             # the other conv kernel instantiations by share of conv time (same definition of `achieved` for each)
             "kernels": [{"kernel": v, "share": round(t / all_ms, 3), "launches_per_step": round(c / nsteps, 1),
