@@ -368,3 +368,14 @@ def test_wide_3x3_route_gives_identical_bits():
         out[wide] = [ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")]
         assert len(out[wide]) == 2
     assert out["0"] == out["1"]
+
+
+def test_detector_head_forms_are_identical_and_race_free():
+    """The server detector's last conv has two kernels — the streaming one and the persistent resident-weight one (the default):
+    same bits on five shapes, and the same bits every time beside unrelated work on another stream (tools/race_screen_det.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "race_screen_det.py"), "10"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "clean, both forms identical" in r.stdout

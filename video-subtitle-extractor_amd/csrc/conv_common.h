@@ -288,8 +288,10 @@ __device__ __forceinline__ float conv_epilogue_dot(const ConvParams& p, const fl
 #pragma unroll
     for (int e = 0; e < 16; ++e) v[e] = acc[e] + bias[e];
     vse_act_n(v, p.act, p.act_a, p.act_b);
+    if (!VSE_EPI_SKIP || p.post_a != 1.f || p.post_b != 0.f) {        // as conv_epilogue_tile: the affine is the identity almost everywhere
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = v[e] * p.post_a + p.post_b;
+        for (int e = 0; e < 16; ++e) v[e] = v[e] * p.post_a + p.post_b;
+    }
     vse_act_n(v, p.act2, 0.f, 0.f);
     float part = 0.f;
 #pragma unroll

@@ -22,6 +22,7 @@
 //             parity (columns 2j, 2j+1)
 // weights stream (compiler.py head_up2_weights): [chunk][parity a*2+b][tap r*2+s][64][32] fp16, then [64][32] for u
 // (k = 3*dy + dx < 9, rest zero).
+#include <stdlib.h>
 #include <type_traits>
 #include "conv_common.h"
 
@@ -238,6 +239,262 @@ __global__ __launch_bounds__(512) void conv_head_up2_kernel(const ConvParams p) 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Resident-weight form (end of round 3).  conv_head_up2_kernel streams 128 KiB of folded weights + 48 KiB of patch through
+// LDS-DMA per 256-pixel tile — 5.7 GB per 64 frames at the ~3 TB/s such streams reach on this chip = the kernel's 1.9 ms;
+// its matrix pipe is busy a quarter of the time.  Here a PERSISTENT block (one per CU) owns ONE output row parity a: the
+// 64 KiB of weights of parities (a, 0), (a, 1) are loaded ONCE per block and stay in LDS; the block walks 16 x 32 low-res
+// tiles, and the only stream left is the halo patch (2 x 39 KiB per tile, the next tile's chunks prefetched behind the
+// current tile's compute): 2.25x fewer staged bytes per output, three barriers per tile instead of eight, 14 fragment reads
+// per 16 MFMAs instead of 20.
+//   wave   = 4 low-res rows (wave >> 1) x 32 couts (wave & 1) x 2 column parities: acc[2][4] (128 VGPRs)
+//   LDS    = weights 64 KiB + two patch chunks 80 KiB + u weights 4 KiB + u tile 4.5 KiB + dot exchange 4 KiB + constants
+//   order  = per parity: chunk 0 (ks, r, s), chunk 1, u slice — conv_head_up2_kernel's, so the bits are identical
+//   stream = chunk 0 of tile t+1 is issued during chunk 1 of tile t (SIMD partners at different points), chunk 1 of t+1
+//            behind the barrier that ends tile t's reads; counted waits: vmcnt(5) (chunk 0 landed, chunk 1 may fly) at the
+//            end of a tile, vmcnt(0) in front of chunk 1.  The u tile's plain loads are issued in front of the chunk-0 DMAs
+//            and consumed behind that barrier, so the compiler's own wait for them drains nothing that is not needed anyway.
+#define RT_ROWS 16
+#define RPH (RT_ROWS + 2)
+#define RHP (HPW * RPH)              // 612 patch pixels
+#define RPJ 5                        // patch DMA instructions per wave and chunk (40 x 16 pixels)
+#define RUTH (2 * RT_ROWS + 2)       // u tile rows
+#define RUPT 5                       // u values per thread (34 x 66 <= 5 x 512)
+
+__global__ __launch_bounds__(512, 2) void conv_head_up2r_kernel(const ConvParams p) {
+    constexpr int WST = 4 * 64 * 32;                         // halfs per (chunk, parity) weight stage: 4 taps x 64 couts x 32 ch
+    constexpr int PCH = 8 * RPJ * 16 * 32;                   // halfs per patch chunk buffer (40 KiB)
+    __shared__ __attribute__((aligned(16))) half_t lds[4 * WST + 2 * PCH + 64 * 32 + RUTH * UTW + 2 * 1024 + 2 * 128];
+    half_t* const wres = lds;                                // [chunk][b] stages
+    half_t* const patch0 = lds + 4 * WST;
+    half_t* const uw0 = patch0 + 2 * PCH;
+    half_t* const ut0 = uw0 + 64 * 32;
+    float* const part0 = reinterpret_cast<float*>(ut0 + RUTH * UTW);     // [4 wrow][2 b][4 rows][32 px]: the upper cout half's dots
+    float* const sbias = part0 + 1024;
+    float* const sdotw = sbias + 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = wave >> 1, wco = wave & 1;
+    const int fx = lane & 31, fj = lane >> 5;
+    const int Hl = p.in2_hs, Wl = p.in2_ws;
+
+    // ---- this block's work: row parity a, tiles x0 + slot, x0 + slot + na, ... of its XCD's contiguous tile range ----------
+    const unsigned G = gridDim.x, bid = blockIdx.x, xcd = bid & 7, bslot = bid >> 3;
+    const int a = (int)(bslot & 1);
+    const unsigned T = p.ntiles, q8 = T >> 3, r8 = T & 7;
+    const unsigned x0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const unsigned tend = x0 + q8 + (xcd < r8 ? 1u : 0u);
+    const unsigned na = (G >> 3) >> 1;                       // blocks per XCD and parity (the launcher makes G a multiple of 16)
+    unsigned t = x0 + (bslot >> 1);
+    if (t >= tend) return;
+    int oy0, ox0;
+    long img;
+    auto decode = [&](unsigned tt) {
+        const unsigned tx = tt % (unsigned)p.tiles_w, r = tt / (unsigned)p.tiles_w;
+        ox0 = (int)tx * HT_COLS;
+        oy0 = (int)(r % (unsigned)p.tiles_h) * RT_ROWS;
+        img = (long)(r / (unsigned)p.tiles_h);
+    };
+    decode(t);
+
+    const int kv = (lane & 3) ^ ((lane >> 4) & 3);           // logical k-vector this lane fetches (source-side swizzle)
+    auto issue_patch = [&](int c, bool live) __attribute__((always_inline)) {
+        half_t* dstb = patch0 + c * PCH;
+#pragma unroll
+        for (int j = 0; j < RPJ; ++j) {
+            const int q = 16 * (wave + 8 * j) + (lane >> 2);
+            const int py = q / HPW, px = q - py * HPW;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            const bool ok = live && (q < RHP) && (iy >= 0) && (iy < Hl) && (ix >= 0) && (ix < Wl);
+            const half_t* src = ok ? p.in2 + ((img * Hl + iy) * Wl + ix) * (long)p.in2_ld + c * 32 + kv * 8 : p.zero;
+            glds16_asm(src, dstb + (wave + 8 * j) * 16 * 32);
+        }
+    };
+    half_t uval[RUPT];
+    unsigned uok = 0;                                        // bit k: uval[k] lies inside the map
+    auto load_u = [&]() __attribute__((always_inline)) {
+        const half_t* ub = p.in + img * (long)(2 * Hl) * (2 * Wl) * p.in_ld;
+#pragma unroll
+        for (int k = 0; k < RUPT; ++k) {
+            const int idx = tid + 512 * k;
+            const int uy = idx / 66, ux = idx - uy * 66;
+            const int fy = 2 * oy0 - 1 + uy, fx2 = 2 * ox0 - 1 + ux;
+            // unconditional loads from clamped addresses, zero selected afterwards: a load under a condition makes hipcc branch around
+            // it and wait vmcnt(0) per element — five dependent round trips, each draining the DMA queue
+            const bool ok = idx < RUTH * 66 && fy >= 0 && fy < 2 * Hl && fx2 >= 0 && fx2 < 2 * Wl;
+            const int cy = min(max(fy, 0), 2 * Hl - 1), cx = min(max(fx2, 0), 2 * Wl - 1);
+            uval[k] = ub[((long)cy * (2 * Wl) + cx) * p.in_ld];      // raw: the select waits for the load, so it happens in store_u
+            uok = ok ? (uok | (1u << k)) : (uok & ~(1u << k));
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto store_u = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < RUPT; ++k) {
+            const int idx = tid + 512 * k;
+            const int uy = idx / 66, ux = idx - uy * 66;
+            if (idx < RUTH * 66) ut0[uy * UTW + ux] = ((uok >> k) & 1u) ? uval[k] : (half_t)0.f;
+        }
+    };
+
+    // ---- prologue: constants, the block's 64 KiB of weights, the first tile ----------------------------------------------
+    load_u();
+    conv_stage_consts<true>(sbias, p.bias, p.zero, 0, 64, p.Np, wave, lane);            // wave 0
+    conv_stage_consts<true>(sdotw, p.dotw, p.zero, 0, 64, p.Np, wave - 4, lane);        // wave 4
+    {
+        const half_t* wl = p.w + ((long)(wave >> 2) * 64 + ((tid >> 2) & 63)) * 32 + kv * 8;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {                      // st = chunk * 2 + b  <-  stream stage chunk * 4 + a * 2 + b
+            const half_t* src = wl + (long)((st >> 1) * 4 + a * 2 + (st & 1)) * WST;
+            half_t* dst = wres + st * WST;
+            glds16_asm(src, dst + (wave >> 2) * 64 * 32 + (wave & 3) * 16 * 32);
+            glds16_asm(src + 2 * 64 * 32, dst + (2 + (wave >> 2)) * 64 * 32 + (wave & 3) * 16 * 32);
+        }
+        const half_t* const wu = p.w + 8L * WST;
+        if (wave < 4) glds16_asm(wu + (wave * 16 + (lane >> 2)) * 32 + kv * 8, uw0 + wave * 16 * 32);
+    }
+    issue_patch(0, true);
+    issue_patch(1, true);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_u();
+    __syncthreads();
+
+    const int wr = wco * 32 + conv_wrow(fx);                 // weight row (cout) this lane supplies
+    const unsigned woffb = (unsigned)(wr * 64 + ((fj ^ ((wr >> 2) & 3)) << 4));
+    const char* const wres_b = reinterpret_cast<const char*>(wres);
+    const half8 wfu = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(uw0) + woffb);   // k 0..15 of row wr
+    const bool early = wave < 4;                             // SIMD partners (w, w + 4) issue the next tile's stream at different points
+
+    for (;;) {
+        float16v acc[2][4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][i][r] = 0.f;
+        // one (chunk, column parity): 32 MFMAs, 28 fragment reads
+        auto compute = [&](int c, auto b_c) __attribute__((always_inline)) {
+            constexpr int B = decltype(b_c)::value;
+            const char* const pb = reinterpret_cast<const char*>(patch0 + c * PCH);
+            const unsigned wsb = (unsigned)(c * 2 + B) * (WST * 2);
+            unsigned q0 = (unsigned)((4 * wrow + a) * HPW + fx + B);      // recomputed per call: hoisted out of the tile loop, the 80 fragment
+            asm volatile("" : "+v"(q0));                                 // addresses of a tile would live (spilled) across everything
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                half8 xf[5][2];
+#pragma unroll
+                for (int rr = 0; rr < 5; ++rr)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const unsigned q = q0 + (unsigned)(rr * HPW + s2);
+                        xf[rr][s2] = *reinterpret_cast<const half8*>(pb + ((q << 6) + (((2 * ks + fj) ^ ((q >> 2) & 3)) << 4)));
+                    }
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const half8 wf = *reinterpret_cast<const half8*>(wres_b + wsb + (r * 2 + s2) * (64 * 64) + (woffb ^ (ks << 5)));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            acc[B][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xf[i + r][s2], acc[B][i], 0, 0, 0);
+                    }
+            }
+        };
+        compute(0, std::integral_constant<int, 0>{});
+        compute(0, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own part of chunk 1 landed (and the previous tile's stores)
+        __builtin_amdgcn_s_barrier();                       // chunk 1 visible; nobody reads chunk 0 any more
+        asm volatile("" ::: "memory");
+
+        // the next tile: its geometry replaces this tile's behind the epilogue
+        const int c_oy0 = oy0, c_ox0 = ox0;
+        const long c_img = img;
+        const unsigned tn = t + na;
+        const bool have_next = tn < tend;
+        if (have_next) decode(tn);
+        if (early && have_next) { load_u(); issue_patch(0, true); }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if (!early && have_next) { load_u(); issue_patch(0, true); }
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, std::integral_constant<int, 1>{});
+
+        // ---- the 1-channel full-resolution source: one K = 16 slice per column parity and row ----------------------------
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int ub0 = (2 * (4 * wrow + i) + a) * UTW + 2 * fx + b;          // u-tile index of tap (0, 0)
+                asm volatile("" : "+v"(ub0));
+                half8 xu = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (fj == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xu[e] = ut0[ub0 + (e / 3) * UTW + e % 3];
+                } else {
+                    xu[0] = ut0[ub0 + 2 * UTW + 2];                                // k = 8: tap (2, 2)
+                }
+                acc[b][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfu, xu, acc[b][i], 0, 0, 0);
+            }
+
+        // ---- epilogue: dots over this wave's 32 couts; the upper cout half hands its dots to the lower one ----------------
+        float part[2][4];
+        float dbias[16], dw[16];                            // read back per tile: held across the K loop they cost 32 VGPRs (spills)
+        conv_epilogue_consts(sbias, wco * 32, lane, dbias);
+        conv_epilogue_consts(sdotw, wco * 32, lane, dw);
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = conv_epilogue_dot(p, acc[b][i], dbias, dw);
+                v += __shfl_xor(v, 32);
+                part[b][i] = v;
+                if (wco == 1 && fj == 0) part0[((wrow * 2 + b) * 4 + i) * 32 + fx] = v;
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();                                    // dots visible; chunk 1 and the u tile are free
+        if (have_next) {
+            store_u();
+            issue_patch(1, true);
+        }
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // own part of the next tile's chunk 0 landed; its chunk 1 (the 5 youngest) may fly
+        if (wco == 0) {
+            // lanes 0-31: rows 0, 1 of the wave's four, lanes 32-63: rows 2, 3; both column parities of a pixel -> one 8-byte store
+            // (no array indexed by fj: hipcc moves such an array to scratch memory, and scratch traffic sits in the vmcnt queue)
+            const float own[2][2] = {{fj == 0 ? part[0][0] : part[0][2], fj == 0 ? part[0][1] : part[0][3]},
+                                     {fj == 0 ? part[1][0] : part[1][2], fj == 0 ? part[1][1] : part[1][3]}};
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * fj + ii;
+                const int oy = c_oy0 + 4 * wrow + i, ox = c_ox0 + fx;
+                if (oy < Hl && ox < Wl) {
+                    float z[2];
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        z[b] = vse_act(own[b][ii] + part0[((wrow * 2 + b) * 4 + i) * 32 + fx] + p.dotb, p.dotact, 0.f, 0.f);
+                    const long m = ((c_img * (2 * Hl) + 2 * oy + a) * (long)(2 * Wl) + 2 * ox) * p.dot_ld;
+                    if (p.dot_f32) {
+                        float* o = reinterpret_cast<float*>(p.dot_out) + m;
+                        if (p.dot_ld == 1) *reinterpret_cast<float2*>(o) = make_float2(z[0], z[1]);
+                        else { o[0] = z[0]; o[p.dot_ld] = z[1]; }
+                    } else {
+                        half_t* o = reinterpret_cast<half_t*>(p.dot_out) + m;
+                        o[0] = (half_t)z[0]; o[p.dot_ld] = (half_t)z[1];
+                    }
+                }
+            }
+        }
+        if (!have_next) break;
+        t = tn;
+        __syncthreads();                                    // the next tile's chunk 0 and u tile visible; the dot exchange is free
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 int launch_conv_head_up2(const ConvParams& pin, int n_img, hipStream_t st) {
     ConvParams p = pin;
     // u = in0: [n, 2Hl, 2Wl, 8-channel padded, 1 real]; x = in2: [n, Hl, Wl, 64], upsampled by 2
@@ -250,6 +507,25 @@ int launch_conv_head_up2(const ConvParams& pin, int n_img, hipStream_t st) {
     p.tiles_w = (p.in2_ws + HT_COLS - 1) / HT_COLS;
     const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w;
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
+    static const int resident = [] { const char* e = getenv("VSE_HEAD_RESIDENT"); return e && e[0] ? atoi(e) : 1; }();
+    if (resident) {
+        // resident-weight form: 16 x 32 tiles, persistent blocks, grid a multiple of 16 (8 XCDs x 2 row parities)
+        p.tiles_h = (p.in2_hs + RT_ROWS - 1) / RT_ROWS;
+        const unsigned long long tiles = (unsigned long long)n_img * p.tiles_h * p.tiles_w;
+        if (tiles == 0 || tiles > 0x7fffffffull) return VSE_E_INVAL;
+        p.ntiles = (unsigned)tiles;
+        static const int cus = [] {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+            return prop.multiProcessorCount;
+        }();
+        unsigned long long want = 2 * ((tiles + 7) / 8) * 8;                 // two blocks (row parities) per tile slot, whole XCD rounds
+        if (want > (unsigned long long)cus) want = (unsigned long long)cus;
+        const unsigned grid = (unsigned)(want < 16 ? 16 : want / 16 * 16);
+        hipLaunchKernelGGL(conv_head_up2r_kernel, dim3(grid), dim3(512), 0, st, p);
+        return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+    }
     hipLaunchKernelGGL(conv_head_up2_kernel, dim3((unsigned)blocks), dim3(512), 0, st, p);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }
