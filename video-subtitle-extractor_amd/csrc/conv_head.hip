@@ -254,6 +254,15 @@ __global__ __launch_bounds__(512) void conv_head_up2_kernel(const ConvParams p) 
 //            behind the barrier that ends tile t's reads; counted waits: vmcnt(5) (chunk 0 landed, chunk 1 may fly) at the
 //            end of a tile, vmcnt(0) in front of chunk 1.  The u tile's plain loads are issued in front of the chunk-0 DMAs
 //            and consumed behind that barrier, so the compiler's own wait for them drains nothing that is not needed anyway.
+#ifdef VSE_TRACE
+#include <stdio.h>
+#include <vector>
+#define HTR(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define HACC(acc_, a_, b_) acc_ += (b_) - (a_)
+#else
+#define HTR(v) do { } while (0)
+#define HACC(acc_, a_, b_) do { } while (0)
+#endif
 #define RT_ROWS 16
 #define RPH (RT_ROWS + 2)
 #define RHP (HPW * RPH)              // 612 patch pixels
@@ -367,7 +376,12 @@ __global__ __launch_bounds__(512, 2) void conv_head_up2r_kernel(const ConvParams
     const half8 wfu = *reinterpret_cast<const half8*>(reinterpret_cast<const char*>(uw0) + woffb);   // k 0..15 of row wr
     const bool early = wave < 4;                             // SIMD partners (w, w + 4) issue the next tile's stream at different points
 
+#ifdef VSE_TRACE
+    unsigned long long tr_c0 = 0, tr_b1 = 0, tr_c1 = 0, tr_u = 0, tr_dot = 0, tr_b2 = 0, tr_tail = 0, tr_b3 = 0, tr_n = 0;
+    const unsigned long long tr_begin = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        HTR(t0);
         float16v acc[2][4];
 #pragma unroll
         for (int b = 0; b < 2; ++b)
@@ -406,9 +420,11 @@ __global__ __launch_bounds__(512, 2) void conv_head_up2r_kernel(const ConvParams
         compute(0, std::integral_constant<int, 0>{});
         compute(0, std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
+        HTR(t1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own part of chunk 1 landed (and the previous tile's stores)
         __builtin_amdgcn_s_barrier();                       // chunk 1 visible; nobody reads chunk 0 any more
         asm volatile("" ::: "memory");
+        HTR(t2);
 
         // the next tile: its geometry replaces this tile's behind the epilogue
         const int c_oy0 = oy0, c_ox0 = ox0;
@@ -423,6 +439,8 @@ __global__ __launch_bounds__(512, 2) void conv_head_up2r_kernel(const ConvParams
         if (!early && have_next) { load_u(); issue_patch(0, true); }
         __builtin_amdgcn_sched_barrier(0);
         compute(1, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        HTR(t3);
 
         // ---- the 1-channel full-resolution source: one K = 16 slice per column parity and row ----------------------------
 #pragma unroll
@@ -441,6 +459,8 @@ __global__ __launch_bounds__(512, 2) void conv_head_up2r_kernel(const ConvParams
                 acc[b][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfu, xu, acc[b][i], 0, 0, 0);
             }
 
+        __builtin_amdgcn_sched_barrier(0);
+        HTR(t4);
         // ---- epilogue: dots over this wave's 32 couts; the upper cout half hands its dots to the lower one ----------------
         float part[2][4];
         float dbias[16], dw[16];                            // read back per tile: held across the K loop they cost 32 VGPRs (spills)
@@ -456,7 +476,9 @@ __global__ __launch_bounds__(512, 2) void conv_head_up2r_kernel(const ConvParams
                 if (wco == 1 && fj == 0) part0[((wrow * 2 + b) * 4 + i) * 32 + fx] = v;
             }
         __builtin_amdgcn_sched_barrier(0);
+        HTR(t5);
         __syncthreads();                                    // dots visible; chunk 1 and the u tile are free
+        HTR(t6);
         if (have_next) {
             store_u();
             issue_patch(1, true);
@@ -488,11 +510,24 @@ __global__ __launch_bounds__(512, 2) void conv_head_up2r_kernel(const ConvParams
                 }
             }
         }
+        HTR(t7);
+        HACC(tr_c0, t0, t1); HACC(tr_b1, t1, t2); HACC(tr_c1, t2, t3); HACC(tr_u, t3, t4); HACC(tr_dot, t4, t5); HACC(tr_b2, t5, t6); HACC(tr_tail, t6, t7);
+#ifdef VSE_TRACE
+        ++tr_n;
+#endif
         if (!have_next) break;
         t = tn;
         __syncthreads();                                    // the next tile's chunk 0 and u tile visible; the dot exchange is free
+        HTR(t8);
+        HACC(tr_b3, t7, t8);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef VSE_TRACE
+    if (lane == 0 && p.trace && (wave == 0 || wave == 4)) {
+        unsigned long long* o = p.trace + ((unsigned long long)blockIdx.x * 2 + (wave >> 2)) * 10;
+        o[0] = __builtin_amdgcn_s_memtime() - tr_begin; o[1] = tr_c0; o[2] = tr_b1; o[3] = tr_c1; o[4] = tr_u; o[5] = tr_dot; o[6] = tr_b2; o[7] = tr_tail; o[8] = tr_b3; o[9] = tr_n;
+    }
+#endif
 }
 
 int launch_conv_head_up2(const ConvParams& pin, int n_img, hipStream_t st) {
@@ -523,7 +558,33 @@ int launch_conv_head_up2(const ConvParams& pin, int n_img, hipStream_t st) {
         unsigned long long want = 2 * ((tiles + 7) / 8) * 8;                 // two blocks (row parities) per tile slot, whole XCD rounds
         if (want > (unsigned long long)cus) want = (unsigned long long)cus;
         const unsigned grid = (unsigned)(want < 16 ? 16 : want / 16 * 16);
+#ifdef VSE_TRACE
+        static unsigned long long* trace_dev = nullptr;
+        if (!trace_dev) (void)hipMalloc(&trace_dev, 256 * 20 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(trace_dev, 0, 256 * 20 * sizeof(unsigned long long), st);
+        p.trace = grid <= 256 ? trace_dev : nullptr;
+#endif
         hipLaunchKernelGGL(conv_head_up2r_kernel, dim3(grid), dim3(512), 0, st, p);
+#ifdef VSE_TRACE
+        if (p.trace) {
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> h((size_t)grid * 20);
+            (void)hipMemcpy(h.data(), trace_dev, h.size() * 8, hipMemcpyDeviceToHost);
+            for (int g = 0; g < 2; ++g) {
+                double d[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                size_t nb = 0;
+                for (size_t b = 0; b < grid; ++b) {
+                    const unsigned long long* t = &h[(b * 2 + g) * 10];
+                    if (!t[9]) continue;
+                    for (int i = 0; i < 10; ++i) d[i] += (double)t[i];
+                    ++nb;
+                }
+                if (nb) fprintf(stderr, "[head trace] grid %u wave %d: per block total %.0f ticks over %.1f tiles; per tile: chunk 0 %.0f, wait+barrier %.0f, chunk 1 (+ next chunk 0 issue) %.0f, "
+                                "u slice %.0f, dots %.0f, barrier %.0f, u store + chunk 1 issue + wait + stores %.0f, barrier %.0f\n", grid, 4 * g, d[0] / nb, d[9] / nb, d[1] / d[9],
+                                d[2] / d[9], d[3] / d[9], d[4] / d[9], d[5] / d[9], d[6] / d[9], d[7] / d[9], d[8] / d[9]);
+            }
+        }
+#endif
         return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
     }
     hipLaunchKernelGGL(conv_head_up2_kernel, dim3((unsigned)blocks), dim3(512), 0, st, p);

@@ -411,7 +411,11 @@ const char* vse_plan_op_kernel_name(vse_plan* p, int i) {
     else if (code >= 700000) snprintf(buf, sizeof buf, "conv_c3_kernel<%d, %d>", code - 700000, 8 / (code - 700000));
     else if (code >= 600000) snprintf(buf, sizeof buf, "conv_col_kernel<%d, %d>", (code - 600000) / 100, code % 100);
     else if (code >= 500000) snprintf(buf, sizeof buf, "conv_stem_kernel");
-    else if (code >= 400000) snprintf(buf, sizeof buf, "conv_head_up2_kernel");
+    else if (code >= 400000) {
+        // (the launcher's switch, conv_head.hip: the persistent resident-weight form unless VSE_HEAD_RESIDENT=0)
+        static const bool resident = [] { const char* e = getenv("VSE_HEAD_RESIDENT"); return !(e && e[0] == '0'); }();
+        snprintf(buf, sizeof buf, resident ? "conv_head_up2r_kernel" : "conv_head_up2_kernel");
+    }
     else if (o.flags & F_PATCH) snprintf(buf, sizeof buf, "conv_patch_kernel<%d, %d, %d>", (code / 1000) % 100, code % 1000, code / 100000);
     else if (code >= 200000) {
         static const char* cfg[] = {"128, 128, 2, 2, 32, 3", "256, 64, 4, 1, 32, 3", "256, 32, 4, 1, 32, 3", "", "", "", "256, 128, 4, 2, 32, 3",
