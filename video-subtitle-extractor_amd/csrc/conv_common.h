@@ -321,7 +321,11 @@ int launch_conv_head_up2(const ConvParams& p, int n_img, hipStream_t st);
 int launch_conv_stem(const ConvParams& p, int n_img, hipStream_t st);
 // scalar-addressed implicit GEMM (conv_gemm.hip): VSE_E_UNSUPPORTED when the layer is not eligible
 int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st);
-int conv_gemm_config(int Np, int cinp, long M);   // index into the tile-configuration table of conv_gemm.hip
+int conv_gemm_config(int Np, int cinp, long M);
+// 1x1 conv over <= 256 pixels, operands straight from global memory (conv_smallm.hip); `mode` = conv_gemm_mode()
+bool conv_smallm_ok(const ConvParams& p, int mode);
+bool conv_smallm_shape_ok(int mode, long M, int sh, int sw, int same_hw, int flags, int cinp);
+int launch_conv_smallm(const ConvParams& p, hipStream_t st);   // index into the tile-configuration table of conv_gemm.hip
 int conv_gemm_mode(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int Kp, int inshift, int flags);
 int conv_patch_th(int kh, int kw, int OH, int bn);
 int conv_patch_bn(int Np);

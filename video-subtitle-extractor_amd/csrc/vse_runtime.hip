@@ -388,6 +388,8 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if (mode) {
         long m = (long)o.out.n * o.out.h * o.out.w;
         if (o.flags & F_PIXSHUF) m /= 4;
+        if (conv_smallm_shape_ok(mode, m, o.p[P_SH], o.p[P_SW], o.in0.h == o.out.h && o.in0.w == o.out.w, o.flags, o.p[P_CINP]))
+            return 900000 + ((o.flags & F_WK32) ? 32 : 64);            // conv_smallm_kernel<KT>
         return 200000 + 10 * conv_gemm_config(o.p[P_COUT], o.p[P_CINP], m) + (mode == 1 ? 1 : 0);
     }
     return (o.p[P_INSHIFT] ? 10000 : 0) + conv_tile_bn(o.p[P_COUT]);
@@ -406,7 +408,8 @@ const char* vse_plan_op_kernel_name(vse_plan* p, int i) {
         return buf;
     }
     const int code = vse_plan_op_variant(p, i);
-    if (code >= 800000) snprintf(buf, sizeof buf, "conv_pw_kernel<%d>", code - 800000);
+    if (code >= 900000) snprintf(buf, sizeof buf, "conv_smallm_kernel<%d>", code - 900000);
+    else if (code >= 800000) snprintf(buf, sizeof buf, "conv_pw_kernel<%d>", code - 800000);
     else if (code >= 750000) snprintf(buf, sizeof buf, "conv_c3n32_kernel<%d, %d>", code - 750000, 8 / (code - 750000));
     else if (code >= 700000) snprintf(buf, sizeof buf, "conv_c3_kernel<%d, %d>", code - 700000, 8 / (code - 700000));
     else if (code >= 600000) snprintf(buf, sizeof buf, "conv_col_kernel<%d, %d>", (code - 600000) / 100, code % 100);
