@@ -16,6 +16,8 @@ LAYERS = {  # name: cin, cout, k, stride, pad, h, w, n
     "det_1x1_1216_512": (1216, 512, (1, 1), (1, 1), (0, 0), 68, 120, 64),
     "det_1x1_256_256": (256, 256, (1, 1), (1, 1), (0, 0), 136, 240, 64),
     "det_1x1_1920_768": (1920, 768, (1, 1), (1, 1), (0, 0), 34, 60, 64),
+    "det_1x1_512_256": (512, 256, (1, 1), (1, 1), (0, 0), 68, 120, 64),
+    "det_1x1_768_256": (768, 256, (1, 1), (1, 1), (0, 0), 34, 60, 64),
     "det_3x3_64_128": (64, 128, (3, 3), (1, 1), (1, 1), 272, 480, 64),
     "det_3x3_64_64": (64, 64, (3, 3), (1, 1), (1, 1), 272, 480, 64),
     "det_1x1_64_256": (64, 256, (1, 1), (1, 1), (0, 0), 272, 480, 64),
