@@ -163,7 +163,13 @@ def cpu_baseline(args, frames, truth, det, rec, charset, overlay=None):
 
 def main():
     args = parse()
+    # one process per GPU: cap this rank's host thread pools at cores / world BEFORE torch / OpenMP start them (8 ranks x all
+    # cores otherwise); the host side of a step (DB geometry, grouping, decode) is single-threaded Python + numpy anyway
+    from vse_amd import parallel as _parallel
+    host_threads = _parallel.cap_host_threads()
     import torch
+    if host_threads:
+        torch.set_num_threads(host_threads)
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -367,6 +373,7 @@ def main():
                        "frames_per_gpu_step": args.batch, "det_model": det_id, "rec_model": rec_id,
                        "weights": "real" if modelzoo.has_real_weights(det_id) else "seeded random (reference blobs missing)",
                        "gather": "one variable-length gather of all ranks' records to rank 0 at the end of the timed region",
+                       "host_threads_per_rank": host_threads if host_threads else "uncapped (1 rank)",
                        "records_gathered": len(out) if out is not None else 0},
         }
         if not args.no_roofline:

@@ -151,7 +151,8 @@ int vse_det_preprocess(vse_ctx* ctx, const void* d_bgr, int n, int src_h, int sr
 /* ---- DB post-processing (device part) ----------------------------------------------------------------- */
 /* prob map fp32 [n,h,w] -> connected components (8-connectivity) of (prob > thresh) with, per component,
  * pixel count, bounding box and per-row x-extents (the rows' extreme pixels are a superset of the convex
- * hull vertices).  Host finishing (hull, min-area rect, score, unclip) is vse_db_boxes().
+ * hull vertices).  Host finishing (hull, min-area rect, score, unclip: csrc/db_geometry.h) happens inside
+ * vse_db_postprocess() below.
  * Replaces cv2.findContours / minAreaRect / fillPoly+mean inside paddleocr DBPostProcess (App. C.2). */
 typedef struct vse_db_params {
     double box_thresh;     /* 0.6: compared with the box score as Python floats (doubles) in the reference */

@@ -55,3 +55,100 @@ def test_gather_world2_gloo():
     assert [g[0] for g in got] == list(range(11))
     for f, boxes, texts in got:
         assert len(boxes) == f % 3 and texts == [(f"t{f}_{k}", np.float32(0.1 * k).item()) for k in range(f % 3)]
+
+
+# ---- eight ranks on one node: the HOST side of a step under the per-rank thread cap ---------------------------------------
+def _host_step(pipe, boxes_per_frame, texts, base):
+    """What every rank does on the host for one 64-frame batch between the detector's maps and the gather: box ordering,
+    crop geometry, the reference's chunking + the ragged partition, string decode, record packing (the DB hull / rectangle
+    geometry itself runs in C++ inside vse_db_postprocess and needs the device part before it)."""
+    from vse_amd import pipeline
+    ordered = [pipeline.sorted_boxes(b) for b in boxes_per_frame]
+    specs = pipe._crop_specs(ordered)
+    groups = pipe._groups(specs)
+    assert sum(len(g[0]) for g in groups) == len(specs)
+    res = [[("".join(pipe.charset[j] for j in texts[(f + k) % len(texts)]), 0.9) for k in range(len(b))] for f, b in enumerate(ordered)]
+    recs = [(base + f, np.asarray(b, np.float32).reshape(-1, 4, 2), r) for f, (b, r) in enumerate(zip(ordered, res))]
+    return parallel.pack_records(recs), recs
+
+
+def _host_workload(seed):
+    from vse_amd import pipeline
+    rng = np.random.default_rng(seed)
+    pipe = pipeline.OcrPipeline.__new__(pipeline.OcrPipeline)
+    pipe.rec_mode, pipe.rec_h, pipe.rec_base_w, pipe.rec_batch_num = "ragged", 48, 320, 6
+    pipe.bucket, pipe.batch_round, pipe.max_rec_batch, pipe.min_rec_group = 256, 4, 64, 8
+    pipe.charset = [""] + [chr(0x4e00 + i) for i in range(6000)]
+    boxes = []
+    for f in range(64):
+        bf = []
+        for _ in range(int(rng.integers(1, 4))):
+            x0, y0 = int(rng.integers(100, 600)), int(rng.integers(700, 950))
+            w, h = int(rng.integers(200, 1200)), int(rng.integers(40, 70))
+            bf.append(np.array([[x0, y0], [x0 + w, y0], [x0 + w, y0 + h], [x0, y0 + h]], np.float32))
+        boxes.append(bf)
+    texts = [rng.integers(1, 6000, size=int(rng.integers(5, 25))) for _ in range(37)]
+    return pipe, boxes, texts
+
+
+def _best_host_ms(pipe, boxes, texts, reps=30):
+    import time
+    best = 1e9
+    for r in range(reps):
+        t0 = time.perf_counter()
+        _host_step(pipe, boxes, texts, r * 64)
+        best = min(best, 1e3 * (time.perf_counter() - t0))
+    return best
+
+
+def _worker8(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["WORLD_SIZE"] = str(world)
+    cap = parallel.cap_host_threads(world)
+    import torch
+    torch.set_num_threads(cap)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pipe, boxes, texts = _host_workload(100 + rank)
+    _best_host_ms(pipe, boxes, texts, reps=3)              # warm
+    dist.barrier()                                         # all eight ranks time their host step AT THE SAME TIME
+    ms = _best_host_ms(pipe, boxes, texts)
+    _payload, recs = _host_step(pipe, boxes, texts, rank * 64)
+    out = parallel.gather_records(recs)
+    q.put((rank, ms, cap, torch.get_num_threads(), None if out is None else [r[0] for r in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_host_side_under_the_thread_cap():
+    """SURVEY §8(e) first contact with an 8-GPU node, host side: eight gloo ranks run the host part of a step concurrently
+    with their thread pools capped at cores / 8, then gather their records to rank 0.  The per-rank host time must stay
+    within 1.2 x of a single rank's (+ 0.5 ms of scheduler noise; median rank with a core per rank, every rank with two) — oversubscribed
+    thread pools are what would break that — and the gather must return all 8 x 64 records in frame order."""
+    cores = os.cpu_count() or 1
+    pipe, boxes, texts = _host_workload(100)
+    _best_host_ms(pipe, boxes, texts, reps=3)
+    one = _best_host_ms(pipe, boxes, texts)
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(g[2] == parallel.host_threads_per_rank(world) == g[3] for g in got)         # the cap reached torch
+    assert got[0][4] == list(range(world * 64)) and all(g[4] is None for g in got[1:])      # gather to rank 0, frame order
+    worst = max(g[1] for g in got)
+    print(f"host ms per 64-frame step: 1 rank {one:.2f}, 8 concurrent ranks worst {worst:.2f} ({cores} cores, cap {got[0][2]} threads/rank)")
+    times = sorted(g[1] for g in got)
+    if cores >= world:
+        # with exactly one core per rank the test runner and the OS take a core from some rank: the median rank must hold the
+        # bound, the worst one only when there are cores to spare (the GPU boxes: 64+)
+        assert times[len(times) // 2] <= 1.2 * one + 0.5, (one, times)
+    if cores >= 2 * world:
+        assert worst <= 1.2 * one + 0.5, (one, times)

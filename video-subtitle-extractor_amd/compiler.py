@@ -573,6 +573,13 @@ class Compiler:
         elif kind == ir.OP_BINARY:
             if p.get(ir.P_BIN_SHIFT, 0):
                 raise UnsupportedGraph(f"ragged plan: {name} adds an upsampled tensor")
+            # binary_kernel has no mask of its own: zeros right of a sample come from BOTH operands being masked at the same
+            # level and from an activation with f(0) = 0 — anything else would leak values into the padding, silently
+            for v in ins:
+                if v is not None and v.buf.wl != lin:
+                    raise UnsupportedGraph(f"ragged plan: {name} combines tensors of width levels {lin} and {v.buf.wl}")
+            if p.get(ir.P_BIN_ACT, 0) in (ir.ACT_SIGMOID, ir.ACT_HSIGMOID):
+                raise UnsupportedGraph(f"ragged plan: {name} applies an activation with f(0) != 0 behind an element-wise op")
             lout = lin
         elif kind == ir.OP_RESIZE:
             if p.get(0, 0):

@@ -342,13 +342,17 @@ int launch_conv_c3(const ConvParams& pin, int n_img, hipStream_t st) {
     ConvParams p = pin;
     if (!conv_c3_ok(p.kh, p.kw, p.sh, p.sw, p.ph, p.pw, p.cinp, p.flags)) return VSE_E_UNSUPPORTED;
     if ((double)p.Hs * p.Ws * p.in_ld > 2.0e9) return VSE_E_UNSUPPORTED;      // 32-bit in-image offsets
+#ifdef VSE_DEV_BUILD      // kernel experiments (conv_c3w.hip, forced tile shapes): compiled only into development builds
     static const int wide = [] { const char* e = getenv("VSE_C3_WIDE"); return e && e[0] ? atoi(e) : 0; }();
     if (wide == 1 && conv_c3w_ok(p)) return launch_conv_c3w(pin, n_img, st);
     if (wide == 2 && p.Np == 128 && !(p.flags & F_HILO)) return launch_conv_col3w(pin, n_img, st);
+#endif
     int rw;
     conv_c3_plan(p.OH, p.OW, &rw);
+#ifdef VSE_DEV_BUILD
     static const int force = [] { const char* e = getenv("VSE_C3_RW"); return e && e[0] ? atoi(e) : 0; }();
     if (force == 8 || force == 4 || force == 2) rw = force;
+#endif
     const int cw = 8 / rw;
     const int bn = p.Np <= 32 ? 32 : C3BN;
     p.ntn = (unsigned)((p.Np + bn - 1) / bn);

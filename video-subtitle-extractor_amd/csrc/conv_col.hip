@@ -270,7 +270,8 @@ bool conv_col_ok(int kh, int kw, int sh, int sw, int cinp, int Np, int flags) {
            && !(flags & (F_SRC2 | F_PIXSHUF | F_DOT1));
 }
 
-// experiment (VSE_C3_WIDE=1): 3x3 layers with 128 couts on this kernel's one-block-per-CU structure, all couts per block
+#ifdef VSE_DEV_BUILD
+// experiment (VSE_C3_WIDE=2, development builds only): 3x3 layers with 128 couts on this kernel's one-block-per-CU structure, all couts per block
 int launch_conv_col3w(const ConvParams& pin, int n_img, hipStream_t st) {
     ConvParams p = pin;
     p.ntn = 1;
@@ -281,6 +282,7 @@ int launch_conv_col3w(const ConvParams& pin, int n_img, hipStream_t st) {
     hipLaunchKernelGGL((conv_col_kernel<3, 128>), dim3((unsigned)blocks), dim3(512), 0, st, p);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }
+#endif
 
 int launch_conv_col(const ConvParams& pin, int n_img, hipStream_t st) {
     ConvParams p = pin;

@@ -350,11 +350,13 @@ constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 // couts fit 192 / 256 (the activation tile is then fetched once instead of 2-3 times), 256-pixel tiles (weights re-read
 // half as often), as long as the grid still fills the 256 CUs.  Zero-padded couts cost MFMA issue slots only.
 int conv_gemm_config(int Np, int cinp, long M) {
+#ifdef VSE_DEV_BUILD
     const char* e = getenv("VSE_GEMM_CFG");          // experiments: force a configuration where it is legal
     if (e && e[0]) {
         const int c = atoi(e);
         if (c >= 0 && c < kNumCfg && kCfg[c].bm && cinp % kCfg[c].bk == 0) return c;
     }
+#endif
     auto ntn = [&](int bn) { return (long)((Np + bn - 1) / bn); };
     // the 16-wave tiles run 64-deep K tiles in a 2-stage ring where the channels allow it (whole 128-byte lines per
     // activation row and half the barriers; A/B on one box: -2..-4 %); the 8-wave 256 x 128 tile loses its second block per CU

@@ -182,7 +182,10 @@ static inline TView resolve(const vse_view& v, char* ws, char* wts, void* const*
     return t;
 }
 
-static int run_op(vse_plan* p, int i, char* ws, void* const* ext, const int32_t* wtab, hipStream_t st) {
+// geometry of the uint8 source frames of one run (F_U8SRC plans)
+struct SrcGeom { int h, w; long pitch, fstride; };
+
+static int run_op(vse_plan* p, int i, char* ws, void* const* ext, const int32_t* wtab, hipStream_t st, const SrcGeom& src) {
     const vse_op& o = p->ops[i];
     // ragged plans: widths[level][n]
     const int* wl_in = (wtab && o.p[P_WLIN]) ? wtab + (size_t)(o.p[P_WLIN] - 1) * p->batch : nullptr;
@@ -210,7 +213,7 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, const int32_t*
         a.u8src = nullptr; a.u8_h = a.u8_w = 0; a.u8_pitch = a.u8_fstride = 0;
         if (o.flags & F_U8SRC) {
             a.u8src = reinterpret_cast<const uint8_t*>(ext[0]);
-            a.u8_h = p->src_h; a.u8_w = p->src_w; a.u8_pitch = p->src_pitch; a.u8_fstride = p->src_fstride;
+            a.u8_h = src.h; a.u8_w = src.w; a.u8_pitch = src.pitch; a.u8_fstride = src.fstride;
         }
         rc = launch_conv(a, st);
     } else {
@@ -256,15 +259,21 @@ int vse_plan_run(vse_plan* p, void* ws, void* const* ext, int n_ext, void* strea
     return vse_plan_run_ragged(p, ws, ext, n_ext, nullptr, stream);
 }
 
-int vse_plan_run_ragged(vse_plan* p, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream) {
-    int rc = check_run(p, ws, ext, n_ext, d_widths, "vse_plan_run");
-    if (rc != VSE_OK) return rc;
+// the frame geometry travels with the RUN (a by-value copy taken here), never read from the plan while ops are being launched:
+// the same plan may serve callers with different source sizes (vse_det_forward hands over its own arguments)
+static int run_all(vse_plan* p, void* ws, void* const* ext, const int32_t* d_widths, void* stream, const SrcGeom src) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     for (int i = 0; i < (int)p->ops.size(); ++i) {
-        rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, d_widths, st);
+        const int rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, d_widths, st, src);
         if (rc != VSE_OK) return rc;
     }
     return VSE_OK;
+}
+
+int vse_plan_run_ragged(vse_plan* p, void* ws, void* const* ext, int n_ext, const int32_t* d_widths, void* stream) {
+    int rc = check_run(p, ws, ext, n_ext, d_widths, "vse_plan_run");
+    if (rc != VSE_OK) return rc;
+    return run_all(p, ws, ext, d_widths, stream, SrcGeom{p->src_h, p->src_w, p->src_pitch, p->src_fstride});
 }
 
 int vse_plan_width_levels(vse_plan* p) { return p ? p->n_levels : VSE_E_INVAL; }
@@ -279,11 +288,15 @@ int vse_det_forward(vse_ctx* c, vse_plan* det_plan, void* ws, const void* d_bgr,
         return VSE_E_INVAL;
     }
     if (det_plan->u8_source) {
-        // the plan's stem resizes the frames itself: no pre-processing pass, no fp16 input tensor
-        int rc = vse_plan_set_source(det_plan, src_h, src_w, pitch, frame_stride);
-        if (rc != VSE_OK) return rc;
+        // the plan's stem resizes the frames itself: no pre-processing pass, no fp16 input tensor; the geometry of THIS call's
+        // frames goes to the kernels directly (nothing is stored on the shared plan)
+        if (src_h <= 0 || src_w <= 0 || pitch < (int64_t)src_w * 3 || frame_stride < 0 || (!ws && det_plan->ws_bytes)) return VSE_E_INVAL;
+        if (det_plan->max_ext > 1 || det_plan->n_levels) {
+            set_err("vse_det_forward: not a one-map detector plan");
+            return VSE_E_INVAL;
+        }
         void* ext[2] = {const_cast<void*>(d_bgr), d_prob};
-        return vse_plan_run(det_plan, ws, ext, 2, stream);
+        return run_all(det_plan, ws, ext, nullptr, stream, SrcGeom{src_h, src_w, (long)pitch, (long)frame_stride});
     }
     if (!d_in_f16) return VSE_E_INVAL;
     static const float mean[3] = {0.485f, 0.456f, 0.406f}, sd[3] = {0.229f, 0.224f, 0.225f};      // paddleocr NormalizeImage (DB detectors)
@@ -444,7 +457,7 @@ int vse_plan_profile(vse_plan* p, void* ws, void* const* ext, int n_ext, const i
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(hipEventRecord(ev[0], st));
     for (int i = 0; i < n; ++i) {
-        int rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, d_widths, st);
+        int rc = run_op(p, i, reinterpret_cast<char*>(ws), ext, d_widths, st, SrcGeom{p->src_h, p->src_w, p->src_pitch, p->src_fstride});
         if (rc != VSE_OK) return rc;
         HIP_TRY(hipEventRecord(ev[i + 1], st));
     }

@@ -294,6 +294,7 @@ class Net:
         if self.wid is None or len(self.store.blob) != self.wbytes:
             # (re-)upload the shared weight blob; plans created against an older blob are rebuilt lazily
             blob = self.store.array()
+            self._drop_graphs()               # captured graphs replay kernels against the plan handles / weight blob freed below
             if self.wid is not None:
                 for k, (p_, h_) in self.plans.items():
                     if h_ is not None:
@@ -312,6 +313,20 @@ class Net:
             self.plans[key][1] = h
             handle = h
         return prog, handle
+
+    GRAPH_CACHE_MAX = 32      # captured recogniser graphs kept per net (each pins input, workspace and output buffers)
+
+    def _drop_graphs(self, keep=0):
+        """Destroy captured recogniser graphs, oldest first, until `keep` are left (after a device synchronisation: they may be
+        in flight)."""
+        graphs = self.__dict__.get("_graphs")
+        if not graphs or len(graphs) <= keep:
+            return
+        self.ctx.torch.cuda.synchronize(self.ctx.tdev)
+        while len(graphs) > keep:
+            bufs = graphs.pop(next(iter(graphs)))
+            if bufs["graph"] is not None:
+                self.ctx.lib.vse_graph_destroy(bufs["graph"])
 
     def _workspace(self, key, prog, slot):
         """One workspace per (plan, slot): a plan is stateless between runs, so the same plan may run concurrently on
@@ -348,8 +363,30 @@ class Net:
             return None
         if widths is None:
             widths = np.full(n, w, np.int32)          # a uniform batch: every sample as wide as the tensor
-        tab = prog.width_table(widths)
-        return self.ctx.torch.from_numpy(tab).to(self.ctx.tdev)
+        return self._upload_i32(prog.width_table(widths))
+
+    def _upload_i32(self, tab, out=None):
+        """Stream-ordered upload of a small int32 host table through a ring of reusable pinned buffers.  A pageable
+        `tensor.to(device)` blocks the host until the stream has drained (every recogniser group would wait for the previous
+        group's ~80 kernels); a pinned buffer allocated per call costs as much as that stall (round 3 log) — the ring costs
+        neither: slot i is reused after 8 further uploads, guarded by the event recorded behind its last copy."""
+        t = self.ctx.torch
+        ring = self.__dict__.setdefault("_pin_ring", {"slots": [None] * 8, "next": 0})
+        i = ring["next"] % len(ring["slots"])
+        ring["next"] += 1
+        slot = ring["slots"][i]
+        if slot is None or slot[0].numel() < tab.size:
+            if slot is not None:
+                slot[1].synchronize()
+            slot = ring["slots"][i] = (t.empty(max(int(tab.size), 1024), dtype=t.int32).pin_memory(), t.cuda.Event())
+        else:
+            slot[1].synchronize()             # the copy that last read this slot (8 uploads ago) has long finished
+        pin = slot[0][:tab.size].view(tab.shape)
+        pin.numpy()[...] = tab
+        dev = out if out is not None else t.empty(tab.shape, dtype=t.int32, device=self.ctx.tdev)
+        dev.copy_(pin, non_blocking=True)
+        slot[1].record(t.cuda.current_stream(self.ctx.tdev))
+        return dev
 
     def run(self, x, slot=0, widths=None):
         """x: cuda fp16 [N,H,W,8] NHWC (3 real channels).  Returns list of fp32 cuda tensors (prog.outputs order).
@@ -436,7 +473,10 @@ class Net:
         key = (n, h, w, slot)
         if not hasattr(self, "_graphs"):
             self._graphs = {}
-        if key not in self._graphs:
+        if key in self._graphs:
+            self._graphs[key] = self._graphs.pop(key)      # most recently used last
+        else:
+            self._drop_graphs(keep=self.GRAPH_CACHE_MAX - 1)
             self.program(n, h, w)
             prog, handle = self._ensure((n, h, w))
             tt = prog.outputs[0]["w"]
@@ -453,7 +493,7 @@ class Net:
         -> clones of (class ids, lengths, confidences) (the fixed output buffers are overwritten by the next launch)."""
         t = self.ctx.torch
         prog = bufs["prog"]
-        bufs["wt"].copy_(t.from_numpy(prog.width_table(widths)))
+        self._upload_i32(prog.width_table(widths), out=bufs["wt"])
         if bufs["graph"] is None:
             g = C.c_void_p()
             n = bufs["x"].shape[0]

@@ -93,6 +93,8 @@ def run_ocr_tasks(source, tasks, ocr, sub_area=None, rec_char_type="ch", drop_sc
     (one variable-length gather) and therefore returns the same lines.  -> list of raw.txt lines in task order."""
     tasks = [t for t in tasks if t[1] != -1]
     lo, hi = (0, len(tasks)) if shard is None else parallel.shard_range(len(tasks), *shard)
+    if shard is not None and shard[1] > 1:
+        parallel.cap_host_threads(shard[1])       # one process per GPU: this rank's numpy / torch pools get cores / world threads
     results = {}                        # task index -> (dt_box, rec_res)
     batched = hasattr(ocr, "predict_batch")
 

@@ -3,12 +3,41 @@
 Frames are independent units (the reference handles them one at a time, F4), so a job of F frames is split into
 contiguous ranges, one per rank (one process per GPU), with NO collective on the data path.  The only exchange
 step is the final variable-length gather of per-frame records (boxes, scores, text) to rank 0:
-an all_gather of byte counts followed by an all_gather of one padded uint8 tensor (RCCL over xGMI when the
-backend is "nccl"; gloo in the CPU tests).  ~100 B/frame: latency-bound, so it is done once per job/chunk.
+an all_gather of byte counts (8 B per rank: every rank needs the padded size) followed by a gather of one padded uint8
+tensor to rank 0 (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).  ~100 B/frame: latency-bound, so it is done once per job/chunk.
 """
+import os
 import struct
 
 import numpy as np
+
+
+def host_threads_per_rank(world, cores=None):
+    """Host threads one rank may use when `world` ranks share a node: cores / world, at least 1."""
+    cores = cores if cores is not None else (os.cpu_count() or 1)
+    return max(1, cores // max(1, world))
+
+
+def cap_host_threads(world=None, cores=None):
+    """One process per GPU: every rank runs the host side of the path (DB geometry, crop grouping, record packing, string
+    decode) — numpy / torch / OpenMP pools default to ALL cores each, so 8 ranks would run 8 x cores threads.  Caps this
+    process's pools at cores / world.  The environment variables only reach libraries that have not started their pools yet
+    (bench.py calls this before importing torch); torch's own pools are set directly.  Returns the cap (None when world <= 1)."""
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+    if world <= 1:
+        return None
+    n = host_threads_per_rank(world, cores)
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+        os.environ[var] = str(n)
+    import sys
+    if "torch" in sys.modules:
+        import torch
+        torch.set_num_threads(n)
+        try:
+            torch.set_num_interop_threads(max(1, min(n, 4)))
+        except RuntimeError:          # already started: the intra-op cap above is the one that matters
+            pass
+    return n
 
 
 def shard_range(total, rank, world):
@@ -56,7 +85,7 @@ def unpack_records(buf):
 
 def gather_records(records, device=None, to_all=False):
     """All ranks call; rank 0 gets the concatenation ordered by frame number, other ranks get None (to_all=True: every
-    rank gets it — the exchange is an all_gather anyway).  Works without torch.distributed initialised (single process)."""
+    rank gets it through an all_gather instead of the gather).  Works without torch.distributed initialised (single process)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -70,8 +99,22 @@ def gather_records(records, device=None, to_all=False):
     mx = int(max(int(s.item()) for s in sizes))
     buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
     buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, buf)
+    if to_all:
+        bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(bufs, buf)
+    else:
+        # north_star: "RCCL ... only for the final box/text gather" — a gather to rank 0: the other ranks send their padded
+        # buffer once and receive nothing (an all_gather would deliver world x the payload to ranks that drop it)
+        bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        try:
+            dist.gather(buf, bufs, dst=0)
+        except (NotImplementedError, RuntimeError) as exc:
+            # a backend build without gather refuses on every rank alike (no rank is left waiting): the all_gather is the same
+            # exchange with world x the receive volume
+            if "gather" not in str(exc).lower() and not isinstance(exc, NotImplementedError):
+                raise
+            bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
+            dist.all_gather(bufs, buf)
     if rank != 0 and not to_all:
         return None
     out = []

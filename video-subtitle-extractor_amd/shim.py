@@ -338,6 +338,10 @@ class PaddleOCR:
                  det_db_thresh=0.3, det_db_box_thresh=0.6, det_db_unclip_ratio=1.5, **backend):
         if use_angle_cls:
             raise NotImplementedError("angle classifier is never enabled by the reference (ocr.py:104)")
+        if rec_mode not in ("ragged", "reference"):
+            # "bucketed" (crops padded to bucket widths) does NOT give the reference's per-chunk padding and is kept on
+            # pipeline.OcrPipeline for A/B measurements only; the reference-shaped call site offers the two identical modes
+            raise ValueError(f"rec_mode={rec_mode!r}: 'ragged' (default) or 'reference' (same results, the reference's launch structure)")
         if det_algorithm != "DB":
             raise NotImplementedError("only DB detection exists in the reference (SURVEY F9)")
         if rec_algorithm not in ("CRNN", "SVTR_LCNet", "SVTR_HGNet"):
