@@ -12,6 +12,10 @@ the published semantics of each Paddle operator.
 The interpreter walks the descriptor op by op in NCHW / fp32 on torch-CPU, exactly one torch call per
 Paddle op, no fusion, no layout change — deliberately the *dumbest* possible execution so that it shares
 no structure with the HIP engine's compiler (fusion, BN folding, NHWC, fp16).
+
+Consistency checks (NOT pins: neither paddle nor cv2 can run here): tests/test_oracle_crosschecks.py compares the restated
+primitives of this file with independent implementations of the same published definitions (torch.nn.LSTM, a float64
+bilinear resize, brute-force rotation search, scipy's convex hull).
 """
 import json
 import math

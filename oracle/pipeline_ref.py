@@ -16,6 +16,10 @@ Pinning status
     the reference holds no tests or golden outputs for this path).  Call sites: backend/tools/ocr.py:27,
     backend/tools/subtitle_detect.py:25.
 Plain numpy/scipy; loops only over boxes/components.
+
+Consistency checks (NOT pins: neither paddle nor cv2 can run here): tests/test_oracle_crosschecks.py compares the restated
+primitives of this file with independent implementations of the same published definitions (torch.nn.LSTM, a float64
+bilinear resize, brute-force rotation search, scipy's convex hull).
 """
 import math
 
