@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--ragged-floor", type=int, default=None, help="ragged grouping: crop-pixels below which a launch sequence stops getting faster")
     ap.add_argument("--ragged-launch-cost", type=int, default=None, help="ragged grouping: fixed cost of one launch sequence in crop-pixels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="skip config.secondary (4K batch 32, fast mode)")
+    ap.add_argument("--secondary-steps", type=int, default=4)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="finish batch k before the detector of batch k+1 starts")
     ap.add_argument("--det-priority", type=int, default=0, help="HIP stream priority of the detector streams (-1 = high)")
@@ -194,6 +196,32 @@ def main():
             print(f"[bench +{time.time() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     ctx = engine.Context(local)
+    coll_dev = ctx.tdev if backend == "nccl" else "cpu"
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # One workload = (model pair, frame size, frames per step): everything the timed region needs, built and resident before
+    # it starts.  The headline is build(args...) below; `config.secondary` (north_star: "1080p AND 4K frame batches"; the
+    # reference's default fast mode) times two more workloads with the same functions, a few steps each.
+    W = build_workload(args, ctx, world, rank, coll_dev, sync, log, args.models, args.height, args.width, args.batch)
+    pipe, det, rec, det_id, rec_id, lang = W.pipe, W.det, W.rec, W.det_id, W.rec_id, W.lang
+    frames_np, truth, overlay_np, overlay, quads = W.frames_np, W.truth, W.overlay_np, W.overlay, W.quads
+    timed, det_maps, stage2_recognise, span, depth = W.timed, W.det_maps, W.stage2_recognise, W.span, W.depth
+    out, dt = timed(args.warmup, args.steps)
+    log(f"timed region ({args.rec_mode} rec batching): {args.warmup} warmup + {args.steps} steps in {dt:.3f}s")
+    return finish(args, ctx, world, rank, W, out, dt, log, host_threads, build_secondary=lambda m, h, w_, b: build_workload(
+        args, ctx, world, rank, coll_dev, sync, log, m, h, w_, b))
+
+
+def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, width, batch):
+    import types
+    import torch
+    import torch.distributed as dist
+    from vse_amd import engine, modelzoo, parallel, pipeline, shim, synth
+    args = argparse.Namespace(**dict(vars(args), models=models, height=height, width=width, batch=batch))
     if args.models == "server":
         det_id, rec_id, lang = "V4_ch_det", "V4_ch_rec", "ch"
     elif args.models == "fast":
@@ -235,8 +263,6 @@ def main():
         if overlay is not None:
             torch.maximum(maps, overlay, out=maps)      # bench scaffolding only (stand-in weights), on the detector's stream
         return maps
-
-    coll_dev = ctx.tdev if backend == "nccl" else "cpu"
 
     def records(k, boxes, res):
         # frame numbers: step k of rank r covers frames [(k * world + r) * batch, ... + batch) of the job
@@ -309,11 +335,6 @@ def main():
                     ready = []
         return parallel.gather_records(local, device=coll_dev)
 
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     def timed(warmup, steps):
         out = run_steps(warmup)
         sync()
@@ -327,8 +348,18 @@ def main():
             dt = float(tmax.item())
         return out, dt
 
-    out, dt = timed(args.warmup, args.steps)
-    log(f"timed region ({args.rec_mode} rec batching): {args.warmup} warmup + {args.steps} steps in {dt:.3f}s")
+    return types.SimpleNamespace(pipe=pipe, det=det, rec=rec, det_id=det_id, rec_id=rec_id, lang=lang, frames_np=frames_np, truth=truth,
+                                 overlay_np=overlay_np, overlay=overlay, quads=quads, timed=timed, det_maps=det_maps,
+                                 stage2_recognise=stage2_recognise, span=span, depth=depth, args=args)
+
+
+def finish(args, ctx, world, rank, W, out, dt, log, host_threads, build_secondary):
+    import torch
+    import torch.distributed as dist
+    from vse_amd import modelzoo, pipeline, shim
+    pipe, det, rec, det_id, rec_id, lang = W.pipe, W.det, W.rec, W.det_id, W.rec_id, W.lang
+    frames_np, truth, overlay_np, overlay, quads = W.frames_np, W.truth, W.overlay_np, W.overlay, W.quads
+    timed, det_maps, stage2_recognise, span, depth = W.timed, W.det_maps, W.stage2_recognise, W.span, W.depth
     n_boxes = sum(len(r[1]) for r in out[-world * args.batch:]) if out is not None else 0
     # the other recogniser batching mode on the same workload, timed the same way (fewer steps: the reference grouping runs
     # one launch sequence per <= 6 crops of ONE frame and is launch-bound)
@@ -359,7 +390,8 @@ def main():
                                                   "the reference's padding",
                                       "ragged": f"ragged({args.bucket}px groups, min group {args.min_rec_group}): every crop at the padded "
                                                 "width of its reference chunk, crops of all frames share launches, results bit-identical "
-                                                "to the reference grouping",
+                                                "to THIS ENGINE's run in the reference grouping (tests/test_gpu_pipeline.py; the C2 path vs "
+                                                "the CPU oracle: tests/test_gpu_bench.py)",
                                       "reference": "reference (per frame, <= 6 crops per chunk, chunk padded to its widest crop)"}[args.rec_mode],
                        "det_map": ("detector output" if overlay is None else
                                    f"stand-in detector output (head bias -8) max-overlaid inside the step with the text-kernel map of the "
@@ -386,6 +418,27 @@ def main():
                 stage2_recognise(ready)
             result["roofline"] = roofline(pipe, profile_pass, steps_per_call=span)     # rank 0 only: no collective
             log("roofline pass done")
+        if args.secondary and not args.no_roofline and world == 1:      # (the A/B tools pass --no-roofline: headline only)
+            # the other single-GPU configurations north_star names, through the same functions, a few timed steps each (the headline
+            # above is untouched: it was measured first): BASELINE configs[2]'s frame size (4K frames, batch 32; det_limit_side_len
+            # stays the reference's 960, so the detector input is 544 x 960 and the crops come from 4K pixels), and the reference's
+            # DEFAULT mode (backend/config.py:54 mode = fast -> V4/ch_det_fast + V4/ch_rec_fast, the mobile pair)
+            sec = {}
+            for key, (m, h, w_, b) in (("4k_batch32", ("server", 2160, 3840, 32)), ("fast_mode_1080p", ("fast", 1080, 1920, 64))):
+                try:
+                    W2 = build_secondary(m, h, w_, b)
+                    _o2, dt2 = W2.timed(2, args.secondary_steps)
+                    sec[key] = {"metric": f"OCR frames/sec (det+rec) @{h}p", "value": round(b * args.secondary_steps / dt2, 2), "unit": "frames/s",
+                                "ms_per_step": round(1e3 * dt2 / args.secondary_steps, 3), "steps": args.secondary_steps, "warmup": 2,
+                                "workload": f"{b}x{h}p frames/step, {W2.det_id} @{'x'.join(str(v) for v in pipeline.det_resize_shape(h, w_, args.limit_side))} + {W2.rec_id}, "
+                                            f"boxes from DB post-processing, ragged recognition",
+                                "boxes_last_step": sum(len(r[1]) for r in _o2[-b:])}
+                    log(f"secondary {key}: {sec[key]['value']} frames/s")
+                    del W2, _o2
+                    torch.cuda.empty_cache()
+                except Exception as exc:      # the headline line must not die for a secondary figure
+                    sec[key] = {"error": repr(exc)[:300]}
+            result["config"]["secondary"] = sec
         if not args.no_cpu_baseline and world == 1:
             from oracle import pipeline_ref as P
             cs = P.standin_charset(shim._ncls(rec[0])) if lang != "en" else P.en_charset()

@@ -120,6 +120,21 @@ class Emulator:
         idx = (np.arange(n * h * w)[:, None] * ld + np.arange(c)[None, :])
         flat[idx] = arr.astype(dt)
 
+    def write_pair(self, v, lo_off, t):
+        """write() of an fp16 hi + lo pair tensor (Buf.lo_off): the lo half lo_off channels behind the hi half.  The fp32 shadow
+        keeps the whole value in the hi half (a pair carries ~22 bits) and a zero lo; the byte-exact mode splits like the kernels."""
+        if not lo_off:
+            return self.write(v, t)
+        lv = v.copy()
+        lv["off"] = int(lv["off"]) + lo_off * int(lv["esize"])
+        if self.round:
+            hi = t.half().float()
+            self.write(v, hi)
+            self.write(lv, t - hi)
+        else:
+            self.write(v, t)
+            self.write(lv, torch.zeros_like(t))
+
     def wread(self, off, count, dt):
         return self.wblob[off:off + count * np.dtype(dt).itemsize].view(dt)
 
@@ -158,6 +173,72 @@ class Emulator:
             return t
         s = 1 << shift
         return t.repeat_interleave(s, dim=1).repeat_interleave(s, dim=2)
+
+    def _op14(self, r):  # CHAIN (csrc/chain.hip): decoded from the blob the kernel reads — descriptor words, MFMA fragments, dw tables
+        off = int(r["w_off"])
+        hdr = self.wread(off, ir.CH_HDR, np.int32)
+        assert int(hdr[ir.CHH_MAGIC]) == ir.CH_MAGIC
+        n, nb = int(hdr[ir.CHH_NSTAGES]), int(hdr[ir.CHH_NBUFS])
+        bw = self.wread(off + 4 * ir.CH_HDR, nb * ir.CH_BUF, np.int32).reshape(nb, ir.CH_BUF)
+        sw = self.wread(off + 4 * (ir.CH_HDR + nb * ir.CH_BUF), n * ir.CH_STAGE, np.int32).reshape(n, ir.CH_STAGE)
+        img = off + int(hdr[ir.CHH_LDSIMG_OFF])
+        assert int(hdr[ir.CHH_LDS_TOTAL]) <= 160 * 1024 and int(r["p"][ir.P_CH_LDS]) == int(hdr[ir.CHH_LDS_TOTAL])
+
+        def i2f(v):
+            return float(np.asarray([v], np.int32).view(np.float32)[0])
+
+        def pair(t):          # what a hi + lo fp16 pair keeps of an fp32 value
+            if not self.round:
+                return t
+            hi = t.half().float()
+            return hi + (t - hi).half().float()
+        x = self.read(r["in0"])
+        lo_in = int(r["p"][ir.P_CH_LO_IN])
+        if lo_in:
+            v = r["in0"].copy()
+            v["off"] = int(v["off"]) + lo_in * int(v["esize"])
+            x = x + self.read(v)
+        assert x.shape[3] >= int(bw[0, ir.CHB_C])
+        bufs = {0: x[..., :int(bw[0, ir.CHB_C])].permute(0, 3, 1, 2).contiguous()}
+        gviews = [r["out"], r["out2"], r["in2"]]
+        lane = np.arange(64)
+        rows = np.array([(f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1) for f in lane & 31])
+        for j in range(n):
+            s = sw[j]
+            xin = bufs[int(s[ir.CHS_IN])]
+            cin, cout, k, st = int(s[ir.CHS_CIN]), int(s[ir.CHS_COUT]), int(s[ir.CHS_K]), int(s[ir.CHS_S])
+            assert xin.shape[1] == cin
+            if int(s[ir.CHS_TYPE]) == ir.CH_PW:
+                nks, nct = int(s[ir.CHS_NKS]), int(s[ir.CHS_NCT])
+                fr = self.wread(img + int(s[ir.CHS_WLDS]), 2 * nct * nks * 512, np.float16).astype(np.float64).reshape(2, nct, nks, 64, 8)
+                wm = np.zeros((nct * 32, nks * 16), np.float64)
+                for ct in range(nct):
+                    for ks in range(nks):
+                        k0 = ks * 16 + 8 * (lane >> 5)
+                        wm[(ct * 32 + rows)[:, None], k0[:, None] + np.arange(8)[None, :]] = fr[0, ct, ks] + fr[1, ct, ks]
+                assert not wm[cout:].any() and not wm[:, cin:].any()
+                bias = self.wread(img + int(s[ir.CHS_BLDS]), nct * 32, np.float32).astype(np.float64)
+                y = F.conv2d(xin.double(), torch.from_numpy(wm[:cout, :cin].copy()).reshape(cout, cin, 1, 1), torch.from_numpy(bias[:cout].copy())).float()
+            else:
+                nrec = (k * k + 1 + 3) // 4 * 4                 # per-channel record: k*k weights, bias, padding
+                rec = self.wread(img + int(s[ir.CHS_WLDS]), cin * nrec, np.float32).reshape(cin, nrec)
+                assert not rec[:, k * k + 1:].any()
+                wk, bk = rec[:, :k * k].reshape(cin, 1, k, k), rec[:, k * k]
+                y = F.conv2d(xin, torch.from_numpy(wk.copy()), torch.from_numpy(bk.copy()), st, int(s[ir.CHS_PAD]), groups=cin)
+            y = _act(y, int(s[ir.CHS_ACT]), i2f(s[ir.CHS_ACT_A]), i2f(s[ir.CHS_ACT_B]))
+            y = y * i2f(s[ir.CHS_POST_A]) + i2f(s[ir.CHS_POST_B])
+            if int(s[ir.CHS_RES]) >= 0:
+                y = _act(y + bufs[int(s[ir.CHS_RES])], int(s[ir.CHS_ACT2]))
+            if int(s[ir.CHS_OUT]) >= 0:
+                ob = bw[int(s[ir.CHS_OUT])]
+                assert int(ob[ir.CHB_C]) == cout and (int(ob[ir.CHB_HIMG]), int(ob[ir.CHB_WIMG])) == tuple(y.shape[2:])
+                bufs[int(s[ir.CHS_OUT])] = pair(y) if int(ob[ir.CHB_KIND]) == 0 else y
+            g = int(s[ir.CHS_GOUT])
+            if g >= 0:
+                gv = gviews[g]
+                yo = y.permute(0, 2, 3, 1)
+                pc = int(gv["c"])
+                self.write_pair(gv, int(r["p"][ir.P_CH_LO_OUT0 + g]), yo if pc == cout else F.pad(yo, (0, pc - cout)))
 
     def _op1(self, r):   # CONV
         p, f = r["p"], r["f"]
@@ -247,6 +328,9 @@ class Emulator:
         y = _act(y, int(p[ir.P_ACT]), float(f[ir.FS_ACT_A]), float(f[ir.FS_ACT_B]))
         y = y * float(f[ir.FS_POST_A]) + float(f[ir.FS_POST_B])
         flags = int(r["flags"])
+        if flags & ir.F_OGATE:                       # SE block with shortcut folded into the conv: y * (1 + gate[n, c])
+            assert not (flags & (ir.F_SRC2 | ir.F_IMGW | ir.F_PIXSHUF))
+            y = y * (1.0 + self.read(r["in2"])[..., :Np].reshape(y.shape[0], 1, 1, Np))
         if flags & ir.F_PIXSHUF:
             n, h, w, _ = y.shape
             cp = Np // 4
@@ -263,7 +347,7 @@ class Emulator:
             self.write(r["out2"], z if oc2 == 1 else F.pad(z, (0, oc2 - 1)))   # pad channels (if any) are written as 0
             return
         oc = int(r["out"]["c"])
-        self.write(r["out"], y[..., :oc] if y.shape[3] >= oc else F.pad(y, (0, oc - y.shape[3])))
+        self.write_pair(r["out"], int(p[ir.P_LO_OUT]), y[..., :oc] if y.shape[3] >= oc else F.pad(y, (0, oc - y.shape[3])))
 
     def _op2(self, r):   # DWCONV
         p, f = r["p"], r["f"]

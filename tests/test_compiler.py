@@ -373,3 +373,37 @@ def test_input_norm_folded_into_the_stem(mid, hilo):
     assert np.array_equal(ir_emul.Emulator(fused).run(raw)[0], ir_emul.Emulator(prog).run(raw)[0])
     with pytest.raises(compiler.UnsupportedGraph):
         compiler.compile_model(desc, w, 1, 96, 160, hilo=hilo, fuse_preprocess=True)          # needs input_norm
+
+
+@pytest.mark.parametrize("mid", ["V3_ch_det_fast", "V4_ch_det_fast"])
+def test_mobile_detector_chains_and_gated_laterals(mid):
+    """compile_model(hilo=True) for the mobile detectors (the reference's default mode, paddle_model_config.py:53-58):
+    runs of 1x1 / depthwise convs become OP_CHAIN records (chains.py), tensors that feed a chain are fp16 hi + lo pairs, and the
+    RSE-FPN laterals (1x1 conv + SE block with shortcut + top-down add) become ONE gated conv each (F_OGATE, residual in the
+    epilogue).  The emulator decodes the chain blob the kernel reads (descriptor words, MFMA fragments in lane order, depthwise
+    records) and must agree with the fp32 interpreter; the byte-exact fp16 mode must stay within the fp16 budget."""
+    desc, w = net_ref.get_weights(mid)
+    x = np.random.default_rng(3).uniform(-1, 1, (2, 3, 96, 160)).astype(np.float16).astype(np.float32)
+    ref = net_ref.run_graph(desc, w, x)[0].numpy()[:, 0]
+    prog = compiler.compile_model(desc, w, 2, 96, 160, hilo=True)
+    plain = compiler.compile_model(desc, w, 2, 96, 160, hilo=True, chain=False)
+    kinds = [int(o["kind"]) for o in prog.ops]
+    chains = [o for o in prog.ops if int(o["kind"]) == ir.OP_CHAIN]
+    assert len(chains) >= 5 and len(prog.ops) < len(plain.ops) - 10
+    gated = [o for o in prog.ops if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_OGATE]
+    assert len(gated) == 4 and sum(bool(int(o["flags"]) & ir.F_RES) for o in gated) == 3      # four laterals, three top-down adds
+    assert ir.OP_SCALE not in [int(o["kind"]) for o in prog.ops if int(o["out"]["c"]) == 96]        # no 96-channel SE multiply is left
+    for o in chains:
+        hdr = np.frombuffer(bytes(prog.weights.blob[int(o["w_off"]):int(o["w_off"]) + 4 * ir.CH_HDR]), np.int32)
+        assert hdr[ir.CHH_MAGIC] == ir.CH_MAGIC and 2 <= hdr[ir.CHH_NSTAGES] <= 8 and hdr[ir.CHH_LDS_TOTAL] <= 160 * 1024
+        final_h = min(int(o[k]["h"]) for k in ("out", "out2", "in2") if int(o[k]["n"]) > 0)       # tiles cover the LAST stage's output
+        assert int(o["p"][ir.P_CH_TILES_H]) * hdr[ir.CHH_TH] >= final_h and int(o["p"][ir.P_CH_LDS]) == hdr[ir.CHH_LDS_TOTAL]
+    # a tensor that feeds a chain is a pair: its producer stores the lo half, the chain reads it at the same offset
+    lo_in = [int(o["p"][ir.P_CH_LO_IN]) for o in chains]
+    assert any(lo_in) and all(v % 8 == 0 for v in lo_in)
+    err32 = np.abs(ir_emul.Emulator(prog).run(ir_emul.to_nhwc8(x))[0][..., 0] - ref).max()
+    err16 = np.abs(ir_emul.Emulator(prog, round_f16=True).run(ir_emul.to_nhwc8(x))[0][..., 0] - ref).max()
+    err16_plain = np.abs(ir_emul.Emulator(plain, round_f16=True).run(ir_emul.to_nhwc8(x))[0][..., 0] - ref).max()
+    assert err32 < 1e-2 and err16 < 3e-2, (err32, err16, err16_plain)
+    print(f"{mid}: {len(plain.ops)} -> {len(prog.ops)} ops, {len(chains)} chains; max |map - fp32 interpreter|: fp32 emulation {err32:.2e}, "
+          f"fp16-exact emulation chained {err16:.2e} vs unchained {err16_plain:.2e}")

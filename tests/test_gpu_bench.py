@@ -31,7 +31,7 @@ def _run(cmd, env):
 
 def test_bench_two_ranks_one_json_line(ctx):
     env = dict(os.environ, VSE_DIST_BACKEND="gloo", VSE_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    flags = ["--steps", "2", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-roofline", "--other-mode-steps", "0"]
+    flags = ["--steps", "2", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-roofline", "--no-secondary", "--other-mode-steps", "0"]
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + flags, env)
     assert two["n_gpus"] == 2 and two["steps"] == 2 and two["warmup"] == 1 and two["scaling"] == "weak"
@@ -41,3 +41,61 @@ def test_bench_two_ranks_one_json_line(ctx):
     one = _run([sys.executable, "bench.py", "--gpus", "1"] + flags, dict(os.environ))
     assert one["n_gpus"] == 1 and one["config"]["records_gathered"] == 16 * 2
     assert one["config"]["boxes_last_step"] > 0
+
+
+def test_bench_configuration_c2_against_the_oracle_in_one_piece(ctx):
+    """The EXACT path bench.py times (BASELINE configs[1]) against the CPU oracle, end to end on 4 x 1080p frames:
+    V4_ch_det map (engine vs oracle/net_ref) max-overlaid with bench.text_kernel_maps ON BOTH SIDES -> DB post-processing
+    -> boxes (identical integers) -> perspective crops -> V4_ch_rec in the benchmarked ragged mode vs the oracle's
+    rec_batches chunks (backend/tools/ocr.py:24-27,88-113; paddleocr TextSystem): confidences within 1e-3 of the oracle's
+    softmax, strings identical wherever the oracle's own top-2 margin is clear."""
+    import difflib
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import net_ref, pipeline_ref as P
+    from vse_amd import pipeline, shim, synth
+    nf, H, W = 4, 1080, 1920
+    det = net_ref.get_weights("V4_ch_det")
+    det = (det[0], bench.empty_det_head(det[0], dict(det[1])))        # what bench.py does to the stand-in detector
+    rec = net_ref.get_weights("V4_ch_rec")
+    charset = shim.standin_charset("ch", shim._ncls(rec[0]))
+    ref_charset = P.standin_charset(shim._ncls(rec[0]))
+    frames, truth = synth.make_frames(nf, H, W, seed=100, return_truth=True)
+    pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="ragged", bucket=256, batch_round=4, min_rec_group=8)
+    mh, mw = pipeline.det_resize_shape(H, W, pipe.limit)
+    overlay = bench.text_kernel_maps(truth, H, W, mh, mw, unclip_ratio=pipe.db["unclip_ratio"])
+    dev = torch.from_numpy(frames).cuda()
+    maps = pipe.det_maps(dev)
+    torch.maximum(maps, torch.from_numpy(overlay).cuda(), out=maps)
+    got_boxes = [pipeline.sorted_boxes(b[0]) for b in ctx.db_postprocess(maps, H, W, **pipe.db)]
+    got_res = pipe.recognize(dev, got_boxes)
+    maps_h = maps.cpu().numpy()
+    nbox = nexact = 0
+    for f in range(nf):
+        x, _ = P.det_preprocess(frames[f])
+        ref_map = np.maximum(net_ref.run_graph(det[0], det[1], x)[0].numpy()[0, 0], overlay[f])
+        assert np.abs(maps_h[f] - ref_map).max() < 4e-2
+        rb = P.sorted_boxes(P.db_postprocess(ref_map, H, W)[0])
+        assert len(rb) == len(got_boxes[f]) > 0
+        for a, b in zip(got_boxes[f], rb):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), (f, a, b)          # identical integers
+        crops = [P.get_rotate_crop_image(frames[f], b) for b in rb]
+        for idx, img_w in P.rec_batches(crops, 6):
+            batch = np.stack([P.resize_norm_img(crops[i], img_w) for i in idx])
+            probs = net_ref.run_graph(rec[0], rec[1], batch)[0].numpy()
+            for k, i in enumerate(idx):
+                ids, conf = P.ctc_greedy(probs[k])
+                ref_text = P.decode_text(ids, ref_charset)
+                text, score = got_res[f][i]
+                srt = np.sort(probs[k], -1)
+                shaky = int(((srt[:, -1] - srt[:, -2]) < 0.05 * srt[:, -1]).sum())
+                edits = [o for o in difflib.SequenceMatcher(None, text, ref_text).get_opcodes() if o[0] != "equal"]
+                assert len(edits) <= shaky, (text, ref_text, shaky)
+                if not edits:
+                    assert abs(score - conf) < 1e-3, (score, conf)      # mean of the max probabilities of the kept steps
+                    nexact += 1
+                nbox += 1
+    assert nbox >= nf and nexact >= 1
+    print(f"C2 path vs oracle: {nbox} boxes identical, {nexact} / {nbox} strings identical (the rest inside the oracle's top-2 margin)")

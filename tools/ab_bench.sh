@@ -11,7 +11,7 @@ if [ "$1" = prepare ]; then
 else
   for i in 1 2 3; do
     for T in build/ab/old .; do
-      (cd $R/$T && python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$T', d['value'], d['ms_per_step'])")
+      (cd $R/$T && python bench.py --no-cpu-baseline --no-roofline --no-secondary 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$T', d['value'], d['ms_per_step'])")
     done
   done
 fi

@@ -21,20 +21,22 @@ def main():
     desc, wts = net_ref.get_weights(mid)
     x = np.random.default_rng(0).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)
     x8 = ir_emul.to_nhwc8(x)
-    prog = compiler.compile_model(desc, wts, n, h, w, reuse=False)
+    hilo = "--hilo" in sys.argv          # fp16 hi + lo weights; 1x1 / depthwise chains (OP_CHAIN) with them
+    prog = compiler.compile_model(desc, wts, n, h, w, reuse=False, hilo=hilo)
     em = ir_emul.Emulator(prog, round_f16=True)
     ref_outs = em.run(x8)
     ctx = engine.Context(0)
-    net = engine.Net(ctx, desc, wts)
+    net = engine.Net(ctx, desc, wts, hilo=hilo)
     net.plans[(n, h, w)] = [prog, None]
     net.store = prog.weights
     xt = torch.from_numpy(x8.astype(np.float16)).cuda()
     outs = net.run(xt)
     torch.cuda.synchronize()
-    ws = net.ws[(n, h, w)].cpu().numpy()
+    ws = net.ws[((n, h, w), 0)].cpu().numpy()
     bad = 0
-    for k, r in enumerate(prog.ops):
-        v = r["out"]
+    views = [(k, r, r[slot]) for k, r in enumerate(prog.ops)
+             for slot in (("out", "out2", "in2") if int(r["kind"]) == ir.OP_CHAIN else ("out",)) if int(r[slot]["n"]) > 0]
+    for k, r, v in views:
         if int(v["arena"]) != ir.ARENA_WS:
             continue
         nn, hh, ww, cc, ld, es = (int(v[q]) for q in ("n", "h", "w", "c", "ld", "esize"))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the other configurations of BASELINE.json + the sequential form, same build, one box (secondary figures of profiles/README.md)
-run() { echo -n "$*: "; python bench.py "$@" --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
+run() { echo -n "$*: "; python bench.py "$@" --no-cpu-baseline --no-roofline --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
 run
 run --no-overlap
 run --det-depth 1

@@ -29,6 +29,7 @@ import os
 import numpy as np
 
 from . import ir
+from .chains import ChainMixin
 
 
 def rup(x, m):
@@ -49,6 +50,7 @@ class Buf:
     last: int = -1
     offset: int = 0
     wl: Optional[int] = None       # ragged plans: width level of the tensor (index into Program.wlevels); None = no width
+    lo_off: int = 0                # hi + lo PAIR tensor: channels [lo_off, 2 lo_off) of every pixel hold fp16(x - fp16(x)); 0 = plain fp16
 
     @property
     def nbytes(self):
@@ -196,6 +198,7 @@ COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
 # ACROSS plans of one process; a different value is a different set of summation orders)
 RAGGED_SEL_W = int(os.environ.get("VSE_RAGGED_SELW", "768"))
 ONECH = os.environ.get("VSE_ONECH", "1") != "0"             # DB head: last transposed conv stores the fp32 map directly
+SE_LATERAL = os.environ.get("VSE_SE_LATERAL", "1") != "0"   # 1x1 conv + SE block with shortcut -> one gated conv (F_OGATE)
 LSTM_MFMA = os.environ.get("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
 LSTM_WAVES = int(os.environ.get("VSE_LSTM_WAVES", "16"))    # 8: lstm_mfma_kernel, 16: lstm_mfma16_kernel (twice the loads in flight)
 
@@ -249,7 +252,7 @@ def check_attrs(ops):
                                        f"implement {k}={v!r} only)")
 
 
-class Compiler:
+class Compiler(ChainMixin):
     def __init__(self, desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True,
                  store=None, reuse=True):
         self.desc = desc
@@ -268,6 +271,8 @@ class Compiler:
         self.input_norm = None                # (mean3, std3): see fold_input_norm
         self.fuse_preprocess = False          # with input_norm: the stem conv reads the uint8 frames and resizes them itself (F_U8SRC)
         self._merge_parallel_convs()
+        if SE_LATERAL:
+            self._rewrite_se_laterals()
         self.N, self.H, self.Wd = batch, height, width
         self.fetch_cols = tuple(fetch_cols)
         self.want_probs = want_probs
@@ -385,6 +390,86 @@ class Compiler:
                 changed = True
                 break
 
+    def _rewrite_se_laterals(self):
+        """x = conv1x1(c);  o = x + x * hsigmoid(fc2(relu(fc1(avgpool(x)))))   (PaddleOCR RSELayer with shortcut, the laterals of
+        the mobile detectors' RSE-FPN: 96 channels at up to 136 x 240 from a 12..56-channel input)
+        ->  avgpool(x) = conv1x1(avgpool(c)) — a 1x1 conv without padding commutes with the spatial mean —, so the gate is computed
+        from the mean of the NARROW input, and  o = conv1x1(c) * (1 + gate)  is ONE conv with an output gate in its epilogue
+        (F_OGATE).  x (the widest tensor of the neck), its pooling pass, the multiply and the add are never executed; the top-down
+        add behind o then rides in the same epilogue as a residual.  Exact in real arithmetic."""
+        changed = True
+        while changed:
+            changed = False
+            prod, cons = {}, {}
+            for i, op in enumerate(self.ops):
+                for outs in op["out"].values():
+                    for o in outs:
+                        prod.setdefault(o, i)
+                for ins in op["in"].values():
+                    for nme in ins:
+                        cons.setdefault(nme, []).append(i)
+
+            def single(name, typ):
+                c = cons.get(name, [])
+                return c[0] if len(c) == 1 and self.ops[c[0]]["type"] == typ else None
+            for ic, op in enumerate(self.ops):
+                if op["type"] != "conv2d" or "out_gate" in op["attrs"]:
+                    continue
+                a = op["attrs"]
+                w = self.W.get(op["in"]["Filter"][0])
+                if (w is None or tuple(w.shape[2:]) != (1, 1) or list(a["strides"]) != [1, 1] or any(a["paddings"]) or a.get("groups", 1) != 1
+                        or w.shape[0] % 8):
+                    continue
+                x = op["out"]["Output"][0]
+                cx = cons.get(x, [])
+                if len(cx) != 3 or sorted(self.ops[j]["type"] for j in cx) != ["elementwise_add", "elementwise_mul", "pool2d"]:
+                    continue
+                ipool = next(j for j in cx if self.ops[j]["type"] == "pool2d")
+                imul = next(j for j in cx if self.ops[j]["type"] == "elementwise_mul")
+                iadd = next(j for j in cx if self.ops[j]["type"] == "elementwise_add")
+                pa = self.ops[ipool]["attrs"]
+                if not (pa.get("pooling_type") == "avg" and (pa.get("adaptive", False) and list(pa.get("ksize", [])) == [1, 1] or pa.get("global_pooling", False))):
+                    continue
+                # pooled -> conv (+bias) -> relu -> conv (+bias) -> hard_sigmoid -> gate
+                nme = self.ops[ipool]["out"]["Out"][0]
+                ok = True
+                for typ in ("conv2d", "elementwise_add", "relu", "conv2d", "elementwise_add", "hard_sigmoid"):
+                    j = single(nme, typ)
+                    if j is None:
+                        ok = False
+                        break
+                    o2 = self.ops[j]
+                    nme = (o2["out"].get("Output") or o2["out"].get("Out"))[0]
+                if not ok:
+                    continue
+                gate = nme
+                mul, add = self.ops[imul], self.ops[iadd]
+                if sorted([mul["in"]["X"][0], mul["in"]["Y"][0]]) != sorted([x, gate]) or cons.get(gate, []) != [imul]:
+                    continue
+                m = mul["out"]["Out"][0]
+                if sorted([add["in"]["X"][0], add["in"]["Y"][0]]) != sorted([x, m]) or cons.get(m, []) != [iadd]:
+                    continue
+                cin_name = op["in"]["Input"][0]
+                pc = x + ":gap_of_input"
+                pool_c = {"type": "pool2d", "in": {"X": [cin_name]}, "out": {"Out": [pc]}, "attrs": dict(pa)}
+                conv_p = {"type": "conv2d", "in": {"Input": [pc], "Filter": list(op["in"]["Filter"])},
+                          "out": {"Output": [self.ops[ipool]["out"]["Out"][0]]}, "attrs": dict(a)}
+                gated = {"type": "conv2d", "in": dict(op["in"], Gate=[gate]), "out": {"Output": [add["out"]["Out"][0]]},
+                         "attrs": dict(a, out_gate=gate)}          # (the gate is an INPUT: liveness and ordering see it)
+                new_ops = []
+                for k, o in enumerate(self.ops):
+                    if k == ic:
+                        new_ops += [pool_c, conv_p]
+                    elif k == iadd:
+                        new_ops.append(gated)
+                    elif k in (ipool, imul):
+                        continue
+                    else:
+                        new_ops.append(o)
+                self.ops = new_ops
+                changed = True
+                break
+
     # -------------------------------------------------------------------------------------------- helpers
     def _mark_live(self):
         """Dead-code elimination backwards from the requested fetch columns."""
@@ -474,8 +559,24 @@ class Compiler:
         assert dims is not None and len(dims) == 4 and dims[1] > 0, (name, dims)
         return dims[1]
 
-    def alloc_out(self, name, n, h, w, c, esize=2):
-        """Output view for tensor `name`; lands inside a concat buffer slice when planned so."""
+    def wants_lo(self, name):
+        """The tensor feeds an OP_CHAIN (chains.py): store it as an fp16 hi + lo pair so that the chain computes on ~22 bits of it
+        instead of 11 — the one rounding per chain edge that is left once the intermediates live in LDS.  Ordinary consumers read
+        the hi half (a plain fp16 tensor with a wider pixel stride)."""
+        if not (getattr(self, "chain", False) and getattr(self, "chain_lo", True)) or self.ragged:
+            return False
+        if name in self.placement or name in self.fetched_names:
+            return False
+        return any(self._chain_candidate(j) is not None and self.ops[j]["in"]["Input"][0] == name for j in self._live_consumers(name))
+
+    def alloc_out(self, name, n, h, w, c, esize=2, lo=False):
+        """Output view for tensor `name`; lands inside a concat buffer slice when planned so.  lo: room for the lo half of an
+        fp16 hi + lo pair behind the hi channels of every pixel (Buf.lo_off)."""
+        if lo and esize == 2 and self.placement.get(name) is None:
+            span = rup(c, 8)
+            b = self.new_buf(n, h, w, 2 * span, esize)
+            b.lo_off = span
+            return View(b, 0, n, h, w, [(0, c)], span)
         cname = self.placement.get(name)
         if cname is not None and esize == 2:
             lay = self._concat_buf(cname, n, h, w)
@@ -768,6 +869,10 @@ class Compiler:
                             shift += pv
                     else:
                         break
+                elif (t == "elementwise_add" and allow_res and stage <= 1 and st["res"] is None
+                      and getattr(self, "chain_res", None) is not None and other in self.chain_res):
+                    st["res"] = ("chain", other)          # chains.py: the residual is a channel-minor LDS buffer of the same chain
+                    stage = 2
                 elif t == "elementwise_add" and allow_res and stage <= 1 and st["res"] is None:
                     rv = self.resolve(other)
                     if rv is None or rv.tag not in ("nchw", "btc", "tbc") or rv.segs != [(0, cout)]:
@@ -1086,7 +1191,7 @@ class Compiler:
         coutp, Kp = rup(cout, 8), rup(kh * kw * inv.span, ir.KT)
         bias = np.zeros(coutp, np.float32)
         bias[:cout] = ep["shift"]
-        out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
+        out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout, lo=self.wants_lo(ep["out_name"]))
         res = ep["res"]
         flags = 0
         # width the kernel selection sees: the map's own — or, in a ragged plan, the map width of a nominal sample, so that a
@@ -1230,6 +1335,17 @@ class Compiler:
                     ins.append(None)
                 ins.append(wview)
         b_off = self.add_weights(("convb", wname, ep["out_name"]), bias)
+        if a.get("out_gate") is not None:
+            # an SE block with shortcut folded into this 1x1 conv (_rewrite_se_laterals): out = conv * (1 + gate[n, c]) (+ residual)
+            gv = self.resolve(a["out_gate"])
+            if (gv is None or (gv.h, gv.w) != (1, 1) or gv.c != cout or gv.segs != [(0, cout)] or gv.up or dot is not None
+                    or flags & (ir.F_SRC2 | ir.F_IMGW | ir.F_PATCH | ir.F_COL | ir.F_STEM) or ep["act"] != ir.ACT_NONE or ep["act2"] != ir.ACT_NONE):
+                raise UnsupportedGraph(f"gated conv {outname}: the gate / layer form is not supported (gate {gv and (gv.h, gv.w, gv.c, gv.segs, gv.up)}, "
+                                       f"flags {flags:#x}, act {ep['act']}/{ep['act2']}, dot {dot is not None})")
+            flags |= ir.F_OGATE
+            while len(ins) < 2:
+                ins.append(None)
+            ins.append(gv)
         if dot is not None:
             aux_off = self.add_weights(("dot1", dot["wname"], ep["out_name"]), dot["w"])
             self.emit(ir.OP_CONV, dot["out_name"], ins, dot["view"], flags=flags | ir.F_DOT1,
@@ -1246,7 +1362,8 @@ class Compiler:
         self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
                      ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"], ir.P_COUT: coutp, ir.P_KTOT: Kp,
-                     ir.P_INSHIFT: inv_main.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span, ir.P_IN2SHIFT: in2shift},
+                     ir.P_INSHIFT: inv_main.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span, ir.P_IN2SHIFT: in2shift,
+                     ir.P_LO_OUT: out.buf.lo_off},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                      ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
         self.add_gmacs(inv.n * oh * ow * cin * cout * self.merged_gmac_credit.get(wname, kh * kw) / 1e9)
@@ -1713,7 +1830,8 @@ class Compiler:
             elif t == "fetch":
                 self._lower_fetch(i)
             elif t in ("conv2d", "depthwise_conv2d", "conv2d_transpose"):
-                self.lower_conv(i)
+                if not self.try_lower_chain(i):
+                    self.lower_conv(i)
             elif t == "batch_norm":
                 raise NotImplementedError(f"stand-alone batch_norm at op {i}")
             elif t == "pool2d":
@@ -1822,7 +1940,7 @@ class Compiler:
 
 
 def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True, hilo=False,
-                  ragged=False, input_norm=None, fuse_preprocess=False):
+                  ragged=False, input_norm=None, fuse_preprocess=False, chain=None):
     """reuse=False gives every buffer its own workspace range (debugging: all intermediates stay readable).
     hilo=True stores every conv / depthwise / transposed-conv weight as an fp16 hi + lo pair (F_HILO): ~22-bit weights for
     twice the MFMA work — for nets whose boxes must track an fp32 reference closely.
@@ -1833,6 +1951,8 @@ def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_pro
     c.hilo = bool(hilo)
     c.input_norm = input_norm      # (mean3, std3): the plan takes RAW resized pixels + a ones channel (Compiler.fold_input_norm)
     c.fuse_preprocess = bool(fuse_preprocess)    # ... and resizes them itself from the uint8 frames (F_U8SRC): the plan input IS the frames
+    c.chain = bool(hilo) if chain is None else bool(chain)      # 1x1 / depthwise chains as OP_CHAIN (chains.py): the hi + lo nets (mobile detectors)
+    c.chain_lo = os.environ.get("VSE_CHAIN_LO", "1") != "0"     # tensors that feed a chain are stored as fp16 hi + lo pairs
     if c.hilo:
         c.use_patch = False          # conv_patch_kernel has no two-pass K walk (the implicit-GEMM, stem and column kernels do)
     return c.compile()

@@ -34,6 +34,9 @@ struct ConvParams {
     long wimg_stride;       // F_IMGW: weight elements per image (Kp * Np); M tiles are then aligned to images
     int hw_img, tiles_img;  // F_IMGW: output pixels per image, M tiles per image
     const int* wl_out;      // ragged plans: per-image output width; pixels at ow >= wl_out[n] are stored as zeros
+    int lo_off;             // != 0: fp16 hi + lo pair output: fp16(v - fp16(v)) goes lo_off channels behind the hi value
+    const half_t* ogate;    // F_OGATE: per-(image, cout) gate [n][ogate_ld] fp16; the value is multiplied by (1 + gate) ahead of the residual
+    int ogate_ld;
     const uint8_t* u8src;   // F_U8SRC (stem): uint8 BGR frames [n][u8_h][u8_w][3], row pitch / frame stride in bytes
     int u8_h, u8_w;
     long u8_pitch, u8_fstride;
@@ -212,6 +215,17 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
             opix[g] = (n * (2 * p.OH) + 2 * oh + (quad >> 1)) * (2L * p.OW) + 2 * ow + (quad & 1);
         }
     }
+    if (p.ogate != nullptr) {
+        // an SE block with shortcut behind a 1x1 conv, x + x * gate(mean(x)), folded into the conv: the gate comes from the mean
+        // of the conv's INPUT (the mean commutes with a 1x1 conv), so x itself is never written (compiler.py _rewrite_se_laterals)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (!live[g]) continue;
+            const half8 g8 = *reinterpret_cast<const half8*>(p.ogate + n * p.ogate_ld + oc[g]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[g * 8 + e] *= 1.0f + (float)g8[e];
+        }
+    }
     if (has_res) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -253,8 +267,15 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
         } else {
             half_t* op = reinterpret_cast<half_t*>(p.out) + opix[g] * p.out_ld + oc[g];
             if (p.vec16) {
-                *reinterpret_cast<half8*>(op) = half8{(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3],
-                                                      (half_t)w[4], (half_t)w[5], (half_t)w[6], (half_t)w[7]};
+                const half8 hi8 = half8{(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3],
+                                        (half_t)w[4], (half_t)w[5], (half_t)w[6], (half_t)w[7]};
+                *reinterpret_cast<half8*>(op) = hi8;
+                if (p.lo_off) {          // the tensor feeds an OP_CHAIN: what fp16 dropped travels beside it (launch_conv checks vec16)
+                    half8 lo8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) lo8[e] = (half_t)(w[e] - (float)hi8[e]);
+                    *reinterpret_cast<half8*>(op + p.lo_off) = lo8;
+                }
             } else {
                 *reinterpret_cast<half4*>(op) = half4{(half_t)w[0], (half_t)w[1], (half_t)w[2], (half_t)w[3]};
                 *reinterpret_cast<half4*>(op + 4) = half4{(half_t)w[4], (half_t)w[5], (half_t)w[6], (half_t)w[7]};

@@ -287,6 +287,17 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.in2_hs = a.in2.h; p.in2_ws = a.in2.w; p.nv0 = a.in.c >> 3;
     p.wimg_stride = 0; p.hw_img = 0; p.tiles_img = 0;
     p.wl_out = a.wl_out;
+    p.lo_off = a.lo_off;
+    if (a.lo_off && (!p.vec16 || (a.flags & (F_OUT_F32 | F_ONECH | F_DOT1 | F_UP2HEAD)) || (a.lo_off & 7) || a.out.ld < a.lo_off + a.Np / ((a.flags & F_PIXSHUF) ? 4 : 1)))
+        return VSE_E_INVAL;
+    p.ogate = nullptr; p.ogate_ld = 0;
+    if (a.flags & F_OGATE) {
+        // (in2 carries the gate: not combined with the other users of that slot)
+        if ((a.flags & (F_SRC2 | F_IMGW | F_PIXSHUF | F_DOT1 | F_UP2HEAD)) || !a.in2.ptr || a.in2.esize != 2 || a.in2.n != a.in.n || a.in2.h != 1 || a.in2.w != 1
+            || a.in2.c < a.Np || (a.in2.ld & 7) || (reinterpret_cast<uintptr_t>(a.in2.ptr) & 15)) return VSE_E_INVAL;
+        p.ogate = reinterpret_cast<const half_t*>(a.in2.ptr);
+        p.ogate_ld = a.in2.ld;
+    }
     p.u8src = a.u8src; p.u8_h = a.u8_h; p.u8_w = a.u8_w; p.u8_pitch = a.u8_pitch; p.u8_fstride = a.u8_fstride;
     if ((a.flags & F_U8SRC) && (!(a.flags & F_STEM) || !a.u8src || a.u8_h <= 0 || a.u8_w <= 0)) return VSE_E_INVAL;
     if (a.wl_out && (a.flags & (F_DOT1 | F_SRC2 | F_UP2HEAD | F_PIXSHUF))) return VSE_E_UNSUPPORTED;   // no per-sample width in these forms

@@ -128,7 +128,7 @@ int vse_plan_create(vse_ctx* c, int weights_id, const vse_op* ops, int n_ops, si
     const size_t wbytes = c->weight_bytes[weights_id];
     for (int i = 0; i < n_ops; ++i) {
         const vse_op& o = ops[i];
-        if (o.kind < OP_CONV || o.kind > OP_WSCALE) {
+        if (o.kind < OP_CONV || o.kind > OP_CHAIN) {
             set_err("op %d: unknown kind %d", i, o.kind);
             delete p;
             return VSE_E_INVAL;
@@ -210,12 +210,15 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, const int32_t*
         a.in2 = in2; a.in2shift = o.p[P_IN2SHIFT];
         if (o.flags & F_IMGW) a.w = reinterpret_cast<const half_t*>(in2.ptr);      // per-image weights in the workspace
         a.wl_out = wl_out;
+        a.lo_off = o.p[P_LO_OUT];
         a.u8src = nullptr; a.u8_h = a.u8_w = 0; a.u8_pitch = a.u8_fstride = 0;
         if (o.flags & F_U8SRC) {
             a.u8src = reinterpret_cast<const uint8_t*>(ext[0]);
             a.u8_h = src.h; a.u8_w = src.w; a.u8_pitch = src.pitch; a.u8_fstride = src.fstride;
         }
         rc = launch_conv(a, st);
+    } else if (o.kind == OP_CHAIN) {
+        rc = launch_chain(o, in0, out, out2, in2, wts, st);
     } else {
         rc = launch_simple_op(o, in0, in1, in2, out, out2, wts, wl_in, wl_out, st);
     }
@@ -415,9 +418,9 @@ const char* vse_plan_op_kernel_name(vse_plan* p, int i) {
     if (!p || i < 0 || i >= (int)p->ops.size()) return buf;
     const vse_op& o = p->ops[i];
     static const char* simple[] = {"", "", "dwconv_kernel", "pool_kernel", "gap_kernel", "scale_kernel", "binary_kernel", "resize_kernel",
-                                   "unary_kernel", "layernorm_kernel", "attn_kernel", "softmax_kernel", "lstm_kernel", "wscale_kernel"};
+                                   "unary_kernel", "layernorm_kernel", "attn_kernel", "softmax_kernel", "lstm_kernel", "wscale_kernel", "chain_kernel"};
     if (o.kind != OP_CONV) {
-        snprintf(buf, sizeof buf, "%s", (o.kind >= 2 && o.kind <= OP_WSCALE) ? simple[o.kind] : "?");
+        snprintf(buf, sizeof buf, "%s", (o.kind >= 2 && o.kind <= OP_CHAIN) ? simple[o.kind] : "?");
         return buf;
     }
     const int code = vse_plan_op_variant(p, i);

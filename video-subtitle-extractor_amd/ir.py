@@ -57,6 +57,7 @@ P_KTOT = 9          # padded K (multiple of KT)
 P_INSHIFT = 10      # nearest-upsample shift applied when gathering the input
 P_RESSHIFT = 11     # nearest-upsample shift applied when reading the residual
 P_CINP = 12         # physical input channels (multiple of 8)
+P_LO_OUT = 15       # != 0: the output is an fp16 hi + lo PAIR: fp16(v - fp16(v)) is stored P_LO_OUT channels behind the hi value
 # flags for OP_CONV
 F_RES = 1           # has residual (in1)
 F_PIXSHUF = 2       # 2x2 stride-2 transposed conv: N = 4*Coutp ordered (dy,dx,co)
@@ -77,6 +78,8 @@ F_IMGW = 8192       # OP_CONV (1x1 on conv_gemm_kernel): weights differ per imag
                     # OP_WSCALE): an SE gate folded into its 1x1 consumer; M tiles do not straddle images
 F_U8SRC = 65536     # OP_CONV | F_STEM reading the plan input: the input is the uint8 BGR frames and the kernel resizes them itself (cv2
                     # fixed-point bilinear, the bytes vse_det_preprocess writes in raw mode); frame geometry via vse_plan_set_source
+F_OGATE = 131072    # OP_CONV: in2 = gate [N,1,1,Cout] fp16; out = act(conv) * (1 + gate[n, c]) (+ residual): an SE block with shortcut
+                    # behind a 1x1 conv folded into it (Compiler._rewrite_se_laterals)
 F_ONECH = 32768     # OP_CONV with F_PIXSHUF | F_OUT_F32 and ONE real cout: the output is the 1-channel fp32 map itself (ld = 1); every
                     # lane's 8-channel run is one pixel-shuffle quad whose first channel is stored
 F_COL = 2048        # column-per-step LDS-patch kernel (conv_col.hip): weights packed [cinp/16][kw][kh][Np][16] + 3 zero stages
@@ -111,3 +114,26 @@ P_WLIN, P_WLOUT = 20, 21
 
 def empty_view():
     return np.zeros((), dtype=VIEW_DT)
+
+
+# ---- OP_CHAIN: a chain of 1x1 convs (PW) and depthwise convs (DW) with LDS-resident intermediates (csrc/chain.hip) -------------------
+# in0 = the chain's input (NHWC fp16), out / out2 / in2 = the (up to three) tensors it stores; w_off = the chain blob:
+#   int32 header[CH_HDR] | buffers[nbufs][CH_BUF] | stages[nstages][CH_STAGE] | (16-byte aligned) LDS image
+# The LDS image is copied to LDS offset 0 by every block: per PW stage the weight fragments of v_mfma_f32_32x32x16_f16 in lane order
+# ([pass hi, lo][cout tile][K slice][lane 64][8 halves]; lane l holds cout tile row conv_wrow(l & 31), k = 16 ks + 8 (l >> 5) + j)
+# followed by its fp32 bias [32 nct]; per DW stage one fp32 record per channel [k*k weights, bias, zeros up to a multiple of 4].
+OP_CHAIN = 14
+CH_MAGIC = 0x43484E31
+CH_HDR, CH_BUF, CH_STAGE = 16, 16, 28
+# header words
+CHH_MAGIC, CHH_NSTAGES, CHH_NBUFS, CHH_LDSW_BYTES, CHH_LDSIMG_OFF, CHH_LDS_TOTAL, CHH_TH, CHH_TW, CHH_TILES_H, CHH_TILES_W = range(10)
+# buffer words: kind 0 = channel-minor fp16 hi (+ lo) [pixel][Cp] with a pixel stride of 2 Cp + 16 bytes, 1 = planar fp32 [C][stride]
+(CHB_KIND, CHB_OFF_HI, CHB_OFF_LO, CHB_C, CHB_CP, CHB_STRIDE, CHB_TH, CHB_AH, CHB_EH, CHB_TW, CHB_AW, CHB_EW, CHB_P, CHB_HIMG,
+ CHB_WIMG) = range(15)
+# stage words (floats stored by bit pattern)
+(CHS_TYPE, CHS_IN, CHS_OUT, CHS_RES, CHS_CIN, CHS_COUT, CHS_NKS, CHS_NCT, CHS_K, CHS_S, CHS_PAD, CHS_ACT, CHS_ACT_A, CHS_ACT_B,
+ CHS_POST_A, CHS_POST_B, CHS_WLDS, CHS_BLDS, CHS_DWW, CHS_DWB, CHS_GOUT, CHS_MASK, CHS_HASLO, CHS_ACT2, CHS_SHUF) = range(25)
+CH_PW, CH_DW = 0, 1
+# op.p[] of an OP_CHAIN record
+P_CH_TILES_H, P_CH_TILES_W, P_CH_LDS, P_CH_NSTAGES, P_CH_NBUFS = 0, 1, 2, 3, 4
+P_CH_LO_IN, P_CH_LO_OUT0, P_CH_LO_OUT1, P_CH_LO_OUT2 = 10, 11, 12, 13     # channel offset of the lo half of a hi + lo tensor (0 = plain fp16)
