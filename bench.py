@@ -496,13 +496,17 @@ def roofline(pipe, step, repeats=2, steps_per_call=1):
                 if is_det:
                     det_conv[0] += float(ms[k])
                     det_conv[1] += float(prog.op_gmacs[k])
-                a = agg.setdefault(variants[k], [0.0, 0.0, 0])
+                a = agg.setdefault(variants[k], [0.0, 0.0, 0, 0.0])
                 a[0] += float(ms[k])
                 a[1] += float(prog.op_gmacs[k])
                 a[2] += 1
+                # algorithmic HBM bytes of the op: every tensor it touches once (input, residual / second source, output) + its weights
+                a[3] += sum(float(r[v]["n"]) * float(r[v]["h"]) * float(r[v]["w"]) * float(r[v]["c"]) * float(r[v]["esize"])
+                            for v in ("in0", "in1", "in2", "out", "out2") if int(r[v]["n"]) > 0) \
+                    + 2.0 * float(r["p"][ir.P_COUT]) * float(r["p"][ir.P_KTOT])
         pipe_last_sink = pipe.profile_sink
         pipe.profile_sink = None
-    bn, (tms, gmac, cnt) = max(agg.items(), key=lambda kv: kv[1][0])
+    bn, (tms, gmac, cnt, _bytes) = max(agg.items(), key=lambda kv: kv[1][0])
     kname = bn
     achieved = 2.0 * gmac / tms          # GMAC/ms*2 = TFLOP/s
     # HBM bytes per launch of that kernel from the newest committed PMC summary that has it (separate rocprofv3 --pmc FETCH_SIZE /
@@ -516,6 +520,7 @@ def roofline(pipe, step, repeats=2, steps_per_call=1):
             tsrc = "profiles/" + os.path.basename(tpath)
             break
     all_ms = sum(v[0] for v in agg.values())
+    assert all(len(v) == 4 for v in agg.values())
     # per-net totals of the last profiled step (diagnostics on stderr)
     per_net = {}
     for ms, prog, _v in pipe_last_sink:
@@ -540,9 +545,13 @@ def roofline(pipe, step, repeats=2, steps_per_call=1):
                                "ms_per_step": round(det_conv[0] / nsteps, 3)} if det_conv[0] > 0 else None,
             "conv_ms_per_step": round(all_ms / nsteps, 3),
             # the other conv kernel instantiations by share of conv time (same definition of `achieved` for each)
-            "kernels": [{"kernel": v, "share": round(t / all_ms, 3), "launches_per_step": round(c / nsteps, 1),
-                         "achieved": round(2.0 * g / t, 1), "frac": round(2.0 * g / t / MFMA_PEAK_TFLOPS, 3)}
-                        for v, (t, g, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:6]]}
+            # per instantiation: the roofline that BOUNDS it = the larger of (flops / MFMA peak) and (algorithmic bytes / HBM peak): the
+            # 1x1 aggregation convs on the 256 x 256 tile move ~200 FLOP per byte, under the ridge of 310 -> they are priced against HBM
+            "kernels": [dict({"kernel": v, "share": round(t / all_ms, 3), "launches_per_step": round(c / nsteps, 1),
+                              "achieved": round(2.0 * g / t, 1), "frac": round(2.0 * g / t / MFMA_PEAK_TFLOPS, 3),
+                              "hbm_gbs": round(b / t / 1e6, 1), "hbm_frac": round(b / t / 1e6 / HBM_PEAK_GBS, 3)},
+                             bound=("hbm" if b / (HBM_PEAK_GBS * 1e6) > 2.0 * g / MFMA_PEAK_TFLOPS else "mfma"))
+                        for v, (t, g, c, b) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:6]]}
 
 
 if __name__ == "__main__":

@@ -229,12 +229,26 @@ class Emulator:
             y = y * i2f(s[ir.CHS_POST_A]) + i2f(s[ir.CHS_POST_B])
             if int(s[ir.CHS_RES]) >= 0:
                 y = _act(y + bufs[int(s[ir.CHS_RES])], int(s[ir.CHS_ACT2]))
-            if int(s[ir.CHS_OUT]) >= 0:
-                ob = bw[int(s[ir.CHS_OUT])]
+            ob = bw[int(s[ir.CHS_OUT])]
+            assert (int(ob[ir.CHB_KIND]) == 2) == (j == n - 1)
+            # the tile geometry the kernel walks: a stage's input region must be exactly what its output region needs
+            ib = bw[int(s[ir.CHS_IN])]
+            pad_ = int(s[ir.CHS_PAD]) if int(s[ir.CHS_TYPE]) == ir.CH_DW else 0
+            for T, A, E in ((ir.CHB_TH, ir.CHB_AH, ir.CHB_EH), (ir.CHB_TW, ir.CHB_AW, ir.CHB_EW)):
+                assert int(ib[T]) == int(ob[T]) * st and int(ib[A]) == int(ob[A]) * st + pad_, (j, "tile / halo")
+                assert int(ib[E]) == (int(ob[E]) - 1) * st + k, (j, "extent")
+            assert int(ob[ir.CHB_P]) == int(ob[ir.CHB_EH]) * int(ob[ir.CHB_EW])
+            if int(ob[ir.CHB_KIND]) != 2:
                 assert int(ob[ir.CHB_C]) == cout and (int(ob[ir.CHB_HIMG]), int(ob[ir.CHB_WIMG])) == tuple(y.shape[2:])
                 bufs[int(s[ir.CHS_OUT])] = pair(y) if int(ob[ir.CHB_KIND]) == 0 else y
             g = int(s[ir.CHS_GOUT])
-            if g >= 0:
+            if g >= 0 and int(s[ir.CHS_SHUF]):
+                # channel 4 r + c of input pixel (y, x) = pixel (4 y + r, 4 x + c) of the 1-channel fp32 map
+                nb_, _c16, hh, ww = y.shape
+                assert _c16 == 16
+                m = y.reshape(nb_, 4, 4, hh, ww).permute(0, 3, 1, 4, 2).reshape(nb_, 4 * hh, 4 * ww, 1)
+                self.write(gviews[g], m)
+            elif g >= 0:
                 gv = gviews[g]
                 yo = y.permute(0, 2, 3, 1)
                 pc = int(gv["c"])

@@ -397,6 +397,8 @@ def test_mobile_detector_chains_and_gated_laterals(mid):
         hdr = np.frombuffer(bytes(prog.weights.blob[int(o["w_off"]):int(o["w_off"]) + 4 * ir.CH_HDR]), np.int32)
         assert hdr[ir.CHH_MAGIC] == ir.CH_MAGIC and 2 <= hdr[ir.CHH_NSTAGES] <= 8 and hdr[ir.CHH_LDS_TOTAL] <= 160 * 1024
         final_h = min(int(o[k]["h"]) for k in ("out", "out2", "in2") if int(o[k]["n"]) > 0)       # tiles cover the LAST stage's output
+        if int(o["out"]["esize"]) == 4:
+            final_h //= 4               # the head tail stores 4 x 4 map pixels per pixel of its last stage (CHS_SHUF)
         assert int(o["p"][ir.P_CH_TILES_H]) * hdr[ir.CHH_TH] >= final_h and int(o["p"][ir.P_CH_LDS]) == hdr[ir.CHH_LDS_TOTAL]
     # a tensor that feeds a chain is a pair: its producer stores the lo half, the chain reads it at the same offset
     lo_in = [int(o["p"][ir.P_CH_LO_IN]) for o in chains]

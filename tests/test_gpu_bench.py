@@ -57,9 +57,10 @@ def test_bench_configuration_c2_against_the_oracle_in_one_piece(ctx):
     from oracle import net_ref, pipeline_ref as P
     from vse_amd import pipeline, shim, synth
     nf, H, W = 4, 1080, 1920
-    det = net_ref.get_weights("V4_ch_det")
-    det = (det[0], bench.empty_det_head(det[0], dict(det[1])))        # what bench.py does to the stand-in detector
-    rec = net_ref.get_weights("V4_ch_rec")
+    from vse_amd import modelzoo
+    det = modelzoo.get_model("V4_ch_det", seed=0)                     # bench.py's own stand-in detector (seeded, uncalibrated) ...
+    det = (det[0], bench.empty_det_head(det[0], dict(det[1])))        # ... with its head pushed below the threshold, as bench.py does
+    rec = net_ref.get_weights("V4_ch_rec")                            # calibrated stand-in recogniser: a softmax that is not flat
     charset = shim.standin_charset("ch", shim._ncls(rec[0]))
     ref_charset = P.standin_charset(shim._ncls(rec[0]))
     frames, truth = synth.make_frames(nf, H, W, seed=100, return_truth=True)

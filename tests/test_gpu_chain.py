@@ -1,0 +1,61 @@
+"""OP_CHAIN (csrc/chain.hip) and the gated RSE laterals (F_OGATE) on the GPU, through the C ABI, against the CPU oracle.
+
+The mobile detectors (the reference's DEFAULT mode: backend/config.py:54 mode = fast -> backend/tools/paddle_model_config.py:53-58
+V4/ch_det_fast; V3/ch_det_fast is the one model whose real weights the checkout holds) are compiled with fp16 hi + lo weights, which
+turns their 1x1 / depthwise runs into chains whose intermediates never leave LDS, their laterals into gated convs and the DB head's
+two transposed convs into one chain that stores the fp32 map itself."""
+import numpy as np
+import pytest
+
+from oracle import net_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, desc, w, x, chain):
+    import torch
+    from vse_amd import engine
+    n, _, h, wd = x.shape
+    xt = torch.zeros((n, h, wd, 8), dtype=torch.float16, device="cuda")
+    xt[..., :3] = torch.from_numpy(x.transpose(0, 2, 3, 1)).cuda().half()
+    net = engine.Net(ctx, desc, w, fetch_cols=(0,), hilo=True, chain=chain)
+    out = net.run(xt)[0].float().cpu().numpy().reshape(n, h, wd)
+    return out, net.program(n, h, wd)
+
+
+@pytest.mark.parametrize("mid", ["V4_ch_det_fast", "V3_ch_det_fast"])
+@pytest.mark.parametrize("shape", [(1, 96, 160), (2, 160, 256), (1, 224, 352), (3, 64, 64), (1, 32, 608)])
+def test_chained_mobile_detector_matches_the_oracle(ctx, mid, shape):
+    """Tile tails in both directions, single-tile images, batches; chained and unchained programs against the fp32 interpreter."""
+    from vse_amd import ir
+    desc, w = net_ref.get_weights(mid)
+    n, h, wd = shape
+    x = np.random.default_rng(h * 7 + wd).uniform(-1, 1, (n, 3, h, wd)).astype(np.float16).astype(np.float32)
+    ref = net_ref.run_graph(desc, w, x)[0].numpy()[:, 0]
+    got, prog = _run(ctx, desc, w, x, True)
+    plain, prog0 = _run(ctx, desc, w, x, False)
+    kinds = [int(o["kind"]) for o in prog.ops]
+    assert kinds.count(ir.OP_CHAIN) >= 4 and ir.OP_CHAIN not in [int(o["kind"]) for o in prog0.ops]
+    assert int(prog.ops[-1]["kind"]) == ir.OP_CHAIN and int(prog.ops[-1]["out"]["esize"]) == 4       # the head tail stores the map
+    assert sum(bool(int(o["flags"]) & ir.F_OGATE) for o in prog.ops if int(o["kind"]) == ir.OP_CONV) == 4
+    e1, e0 = np.abs(got - ref).max(), np.abs(plain - ref).max()
+    assert np.isfinite(got).all() and e1 < max(5e-3, 2.0 * e0), (e1, e0)
+    assert np.abs(got - plain).max() < 5e-3
+
+
+def test_chained_detector_on_text_frames_tracks_the_oracle_closer(ctx):
+    """Real-weight detector on frames with text (where the map has structure): the chained program rounds a tensor to fp16 once
+    per chain instead of once per layer — its map must not be further from the fp32 oracle than the layer-by-layer program's."""
+    from oracle import pipeline_ref as P
+    from vse_amd import synth
+    desc, w = net_ref.get_weights("V3_ch_det_fast")
+    frames = synth.make_frames(2, 540, 960, seed=31)
+    x = np.concatenate([P.det_preprocess(f)[0] for f in frames])
+    x16 = x.astype(np.float16).astype(np.float32)
+    ref = net_ref.run_graph(desc, w, x16)[0].numpy()[:, 0]
+    got, _ = _run(ctx, desc, w, x16, True)
+    plain, _ = _run(ctx, desc, w, x16, False)
+    e1, e0 = np.abs(got - ref).max(), np.abs(plain - ref).max()
+    f1, f0 = int(((got > 0.3) != (ref > 0.3)).sum()), int(((plain > 0.3) != (ref > 0.3)).sum())
+    print(f"max |map - oracle|: chained {e1:.4f}, layer by layer {e0:.4f}; pixels on the other side of 0.3: {f1} vs {f0}")
+    assert ref.max() > 0.5 and e1 <= e0 * 1.05 + 1e-4 and f1 <= f0 + 1

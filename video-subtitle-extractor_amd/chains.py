@@ -333,7 +333,79 @@ class ChainMixin:
         self._chain_emit(stages, plan, inv, gouts)
         return True
 
-    def _chain_emit(self, stages, plan, inv, gouts):
+    def try_lower_head_tail(self, i0):
+        """The DB head's tail: conv2d_transpose(c0 -> c1, 2x2 s2) + BN + relu -> conv2d_transpose(c1 -> 1, 2x2 s2) + sigmoid -> fetch
+        as ONE chain of two 1x1 convs: stage A = the first transposed conv as a 1x1 conv to 4 c1 channels ordered (dy, dx, co);
+        stage B = the second one applied to each of the four sub-pixels: a block-diagonal 1x1 conv 4 c1 -> 16 whose channel
+        4 r + c is output pixel (4 y + r, 4 x + c) of input pixel (y, x); the kernel stores those 4 x 4 blocks of the fp32 map itself
+        (CHS_SHUF).  The c1-channel tensor at twice the resolution (24 x 272 x 480 per frame, written and read back: 16 MB of the
+        mobile detectors' 200 MB per frame) never exists."""
+        if not (CHAIN and getattr(self, "chain", False)) or self.ragged:
+            return False
+        op0 = self.ops[i0]
+        if op0["type"] != "conv2d_transpose":
+            return False
+        w1 = self.W[op0["in"]["Filter"][0]]
+        a0 = op0["attrs"]
+        if tuple(w1.shape[2:]) != (2, 2) or list(a0["strides"]) != [2, 2] or any(a0["paddings"]) or w1.shape[0] % 8:
+            return False
+        inv = self.resolve(op0["in"]["Input"][0])
+        if inv is None or inv.parts is not None or inv.up or inv.segs != [(0, inv.c)] or inv.c != w1.shape[0] or inv.buf.esize != 2:
+            return False
+        snapshot = set(self.done)
+        c0, c1 = int(w1.shape[0]), int(w1.shape[1])
+        ep1 = self.absorb_epilogue(op0["out"]["Output"][0], i0, c1, allow_res=False)
+        cons = self._live_consumers(ep1["out_name"])
+        ok = len(cons) == 1 and self.ops[cons[0]]["type"] == "conv2d_transpose" and ep1["out_name"] not in self.placement
+        if ok:
+            op1 = self.ops[cons[0]]
+            w2 = self.W[op1["in"]["Filter"][0]]
+            a1 = op1["attrs"]
+            ok = (tuple(w2.shape) == (c1, 1, 2, 2) and list(a1["strides"]) == [2, 2] and not any(a1["paddings"])
+                  and ep1["post_a"] == 1.0 and ep1["post_b"] == 0.0 and ep1["act2"] == ir.ACT_NONE)
+        if ok:
+            ep2 = self.absorb_epilogue(op1["out"]["Output"][0], cons[0], 1, allow_res=False)
+            fc = self._live_consumers(ep2["out_name"])
+            ok = (len(fc) == 1 and self.ops[fc[0]]["type"] == "fetch" and ep2["act2"] == ir.ACT_NONE
+                  and ep2["post_a"] == 1.0 and ep2["post_b"] == 0.0)
+        if not ok:
+            self.done = snapshot
+            return False
+        self.done.add(i0)
+        self.done.add(cons[0])
+        c1p = rup(c1, 8)
+        # stage A: W_A[(dy, dx, co), ci] = w1[ci, co, dy, dx] * scale1[co]
+        wa = np.zeros((4 * c1p, c0), np.float64)
+        ba = np.zeros(4 * c1p, np.float64)
+        for dy in range(2):
+            for dx in range(2):
+                q = (dy * 2 + dx) * c1p
+                wa[q:q + c1] = (w1[:, :, dy, dx].astype(np.float64) * ep1["scale"].reshape(1, -1)).T
+                ba[q:q + c1] = ep1["shift"]
+        # stage B: channel 4 r + c (r = 2 dy + ey, c = 2 dx + ex) reads sub-pixel (dy, dx) through tap (ey, ex) of the second conv
+        wb = np.zeros((16, 4 * c1p), np.float64)
+        for r in range(4):
+            for c in range(4):
+                q = ((r >> 1) * 2 + (c >> 1)) * c1p
+                wb[4 * r + c, q:q + c1] = w2[:, 0, r & 1, c & 1].astype(np.float64) * float(ep2["scale"][0])
+        bb = np.full(16, float(ep2["shift"][0]), np.float64)
+        na, nb = op0["in"]["Filter"][0] + ":head_tail_a", op1["in"]["Filter"][0] + ":head_tail_b"
+        self.W[na], self.W[nb] = wa.reshape(4 * c1p, c0, 1, 1), wb.reshape(16, 4 * c1p, 1, 1)
+        one = lambda n_: np.ones(n_, np.float64)
+        epa = dict(ep1, scale=one(4 * c1p), shift=ba, res=None, out_name=ep1["out_name"])
+        epb = dict(ep2, scale=one(16), shift=bb, res=None, out_name=ep2["out_name"])
+        stages = [dict(type="pw", k=1, s=1, cin=c0, cout=4 * c1p, op=i0, wname=na, ep=epa, in_name=op0["in"]["Input"][0],
+                       out_name=ep1["out_name"], res_buf=-1, res_abs=-1, gout=-1),
+                  dict(type="pw", k=1, s=1, cin=4 * c1p, cout=16, op=cons[0], wname=nb, ep=epb, in_name=ep1["out_name"],
+                       out_name=ep2["out_name"], res_buf=-1, res_abs=-1, gout=0, shuf=1)]
+        plan = self._chain_plan(stages, inv.h, inv.w, bool(getattr(inv.buf, "lo_off", 0)))
+        if plan is None:
+            self.done = snapshot
+            return False
+        self._chain_emit(stages, plan, inv, [1], map_out=True, macs_override=inv.n * inv.h * inv.w * (c0 * c1 * 4 + 4 * c1 * 4))
+        return True
+
+    def _chain_emit(self, stages, plan, inv, gouts, map_out=False, macs_override=None):
         n = len(stages)
         bufs, regs, dims = plan["bufs"], plan["regs"], plan["dims"]
         N = inv.n
@@ -341,8 +413,13 @@ class ChainMixin:
         tiles_h, tiles_w = -(-oh // plan["th"]), -(-ow // plan["tw"])
         hdr = np.zeros(ir.CH_HDR, np.int32)
         hdr[[ir.CHH_MAGIC, ir.CHH_NSTAGES, ir.CHH_NBUFS, ir.CHH_LDSW_BYTES, ir.CHH_LDS_TOTAL, ir.CHH_TH, ir.CHH_TW, ir.CHH_TILES_H,
-             ir.CHH_TILES_W]] = [ir.CH_MAGIC, n, n, plan["wbytes"], plan["lds_total"], plan["th"], plan["tw"], tiles_h, tiles_w]
-        bw = np.zeros((n, ir.CH_BUF), np.int32)
+             ir.CHH_TILES_W]] = [ir.CH_MAGIC, n, n + 1, plan["wbytes"], plan["lds_total"], plan["th"], plan["tw"], tiles_h, tiles_w]
+        bw = np.zeros((n + 1, ir.CH_BUF), np.int32)
+        # buffer n = the REGION of the last stage's output (kind 2: it is stored to global memory only; the kernel needs its tile
+        # geometry all the same — a depthwise last stage indexes its output pixels by it)
+        rl = regs[n]
+        bw[n, :15] = [2, 0, -1, stages[-1]["cout"], stages[-1]["cout"], 0, rl["Th"], rl["ah"], rl["Eh"], rl["Tw"], rl["aw"], rl["Ew"],
+                      rl["Eh"] * rl["Ew"], dims[n][0], dims[n][1]]
         for j, b in enumerate(bufs):
             r = b["reg"]
             bw[j, :15] = [b["kind"], b["off"], (b["off"] + b["size"] // 2) if b["lo"] else -1, b["C"], b["Cp"], b["stride"],
@@ -358,9 +435,10 @@ class ChainMixin:
             is_pw = st["type"] == "pw"
             nxt_dw = j + 1 < n and stages[j + 1]["type"] == "dw"
             row[[ir.CHS_TYPE, ir.CHS_IN, ir.CHS_OUT, ir.CHS_RES, ir.CHS_CIN, ir.CHS_COUT, ir.CHS_K, ir.CHS_S, ir.CHS_PAD, ir.CHS_ACT,
-                 ir.CHS_GOUT, ir.CHS_MASK, ir.CHS_ACT2]] = [ir.CH_PW if is_pw else ir.CH_DW, j, j + 1 if j + 1 < n else -1, st["res_buf"],
+                 ir.CHS_GOUT, ir.CHS_MASK, ir.CHS_ACT2]] = [ir.CH_PW if is_pw else ir.CH_DW, j, j + 1, st["res_buf"],
                                                             st["cin"], st["cout"], st["k"], st["s"], st["k"] // 2, ep["act"],
                                                             st["gout"], 1 if nxt_dw else 0, ep["act2"]]
+            row[ir.CHS_SHUF] = int(st.get("shuf", 0))
             row[ir.CHS_ACT_A], row[ir.CHS_ACT_B] = f2i(ep["act_a"]), f2i(ep["act_b"])
             row[ir.CHS_POST_A], row[ir.CHS_POST_B] = f2i(ep["post_a"]), f2i(ep["post_b"])
             h_out, w_out = dims[j + 1]
@@ -399,7 +477,14 @@ class ChainMixin:
         for g, j in enumerate(gouts):
             st = stages[j]
             h_out, w_out = dims[j + 1]
-            v = self.alloc_out(st["out_name"], N, h_out, w_out, st["cout"], lo=self.wants_lo(st["out_name"]))
+            if map_out:
+                # CHS_SHUF: the stage's 16 channels are the 4 x 4 output pixels of every input pixel: the 1-channel fp32 map itself
+                from .compiler import View
+                ob = self.new_buf(N, 4 * h_out, 4 * w_out, 1, esize=4, ext=len(self.outputs) + 1)
+                self.outputs.append(dict(name=st["out_name"], kind="map", n=N, h=4 * h_out, w=4 * w_out, c=1, ld=1, esize=4))
+                v = View(ob, 0, N, 4 * h_out, 4 * w_out, [(0, 1)], 1)
+            else:
+                v = self.alloc_out(st["out_name"], N, h_out, w_out, st["cout"], lo=self.wants_lo(st["out_name"]))
             outs.append(v)
             self.env[st["out_name"]] = v
         key = ("chain", tuple(st["wname"] for st in stages), tuple(st["out_name"] for st in stages), plan["th"], plan["tw"], inv.h, inv.w,
@@ -408,13 +493,13 @@ class ChainMixin:
         ins = [inv, None, outs[2] if len(outs) > 2 else None]
         name = "chain:" + "+".join(st["out_name"] for st in stages)
         self.emit(ir.OP_CHAIN, name[:200], ins, outs[0], p={ir.P_CH_TILES_H: tiles_h, ir.P_CH_TILES_W: tiles_w, ir.P_CH_LDS: plan["lds_total"],
-                                                             ir.P_CH_NSTAGES: n, ir.P_CH_NBUFS: n,
+                                                             ir.P_CH_NSTAGES: n, ir.P_CH_NBUFS: n + 1,
                                                              ir.P_CH_LO_IN: int(getattr(inv.buf, "lo_off", 0) or 0),
                                                              ir.P_CH_LO_OUT0: outs[0].buf.lo_off,
                                                              ir.P_CH_LO_OUT1: outs[1].buf.lo_off if len(outs) > 1 else 0,
                                                              ir.P_CH_LO_OUT2: outs[2].buf.lo_off if len(outs) > 2 else 0},
                   w_off=w_off, out2=outs[1] if len(outs) > 1 else None)
-        self.add_gmacs(macs / 1e9)
+        self.add_gmacs((macs if macs_override is None else macs_override) / 1e9)
         self.ir_ops[-1]["chain"] = dict(stages=[dict(type=st["type"], k=st["k"], s=st["s"], cin=st["cin"], cout=st["cout"], gout=st["gout"],
                                                      res_buf=st["res_buf"]) for st in stages], th=plan["th"], tw=plan["tw"],
                                         lds=plan["lds_total"], meta=meta)

@@ -567,7 +567,18 @@ class Compiler(ChainMixin):
             return False
         if name in self.placement or name in self.fetched_names:
             return False
-        return any(self._chain_candidate(j) is not None and self.ops[j]["in"]["Input"][0] == name for j in self._live_consumers(name))
+        for j in self._live_consumers(name):
+            o = self.ops[j]
+            if o["type"] not in ("conv2d", "depthwise_conv2d") or o["in"]["Input"][0] != name:
+                continue
+            if self._chain_candidate(j) is not None:
+                return True
+            wj = self.W[o["in"]["Filter"][0]]
+            a = o["attrs"]
+            if (o["type"] == "conv2d" and a.get("groups", 1) == 1 and tuple(wj.shape[2:]) == (1, 1) and list(a["strides"]) == [1, 1]
+                    and not any(a["paddings"])):
+                return True          # a plain 1x1 conv reads both halves as input channels (lower_conv, pair_in)
+        return False
 
     def alloc_out(self, name, n, h, w, c, esize=2, lo=False):
         """Output view for tensor `name`; lands inside a concat buffer slice when planned so.  lo: room for the lo half of an
@@ -1185,6 +1196,17 @@ class Compiler(ChainMixin):
             return
         cout, cin, kh, kw = w.shape
         assert cin == inv.c, (cin, inv.c, outname)
+        pair_in = False
+        if (getattr(self, "chain", False) and getattr(self, "chain_lo", True) and (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0)
+                and inv.buf is not None and inv.buf.lo_off and inv.parts is None and inv.up == 0 and inv.coff == 0
+                and inv.segs == [(0, inv.c)] and op["in"]["Input"][0] not in self.pending_wgate):
+            # the input is an fp16 hi + lo PAIR (it also feeds an OP_CHAIN, or was stored for this conv): a 1x1 conv consumes both
+            # halves with NO kernel change — the lo channels are more input channels with the same weights, W hi + W lo
+            pair_in = True
+            lo_off = inv.buf.lo_off
+            inv = View(inv.buf, 0, inv.n, inv.h, inv.w, [(0, inv.c), (lo_off, inv.c)], 2 * lo_off, 0, inv.tag)
+            w = np.concatenate([w, w], axis=1)
+            cin *= 2
         oh = (inv.h + 2 * ph - kh) // sh + 1
         ow = (inv.w + 2 * pw - kw) // sw + 1
         ep = self.absorb_epilogue(outname, i, cout, out_dims=(inv.n, oh, ow))
@@ -1366,7 +1388,7 @@ class Compiler(ChainMixin):
                      ir.P_LO_OUT: out.buf.lo_off},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                      ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
-        self.add_gmacs(inv.n * oh * ow * cin * cout * self.merged_gmac_credit.get(wname, kh * kw) / 1e9)
+        self.add_gmacs(inv.n * oh * ow * (cin // 2 if pair_in else cin) * cout * self.merged_gmac_credit.get(wname, kh * kw) / 1e9)
         self.env[ep["out_name"]] = out
 
     def lower_dwconv(self, i, inv, w, sh, sw, ph, pw):
@@ -1830,7 +1852,7 @@ class Compiler(ChainMixin):
             elif t == "fetch":
                 self._lower_fetch(i)
             elif t in ("conv2d", "depthwise_conv2d", "conv2d_transpose"):
-                if not self.try_lower_chain(i):
+                if not self.try_lower_chain(i) and not self.try_lower_head_tail(i):
                     self.lower_conv(i)
             elif t == "batch_norm":
                 raise NotImplementedError(f"stand-alone batch_norm at op {i}")

@@ -27,6 +27,10 @@
 #include <cstdio>
 #include "conv_common.h"
 
+#ifndef VSE_CHAIN_ABL
+#define VSE_CHAIN_ABL 0      // timing-only ablations (tools/ablate_chain.sh; results are garbage): 1 no global stores, 2 no depthwise taps,
+#endif                       // 4 no MFMAs, 8 no activation / hi-lo split in the PW epilogue (bit mask)
+
 namespace {
 
 enum { CH_MAGIC = 0x43484e31, CH_HDR = 16, CH_BUF = 16, CH_STAGE = 28, CH_MAX_STAGES = 8, CH_MAX_BUFS = 10 };
@@ -45,6 +49,7 @@ struct ChainArgs {
     GView in, out[3];
     float* out_f32;             // S_SHUF store: the 1-channel fp32 map [n][4 H][4 W]
     int n_img;
+    int desc_words;             // header + buffers + stages
     unsigned long long* trace;  // -DVSE_CHAIN_TRACE builds: s_memtime stamps of block 0's first tiles
 };
 
@@ -74,7 +79,14 @@ __device__ __forceinline__ void dw_taps(const float* __restrict__ plane, int ew_
 
 __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int* __restrict__ D = a.desc;
+    // The descriptor (<= 400 words) is copied into LDS once per block and read from there.  Read from global memory, hipcc turned the
+    // per-stage reads into VECTOR loads + v_readfirstlane (the stage index is a loop variable): two or three DEPENDENT global round
+    // trips at every stage start, each also draining the in-order vmcnt queue of the tile's stores and prefetch loads — 10-15 k of the
+    // ~30 k cycles a two-stage tile took (s_memtime trace, tools/trace_chain.sh).
+    __shared__ int sdesc[CH_HDR + CH_MAX_BUFS * CH_BUF + CH_MAX_STAGES * CH_STAGE];
+    for (int i = threadIdx.x; i < a.desc_words; i += 256) sdesc[i] = a.desc[i];
+    lds_barrier();
+    const int* D = sdesc;
     const int nstages = D[1], nbufs = D[2];
     const int tiles_h = D[8], tiles_w = D[9];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,8 +100,8 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
     const unsigned vbid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
     const unsigned ntiles = (unsigned)a.n_img * tiles_h * tiles_w;
 
-    const int* __restrict__ BF = D + CH_HDR;
-    const int* __restrict__ ST = D + CH_HDR + nbufs * CH_BUF;
+    const int* BF = D + CH_HDR;
+    const int* ST = D + CH_HDR + nbufs * CH_BUF;
 
     // ---- the LDS image of the weights (batched loads: one round trip per 4 x 16 bytes per thread) --------------------------------
     {
@@ -156,9 +168,11 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
     }
 #ifdef VSE_CHAIN_TRACE
     int trace_i = 0;
-#define CH_STAMP() do { if (a.trace && bid == 8 && tid == 0 && trace_i < 120) a.trace[trace_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CH_STAMP() do { if (a.trace && bid == 8 && tid == 0 && trace_i < 60) a.trace[trace_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CH_FINE(slot) do { if (a.trace && bid == 8 && tid == 0 && tile == vbid) a.trace[64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CH_STAMP() do { } while (0)
+#define CH_FINE(slot) do { } while (0)
 #endif
   for (; tile < ntiles; tile += nblk) {
     int n, ty, tx;
@@ -203,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
     for (int si = 0; si < nstages; ++si) {
         // every descriptor word the stage needs is read HERE, into scalar registers: a scalar load inside the loops below could not
         // be hoisted past their stores (it may alias them as far as the compiler knows) and costs a ~200-cycle wait each
-        const int* __restrict__ s = ST + si * CH_STAGE;
+        CH_FINE(si * 8 + 4);
+        const int* s = ST + si * CH_STAGE;
         const int s_type = s[S_TYPE], s_in = s[S_IN], ob = s[S_OUT], s_res = s[S_RES];
         const int act = s[S_ACT], act2 = s[S_ACT2], gout = s[S_GOUT], cout = s[S_COUT], cin = s[S_CIN];
         const int s_mask = s[S_MASK], s_shuf = s[S_SHUF], haslo = s[S_HASLO], nks = s[S_NKS], nct = s[S_NCT];
@@ -211,14 +226,16 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
         const float act_a = __int_as_float(s[S_ACT_A]), act_b = __int_as_float(s[S_ACT_B]);
         const float post_a = __int_as_float(s[S_POST_A]), post_b = __int_as_float(s[S_POST_B]);
         const bool post = post_a != 1.0f || post_b != 0.0f;
-        const int* __restrict__ bi = BF + s_in * CH_BUF;
+        const int* bi = BF + s_in * CH_BUF;
         const int bi_hi = bi[B_OFF_HI], bi_lo = bi[B_OFF_LO], bi_stride = bi[B_STRIDE], bi_P = bi[B_P], bi_ew = bi[B_EW];
         const int bi_th = bi[B_TH], bi_ah = bi[B_AH], bi_tw = bi[B_TW], bi_aw = bi[B_AW], bi_H = bi[B_HIMG], bi_W = bi[B_WIMG];
-        const int* __restrict__ bo = BF + (ob >= 0 ? ob : s_in) * CH_BUF;
-        const int bo_kind = bo[B_KIND], bo_hi = bo[B_OFF_HI], bo_lo = bo[B_OFF_LO], bo_stride = bo[B_STRIDE], bo_cp = bo[B_CP];
+        const int* bo = BF + ob * CH_BUF;              // (always a descriptor: kind 2 = region of the last output, nothing in LDS)
+        const int bo_kind = bo[B_KIND];
+        const bool to_lds = bo_kind != 2;
+        const int bo_hi = bo[B_OFF_HI], bo_lo = bo[B_OFF_LO], bo_stride = bo[B_STRIDE], bo_cp = bo[B_CP];
         const int bo_P = bo[B_P], bo_ew = bo[B_EW], bo_th = bo[B_TH], bo_ah = bo[B_AH], bo_tw = bo[B_TW], bo_aw = bo[B_AW];
         const int bo_H = bo[B_HIMG], bo_W = bo[B_WIMG];
-        const int* __restrict__ br = BF + (s_res >= 0 ? s_res : s_in) * CH_BUF;
+        const int* br = BF + (s_res >= 0 ? s_res : s_in) * CH_BUF;
         const int br_hi = br[B_OFF_HI], br_lo = br[B_OFF_LO], br_stride = br[B_STRIDE], br_ew = br[B_EW];
         const int br_dy = br[B_AH] - bi_ah, br_dx = br[B_AW] - bi_aw;
         const GView gv = a.out[gout >= 0 ? gout : 0];
@@ -236,14 +253,15 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
             const size_t lo_pass = (size_t)nct * nks * 1024;
             for (int it = wave; it < npt * nct; it += 4) {
                 const int pt = it / nct, ct = it - pt * nct;           // (uniform per wave)
+                if (it == wave) CH_FINE(si * 8 + 0);
                 const int pix_raw = pt * 32 + (lane & 31);
                 const int pix = pix_raw < P ? pix_raw : P - 1;
                 float16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
                 const char* xb = xhi + pix * stride + h * 16;
                 const char* xl = xlo + pix * stride + h * 16;
                 const char* wb = wfr + ((size_t)ct * nks * 64 + lane) * 16;
-                if (haslo) {
-
+                if (VSE_CHAIN_ABL & 4) {
+                } else if (haslo) {
                     for (int ks = 0; ks < nks; ++ks) {
                         const half8 bh = *reinterpret_cast<const half8*>(xb + ks * 32);
                         const half8 bl = *reinterpret_cast<const half8*>(xl + ks * 32);
@@ -263,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
                     }
                 }
+                if (it == wave) CH_FINE(si * 8 + 1);
                 // ---- epilogue: lane = pixel (lane & 31); registers 8g + j = channel ct*32 + 16g + 8h + j (conv_wrow order) ----
                 const int ry = fdiv(pix, inv_ew), rx = pix - ry * ew;
                 const int iy = y0 + ry, ix = x0 + rx;
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                     const float4v b0 = *reinterpret_cast<const float4v*>(bias + c0), b1 = *reinterpret_cast<const float4v*>(bias + c0 + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = acc[8 * g + j] + b0[j]; v[4 + j] = acc[8 * g + 4 + j] + b1[j]; }
-                    vse_act_n<8>(v, act, act_a, act_b);
+                    if (!(VSE_CHAIN_ABL & 8)) vse_act_n<8>(v, act, act_a, act_b);
                     if (post) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = v[j] * post_a + post_b;
@@ -304,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                         for (int j = 0; j < 8; ++j) v[j] = 0.f;
                     }
                     if (!live) continue;
-                    if (ob >= 0) {
+                    if (to_lds) {
                         if (bo_kind == 1) {
                             float* pl = reinterpret_cast<float*>(lds + bo_hi) + (size_t)c0 * bo_stride + pix;
 #pragma unroll
@@ -316,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                             if (bo_lo >= 0) *reinterpret_cast<half8*>(lds + bo_lo + pix * bo_stride + c0 * 2) = lo;
                         }
                     }
-                    if (store) {
+                    if (store && !(VSE_CHAIN_ABL & 1)) {
                         if (s_shuf) {
                             // head tail: channel 4 r + c = output (4 iy + r, 4 ix + c) of the 4 x 4 block of input pixel (iy, ix); this
                             // lane's run c0 .. c0 + 7 = rows c0 / 4 and c0 / 4 + 1 of the block -> fp32 map [n][4 H][4 W]
@@ -334,8 +353,9 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                         }
                     }
                 }
+                if (it == wave) CH_FINE(si * 8 + 2);
                 // zero K padding of a channel-minor output (Cp > cout): garbage there would meet zero weights, but NaN * 0 = NaN
-                if (ob >= 0 && bo_kind == 0 && live && ct == nct - 1 && bo_cp > cout && h == 0) {
+                if (bo_kind == 0 && live && ct == nct - 1 && bo_cp > cout && h == 0) {
                     const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                     for (int c0 = cout; c0 < bo_cp; c0 += 8) {
                         *reinterpret_cast<half8*>(lds + bo_hi + pix * bo_stride + c0 * 2) = z;
@@ -357,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
             const int nchunk = (Po + 63) >> 6, ncg = C >> 3;
             for (int it = wave; it < nchunk * ncg; it += 4) {
                 const int cg = it / nchunk, chunk = it - cg * nchunk;
+                if (it == wave) CH_FINE(si * 8 + 0);
                 const int pix_raw = chunk * 64 + lane;
                 const int pix = pix_raw < Po ? pix_raw : Po - 1;
                 const int ry = fdiv(pix, inv_ewo), rx = pix - ry * ewo;
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                         const float4v w0 = wr[0], w1 = wr[1], w2 = wr[2];
                         const float w[9] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w2[0]};
                         float acc = w2[1];
-                        dw_taps<3>(base + (size_t)j * pstride, ew_in, w, acc);
+                        if (!(VSE_CHAIN_ABL & 2)) dw_taps<3>(base + (size_t)j * pstride, ew_in, w, acc);
                         v[j] = acc;
                     }
                 } else {
@@ -383,19 +404,21 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                             w[4 * q] = t4[0]; w[4 * q + 1] = t4[1]; w[4 * q + 2] = t4[2]; w[4 * q + 3] = t4[3];
                         }
                         float acc = w[25];
-                        dw_taps<5>(base + (size_t)j * pstride, ew_in, w, acc);
+                        if (!(VSE_CHAIN_ABL & 2)) dw_taps<5>(base + (size_t)j * pstride, ew_in, w, acc);
                         v[j] = acc;
                     }
                 }
+                if (it == wave) CH_FINE(si * 8 + 1);
                 vse_act_n<8>(v, act, act_a, act_b);
                 if (post) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = v[j] * post_a + post_b;
                 }
+                if (it == wave) CH_FINE(si * 8 + 2);
                 if (pix_raw >= Po) continue;
                 half8 hi, lo;
                 split8(v, hi, lo);
-                if (ob >= 0) {
+                if (to_lds) {
                     *reinterpret_cast<half8*>(lds + bo_hi + pix * bo_stride + cg * 16) = hi;
                     if (bo_lo >= 0) *reinterpret_cast<half8*>(lds + bo_lo + pix * bo_stride + cg * 16) = lo;
                     if (cg == ncg - 1 && bo_cp > C) {
@@ -406,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                         }
                     }
                 }
-                if (gout >= 0) {
+                if (gout >= 0 && !(VSE_CHAIN_ABL & 1)) {
                     const int iy = y0 + ry, ix = x0 + rx;
                     const int oy = ry - bo_ah, ox = rx - bo_aw;
                     if (iy >= 0 && iy < H && ix >= 0 && ix < W && oy >= 0 && oy < bo_th && ox >= 0 && ox < bo_tw && cg * 8 < gv.c) {
@@ -417,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                 }
             }
         }
+        CH_FINE(si * 8 + 5);
         lds_barrier();
         CH_STAMP();
     }
@@ -446,14 +470,15 @@ int launch_chain(const vse_op& o, const TView& in0, const TView& out, const TVie
     a.out[2] = gv(out3, o.p[13]);
     a.out_f32 = reinterpret_cast<float*>(out.ptr);
     a.n_img = in0.n;
+    a.desc_words = CH_HDR + nbufs * CH_BUF + nstages * CH_STAGE;
     const int tiles_h = o.p[0], tiles_w = o.p[1];
     const unsigned long long blocks = (unsigned long long)in0.n * tiles_h * tiles_w;
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
     const int lds_bytes = o.p[2];
-    if (lds_bytes > 160 * 1024) return VSE_E_UNSUPPORTED;
+    if (lds_bytes > 158 * 1024) return VSE_E_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)      // (+ 1.6 KiB of static LDS: the descriptor)
             return VSE_E_HIP;
         attr_set = true;
     }
@@ -465,7 +490,7 @@ int launch_chain(const vse_op& o, const TView& in0, const TView& out, const TVie
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return VSE_E_HIP;
         n_cu = prop.multiProcessorCount;
     }
-    const int per_cu = std::max(1, std::min(2, (160 * 1024) / std::max(lds_bytes, 1)));      // (229 VGPRs: two 4-wave blocks per CU)
+    const int per_cu = std::max(1, std::min(2, (160 * 1024) / (lds_bytes + 2048)));      // (229 VGPRs: two 4-wave blocks per CU)
     unsigned grid = (unsigned)std::min<unsigned long long>(blocks, (unsigned long long)n_cu * per_cu);
     if (grid > 8) grid &= ~7u;
 #ifdef VSE_CHAIN_TRACE
@@ -483,12 +508,14 @@ int launch_chain(const vse_op& o, const TView& in0, const TView& out, const TVie
         unsigned long long h[128];
         (void)hipMemcpy(h, trace_dev, sizeof h, hipMemcpyDeviceToHost);
         const int per = nstages + 2;       // stamps per tile: start, input stored, after each stage
-        fprintf(stderr, "[chain trace] %d stages, grid %u, lds %d, tiles %llu: block 8, s_memtime ticks (100 MHz) per phase of its first tiles:", nstages, grid, lds_bytes, blocks);
+        fprintf(stderr, "[chain trace] %d stages, grid %u, lds %d, tiles %llu: block 8, s_memtime ticks (shader clocks) per phase of its first tiles:", nstages, grid, lds_bytes, blocks);
         for (int t = 0; t < 4 && h[(t + 1) * per - 1]; ++t) {
             fprintf(stderr, "  | tile %d:", t);
             for (int q = 1; q < per; ++q) fprintf(stderr, " %llu", h[t * per + q] - h[t * per + q - 1]);
             if (h[(t + 1) * per]) fprintf(stderr, " (gap %llu)", h[(t + 1) * per] - h[(t + 1) * per - 1]);
         }
+        fprintf(stderr, "  || wave 0, first tile, per stage (stage start->first item, item core, item epilogue, end of first item->loop done):");
+        for (int q = 0; q < nstages; ++q) fprintf(stderr, " [%llu %llu %llu %llu]", h[64 + q * 8] - h[64 + q * 8 + 4], h[64 + q * 8 + 1] - h[64 + q * 8], h[64 + q * 8 + 2] - h[64 + q * 8 + 1], h[64 + q * 8 + 5] - h[64 + q * 8 + 2]);
         fprintf(stderr, "\n");
     }
 #endif

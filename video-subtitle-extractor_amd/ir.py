@@ -127,7 +127,8 @@ CH_MAGIC = 0x43484E31
 CH_HDR, CH_BUF, CH_STAGE = 16, 16, 28
 # header words
 CHH_MAGIC, CHH_NSTAGES, CHH_NBUFS, CHH_LDSW_BYTES, CHH_LDSIMG_OFF, CHH_LDS_TOTAL, CHH_TH, CHH_TW, CHH_TILES_H, CHH_TILES_W = range(10)
-# buffer words: kind 0 = channel-minor fp16 hi (+ lo) [pixel][Cp] with a pixel stride of 2 Cp + 16 bytes, 1 = planar fp32 [C][stride]
+# buffer words: kind 0 = channel-minor fp16 hi (+ lo) [pixel][Cp] with a pixel stride of 2 Cp + 16 bytes, 1 = planar fp32 [C][stride],
+# 2 = the region of the chain's last output (tile geometry only: nothing is kept in LDS)
 (CHB_KIND, CHB_OFF_HI, CHB_OFF_LO, CHB_C, CHB_CP, CHB_STRIDE, CHB_TH, CHB_AH, CHB_EH, CHB_TW, CHB_AW, CHB_EW, CHB_P, CHB_HIMG,
  CHB_WIMG) = range(15)
 # stage words (floats stored by bit pattern)
