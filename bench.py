@@ -62,6 +62,7 @@ def parse():
                     "captured against fixed buffers (needs --rec-streams > 1)")
     ap.add_argument("--ragged-floor", type=int, default=None, help="ragged grouping: crop-pixels below which a launch sequence stops getting faster")
     ap.add_argument("--ragged-launch-cost", type=int, default=None, help="ragged grouping: fixed cost of one launch sequence in crop-pixels")
+    ap.add_argument("--no-det-chains", dest="det_chains", action="store_false", help="mobile detectors layer by layer (no OP_CHAIN / pair tensors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="skip config.secondary (4K batch 32, fast mode)")
     ap.add_argument("--secondary-steps", type=int, default=4)
@@ -237,7 +238,8 @@ def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, 
     charset = shim.standin_charset(lang, shim._ncls(rec[0]))      # stand-in weights: index-faithful placeholder table
     pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode=args.rec_mode, bucket=args.bucket,
                                 batch_round=args.batch_round, min_rec_group=args.min_rec_group,
-                                rec_h=32 if args.models == "v2" else 48, limit_side_len=args.limit_side)
+                                rec_h=32 if args.models == "v2" else 48, limit_side_len=args.limit_side,
+                                det_chains=None if args.det_chains else False)
 
     pipe.rec_streams = args.rec_streams
     pipe.rec_graphs = args.rec_graphs
@@ -418,21 +420,26 @@ def finish(args, ctx, world, rank, W, out, dt, log, host_threads, build_secondar
                 stage2_recognise(ready)
             result["roofline"] = roofline(pipe, profile_pass, steps_per_call=span)     # rank 0 only: no collective
             log("roofline pass done")
-        if args.secondary and not args.no_roofline and world == 1:      # (the A/B tools pass --no-roofline: headline only)
+        if (args.secondary and not args.no_roofline and world == 1 and args.models == "server" and args.height == 1080
+                and args.limit_side == 960):                      # (the default headline only; the A/B tools pass --no-roofline)
             # the other single-GPU configurations north_star names, through the same functions, a few timed steps each (the headline
             # above is untouched: it was measured first): BASELINE configs[2]'s frame size (4K frames, batch 32; det_limit_side_len
             # stays the reference's 960, so the detector input is 544 x 960 and the crops come from 4K pixels), and the reference's
             # DEFAULT mode (backend/config.py:54 mode = fast -> V4/ch_det_fast + V4/ch_rec_fast, the mobile pair)
             sec = {}
-            for key, (m, h, w_, b) in (("4k_batch32", ("server", 2160, 3840, 32)), ("fast_mode_1080p", ("fast", 1080, 1920, 64))):
+            for key, (m, h, w_, b) in (("4k_batch32", ("server", 2160, 3840, 32)), ("fast_mode_1080p", ("fast", 1080, 1920, 64)),
+                                       ("fast_mode_1080p_layerwise", ("fast", 1080, 1920, 64))):
                 try:
+                    args.det_chains = not key.endswith("layerwise")       # (the chained detector is the product default: box parity)
                     W2 = build_secondary(m, h, w_, b)
                     _o2, dt2 = W2.timed(2, args.secondary_steps)
                     sec[key] = {"metric": f"OCR frames/sec (det+rec) @{h}p", "value": round(b * args.secondary_steps / dt2, 2), "unit": "frames/s",
                                 "ms_per_step": round(1e3 * dt2 / args.secondary_steps, 3), "steps": args.secondary_steps, "warmup": 2,
                                 "workload": f"{b}x{h}p frames/step, {W2.det_id} @{'x'.join(str(v) for v in pipeline.det_resize_shape(h, w_, args.limit_side))} + {W2.rec_id}, "
                                             f"boxes from DB post-processing, ragged recognition",
-                                "boxes_last_step": sum(len(r[1]) for r in _o2[-b:])}
+                                "boxes_last_step": sum(len(r[1]) for r in _o2[-b:]),
+                                "detector": ("fp16x2 weights, 1x1 / depthwise chains in LDS, hi + lo pair tensors (the default)" if args.det_chains else
+                                             "fp16x2 weights, layer by layer (det_chains=False)") if m == "fast" else "fp16"}
                     log(f"secondary {key}: {sec[key]['value']} frames/s")
                     del W2, _o2
                     torch.cuda.empty_cache()

@@ -351,6 +351,10 @@ class Emulator:
             y = y.reshape(n, h, w, 2, 2, cp).permute(0, 1, 3, 2, 4, 5).reshape(n, 2 * h, 2 * w, cp)
         if flags & ir.F_RES:
             res = self._up(self.read(r["in1"]), int(p[ir.P_RESSHIFT]))
+            if int(p[ir.P_LO_RES]):           # the residual is an fp16 hi + lo pair
+                lv = r["in1"].copy()
+                lv["off"] = int(lv["off"]) + int(p[ir.P_LO_RES]) * int(lv["esize"])
+                res = res + self.read(lv)
             y[..., :res.shape[3]] += res[..., :y.shape[3]]
         y = _act(y, int(p[ir.P_ACT2]))
         if flags & ir.F_DOT1:
@@ -367,6 +371,10 @@ class Emulator:
         p, f = r["p"], r["f"]
         kh, kw, sh, sw, ph, pw = (int(p[i]) for i in range(6))
         x = self.read(r["in0"])
+        if int(p[ir.P_LO_RES]):               # the input is an fp16 hi + lo pair
+            lv = r["in0"].copy()
+            lv["off"] = int(lv["off"]) + int(p[ir.P_LO_RES]) * int(lv["esize"])
+            x = x + self.read(lv)
         if int(r["flags"]) & ir.F_GATE:       # SE gate applied on load, rounded to fp16 like the separate scale pass
             g = self.read(r["in1"])
             x = ((x * g + x) if int(r["flags"]) & ir.F_RES else x * g).half().float()
@@ -380,7 +388,7 @@ class Emulator:
         y = F.conv2d(x.permute(0, 3, 1, 2), w4, bias, (sh, sw), (ph, pw), groups=cp).permute(0, 2, 3, 1)
         y = _act(y, int(p[ir.P_ACT]), float(f[ir.FS_ACT_A]), float(f[ir.FS_ACT_B]))
         y = y * float(f[ir.FS_POST_A]) + float(f[ir.FS_POST_B])
-        self.write(r["out"], y)
+        self.write_pair(r["out"], int(p[ir.P_LO_OUT]), y)
 
     def _op3(self, r):   # POOL
         p = r["p"]

@@ -55,8 +55,11 @@ def main():
         for r in csv.DictReader(open(path)):
             agg[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
         return agg
-    f = load(os.path.join(go, "pmc_fetch", "bench_counter_collection.csv"))
-    w = load(os.path.join(go, "pmc_write", "bench_counter_collection.csv"))
+    def pmc(name):          # gpurun_out/pmc_<name>_<tag> (collect_profiles.sh since round 4), else the un-tagged directory of rounds 1-3
+        d = os.path.join(go, f"pmc_{name}_{tag}")
+        return d if os.path.isdir(d) else os.path.join(go, f"pmc_{name}")
+    f = load(os.path.join(pmc("fetch"), "bench_counter_collection.csv"))
+    w = load(os.path.join(pmc("write"), "bench_counter_collection.csv"))
     kernels = {}
     for k in f:
         nf, nw = len(f[k]), len(w.get(k, []))
@@ -72,7 +75,7 @@ def main():
                                  "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction)",
                        "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_fetch_pass"]))},
                       fh, indent=1)
-    sq = os.path.join(go, "pmc_sq", "bench_counter_collection.csv")
+    sq = os.path.join(pmc("sq"), "bench_counter_collection.csv")
     if os.path.exists(sq):
         cnt = collections.defaultdict(lambda: collections.defaultdict(float))
         dur = collections.defaultdict(float)

@@ -30,10 +30,13 @@ CHAIN_LDS_1 = 150 * 1024
 CHAIN_TILES = [(8, 32), (16, 16), (8, 16), (4, 32), (4, 16), (2, 32), (4, 8), (2, 16), (2, 8)]
 if os.environ.get("VSE_CHAIN_TILE"):                  # experiments: force the tile, e.g. "4,16"
     CHAIN_TILES = [tuple(int(v) for v in os.environ["VSE_CHAIN_TILE"].split(","))]
-CHAIN_FIX = float(os.environ.get("VSE_CHAIN_FIX", "4000"))        # per-stage fixed cost of a tile (barrier, ramp) in work units
-CHAIN_ONE_BLOCK = float(os.environ.get("VSE_CHAIN_ONEBLOCK", "2.2"))   # cost factor of a plan that leaves one block per CU
-CHAIN_TWO_BLOCKS = float(os.environ.get("VSE_CHAIN_TWOBLOCKS", "1.35"))  # ... two blocks per CU (three fit the register file)
-CHAIN_COMPUTE_BYTES = float(os.environ.get("VSE_CHAIN_CBYTES", "0"))    # bytes of HBM traffic one work unit is worth (segmentation)
+CHAIN_TILE_CYC = float(os.environ.get("VSE_CHAIN_TILECYC", "2400"))    # fixed cycles of a tile (input store, prefetch issue, turn-over)
+CHAIN_STAGE_CYC = float(os.environ.get("VSE_CHAIN_STAGECYC", "600"))   # fixed cycles of a stage (descriptor lanes, barrier)
+CHAIN_ONE_BLOCK = float(os.environ.get("VSE_CHAIN_ONEBLOCK", "1.6"))   # cost factor of a plan that leaves one block per CU
+# segmentation: a chain's estimated time is weighted against the layer-by-layer ops it replaces; < 1 prefers chains (they round a
+# tensor to fp16 once per chain instead of once per layer: the detector's box parity) even where they are not faster
+CHAIN_TIME_WEIGHT = float(os.environ.get("VSE_CHAIN_WEIGHT", "0.5"))
+CHAIN_OP_TBS = 2.5e6            # bytes per microsecond an un-fused streaming op reaches on this chip (measured: 2-3 TB/s), + 6 us per launch
 
 
 def rup(x, m):
@@ -228,14 +231,20 @@ class ChainMixin:
                 total = max(total, off + bufs[j]["size"])
             if total > CHAIN_LDS_1:
                 continue
-            # cost: work per owned output pixel (region pixels x per-pixel work of each stage), small bias towards two blocks per CU
-            work = 0.0
+            # cost: estimated shader cycles of one tile per owned output pixel, from the s_memtime traces of the kernel (tools/
+            # trace_chain.sh): ~2.4 k per tile (input store, turn-over), ~0.6 k per stage (descriptor, barrier), a PW item (32 pixels x
+            # 32 couts) ~3 k + 0.6 k per 16-deep K slice, a DW item (64 pixels x 8 channels) ~0.7 k + 0.21 k per tap; four waves share
+            # the items of a stage; one block per CU instead of two costs its latency hiding
+            cyc = CHAIN_TILE_CYC
             for j, st in enumerate(stages):
                 rp = regs[j + 1]["Eh"] * regs[j + 1]["Ew"]
-                work += rp * (st["cin"] * st["cout"] / 16.0 + 40.0 if st["type"] == "pw" else st["cin"] * (st["k"] ** 2 + 4.0))
-            work += bufs[0]["P"] * stages[0]["cin"] * 1.0
-            blocks_cu = min(2, (160 * 1024) // total)         # 229 VGPRs: two 4-wave blocks per CU at most
-            cost = (work + CHAIN_FIX * n) / float(th * tw) * {1: CHAIN_ONE_BLOCK, 2: CHAIN_TWO_BLOCKS}.get(blocks_cu, 1.0)
+                if st["type"] == "pw":
+                    items, per = -(-rp // 32) * st["nct"], 3000.0 + 600.0 * st["nks"]
+                else:
+                    items, per = -(-rp // 64) * (st["cin"] // 8), 700.0 + 210.0 * st["k"] ** 2
+                cyc += CHAIN_STAGE_CYC + -(-items // 4) * per
+            blocks_cu = min(2, (160 * 1024) // (total + 2048))         # 197-240 VGPRs: two 4-wave blocks per CU at most
+            cost = cyc / float(th * tw) * (CHAIN_ONE_BLOCK if blocks_cu < 2 else 1.0)
             if best is None or cost < best["cost"]:
                 best = dict(cost=cost, th=th, tw=tw, regs=regs, bufs=[dict(b) for b in bufs], lds_total=total, wbytes=wbytes, dims=dims)
         return best
@@ -285,13 +294,14 @@ class ChainMixin:
         t = [dims[0][0] * dims[0][1] * path[0]["cin"] * 2.0] + [dims[j + 1][0] * dims[j + 1][1] * st["cout"] * 2.0 for j, st in enumerate(path)]
         ext = [any(c not in inside_all for c in self._live_consumers(st["out_name"])) or st["out_name"] in self.fetched_names
                or st["out_name"] in self.placement for st in path]
-        launch_eq = 0.25e6                 # one launch + its tail, in bytes of traffic
         INF = float("inf")
+        nimg = inv.n
 
-        def seg_cost(i, j):               # stages i..j inclusive (0-based)
+        def seg_cost(i, j):               # estimated microseconds of stages i..j inclusive (0-based) as ONE op
             if i == j:
                 st = path[i]
-                return t[i] + t[i + 1] + (t[st["res_abs"]] if st["res_abs"] >= 0 else 0.0) + launch_eq
+                byts = t[i] + t[i + 1] + (t[st["res_abs"]] if st["res_abs"] >= 0 else 0.0)
+                return nimg * byts / CHAIN_OP_TBS + 6.0
             if j - i + 1 > CHAIN_MAX_STAGES:
                 return INF
             sub = []
@@ -307,11 +317,11 @@ class ChainMixin:
             plan = self._chain_plan(sub, dims[i][0], dims[i][1], in_lo if i == 0 else False)
             if plan is None:
                 return INF
-            r0 = plan["regs"][0]
-            halo = (r0["Eh"] * r0["Ew"]) / float(r0["Th"] * r0["Tw"])
-            # reads of the halo mostly hit the L2 (neighbouring tiles of one XCD): a quarter of the overlap is priced as HBM traffic
-            return (t[i] * (1.0 + 0.25 * (halo - 1.0)) + t[j + 1] + sum(t[k + 1] for k in range(i, j) if ext[k]) + launch_eq
-                    + CHAIN_COMPUTE_BYTES * plan["cost"] * dims[j + 1][0] * dims[j + 1][1])
+            oh_, ow_ = dims[j + 1]
+            ntiles = nimg * -(-oh_ // plan["th"]) * -(-ow_ // plan["tw"])
+            blocks = 256 * min(2, (160 * 1024) // (plan["lds_total"] + 2048))
+            us = -(-ntiles // blocks) * plan["cost"] * plan["th"] * plan["tw"] / (CHAIN_ONE_BLOCK if blocks < 512 else 1.0) / 2100.0
+            return CHAIN_TIME_WEIGHT * us + 6.0
 
         best = [0.0] * (n + 1)
         cut = [0] * (n + 1)

@@ -569,10 +569,12 @@ class Compiler(ChainMixin):
             return False
         for j in self._live_consumers(name):
             o = self.ops[j]
+            if o["type"] == "conv2d_transpose" and o["in"]["Input"][0] == name and tuple(self.W[o["in"]["Filter"][0]].shape[2:]) == (2, 2):
+                return True          # the DB head's tail runs as a chain (chains.py try_lower_head_tail): right in front of the logits
             if o["type"] not in ("conv2d", "depthwise_conv2d") or o["in"]["Input"][0] != name:
                 continue
-            if self._chain_candidate(j) is not None:
-                return True
+            if self._chain_candidate(j) is not None or self._is_dw(o, self.W[o["in"]["Filter"][0]].shape[0]):
+                return True          # (a depthwise conv filters both halves of a pair: simple_ops.hip)
             wj = self.W[o["in"]["Filter"][0]]
             a = o["attrs"]
             if (o["type"] == "conv2d" and a.get("groups", 1) == 1 and tuple(wj.shape[2:]) == (1, 1) and list(a["strides"]) == [1, 1]
@@ -1385,7 +1387,9 @@ class Compiler(ChainMixin):
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
                      ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"], ir.P_COUT: coutp, ir.P_KTOT: Kp,
                      ir.P_INSHIFT: inv_main.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span, ir.P_IN2SHIFT: in2shift,
-                     ir.P_LO_OUT: out.buf.lo_off},
+                     ir.P_LO_OUT: out.buf.lo_off,
+                     ir.P_LO_RES: (res.buf.lo_off if (res is not None and res.buf is not None and not res.up and res.coff == 0
+                                                      and getattr(self, "chain", False)) else 0)},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                      ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
         self.add_gmacs(inv.n * oh * ow * (cin // 2 if pair_in else cin) * cout * self.merged_gmac_credit.get(wname, kh * kw) / 1e9)
@@ -1408,7 +1412,7 @@ class Compiler(ChainMixin):
         wk[:, :c] = (w.astype(np.float64)[:, 0] * ep["scale"].reshape(-1, 1, 1)).reshape(c, kh * kw).T
         bias = np.zeros(cp, np.float32)
         bias[:c] = ep["shift"]
-        out = self.alloc_out(ep["out_name"], inv.n, oh, ow, c)
+        out = self.alloc_out(ep["out_name"], inv.n, oh, ow, c, lo=self.wants_lo(ep["out_name"]))
         wk_hi = wk.astype(np.float16)
         if self.hilo:       # [2][taps][cp]: hi table, then lo = fp16(w - hi)
             wk_hi = np.concatenate([wk_hi.reshape(-1), (wk.astype(np.float64) - wk_hi.astype(np.float64)).astype(np.float16).reshape(-1)])
@@ -1417,7 +1421,9 @@ class Compiler(ChainMixin):
         self.emit(ir.OP_DWCONV, ep["out_name"], [inv] if gate is None else [inv, gate[0]], out,
                   flags=(0 if gate is None else (ir.F_GATE | gate[1])) | (ir.F_HILO if self.hilo else 0),
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
-                     ir.P_ACT: ep["act"]},
+                     ir.P_ACT: ep["act"], ir.P_LO_OUT: out.buf.lo_off,
+                     # (P_LO_RES of a depthwise conv = the pair offset of its INPUT: both halves are filtered)
+                     ir.P_LO_RES: inv.buf.lo_off if (gate is None and inv.coff == 0 and getattr(self, "chain", False)) else 0},
                   f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
                      ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
         self.add_gmacs(inv.n * oh * ow * c * kh * kw / 1e9)

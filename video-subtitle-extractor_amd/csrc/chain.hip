@@ -218,26 +218,30 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
         // every descriptor word the stage needs is read HERE, into scalar registers: a scalar load inside the loops below could not
         // be hoisted past their stores (it may alias them as far as the compiler knows) and costs a ~200-cycle wait each
         CH_FINE(si * 8 + 4);
-        const int* s = ST + si * CH_STAGE;
-        const int s_type = s[S_TYPE], s_in = s[S_IN], ob = s[S_OUT], s_res = s[S_RES];
-        const int act = s[S_ACT], act2 = s[S_ACT2], gout = s[S_GOUT], cout = s[S_COUT], cin = s[S_CIN];
-        const int s_mask = s[S_MASK], s_shuf = s[S_SHUF], haslo = s[S_HASLO], nks = s[S_NKS], nct = s[S_NCT];
-        const int s_wlds = s[S_WLDS], s_blds = s[S_BLDS], K = s[S_K], S = s[S_S];
-        const float act_a = __int_as_float(s[S_ACT_A]), act_b = __int_as_float(s[S_ACT_B]);
-        const float post_a = __int_as_float(s[S_POST_A]), post_b = __int_as_float(s[S_POST_B]);
+        // the stage record and its three buffer records: TWO lane-indexed LDS reads, then v_readlane per field (~60 separate
+        // ds_read + v_readfirstlane pairs cost 1.2-3 k cycles per stage and tile in the s_memtime trace)
+        const int fs = ST[si * CH_STAGE + min(lane, CH_STAGE - 1)];
+#define SF(k) __builtin_amdgcn_readlane(fs, (k))
+        const int s_type = SF(S_TYPE), s_in = SF(S_IN), ob = SF(S_OUT), s_res = SF(S_RES);
+        const int act = SF(S_ACT), act2 = SF(S_ACT2), gout = SF(S_GOUT), cout = SF(S_COUT), cin = SF(S_CIN);
+        const int s_mask = SF(S_MASK), s_shuf = SF(S_SHUF), haslo = SF(S_HASLO), nks = SF(S_NKS), nct = SF(S_NCT);
+        const int s_wlds = SF(S_WLDS), s_blds = SF(S_BLDS), K = SF(S_K), S = SF(S_S);
+        const float act_a = __int_as_float(SF(S_ACT_A)), act_b = __int_as_float(SF(S_ACT_B));
+        const float post_a = __int_as_float(SF(S_POST_A)), post_b = __int_as_float(SF(S_POST_B));
         const bool post = post_a != 1.0f || post_b != 0.0f;
-        const int* bi = BF + s_in * CH_BUF;
-        const int bi_hi = bi[B_OFF_HI], bi_lo = bi[B_OFF_LO], bi_stride = bi[B_STRIDE], bi_P = bi[B_P], bi_ew = bi[B_EW];
-        const int bi_th = bi[B_TH], bi_ah = bi[B_AH], bi_tw = bi[B_TW], bi_aw = bi[B_AW], bi_H = bi[B_HIMG], bi_W = bi[B_WIMG];
-        const int* bo = BF + ob * CH_BUF;              // (always a descriptor: kind 2 = region of the last output, nothing in LDS)
-        const int bo_kind = bo[B_KIND];
+        const int fb = BF[(lane < 16 ? s_in : (lane < 32 ? ob : (s_res >= 0 ? s_res : s_in))) * CH_BUF + (lane & 15)];
+#define BI(k) __builtin_amdgcn_readlane(fb, (k))
+#define BO(k) __builtin_amdgcn_readlane(fb, 16 + (k))
+#define BR(k) __builtin_amdgcn_readlane(fb, 32 + (k))
+        const int bi_hi = BI(B_OFF_HI), bi_lo = BI(B_OFF_LO), bi_stride = BI(B_STRIDE), bi_P = BI(B_P), bi_ew = BI(B_EW);
+        const int bi_th = BI(B_TH), bi_ah = BI(B_AH), bi_tw = BI(B_TW), bi_aw = BI(B_AW), bi_H = BI(B_HIMG), bi_W = BI(B_WIMG);
+        const int bo_kind = BO(B_KIND);
         const bool to_lds = bo_kind != 2;
-        const int bo_hi = bo[B_OFF_HI], bo_lo = bo[B_OFF_LO], bo_stride = bo[B_STRIDE], bo_cp = bo[B_CP];
-        const int bo_P = bo[B_P], bo_ew = bo[B_EW], bo_th = bo[B_TH], bo_ah = bo[B_AH], bo_tw = bo[B_TW], bo_aw = bo[B_AW];
-        const int bo_H = bo[B_HIMG], bo_W = bo[B_WIMG];
-        const int* br = BF + (s_res >= 0 ? s_res : s_in) * CH_BUF;
-        const int br_hi = br[B_OFF_HI], br_lo = br[B_OFF_LO], br_stride = br[B_STRIDE], br_ew = br[B_EW];
-        const int br_dy = br[B_AH] - bi_ah, br_dx = br[B_AW] - bi_aw;
+        const int bo_hi = BO(B_OFF_HI), bo_lo = BO(B_OFF_LO), bo_stride = BO(B_STRIDE), bo_cp = BO(B_CP);
+        const int bo_P = BO(B_P), bo_ew = BO(B_EW), bo_th = BO(B_TH), bo_ah = BO(B_AH), bo_tw = BO(B_TW), bo_aw = BO(B_AW);
+        const int bo_H = BO(B_HIMG), bo_W = BO(B_WIMG);
+        const int br_hi = BR(B_OFF_HI), br_lo = BR(B_OFF_LO), br_stride = BR(B_STRIDE), br_ew = BR(B_EW);
+        const int br_dy = BR(B_AH) - bi_ah, br_dx = BR(B_AW) - bi_aw;
         const GView gv = a.out[gout >= 0 ? gout : 0];
         if (s_type == 0) {
             // ================= 1x1 conv: D[cout][pixel] = W[cout][k] X[k][pixel], three hi / lo passes ==================

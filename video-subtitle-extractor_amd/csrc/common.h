@@ -17,7 +17,7 @@ enum { F_LSTM_MFMA = 16384, F_ONECH = 32768, F_U8SRC = 65536, F_OGATE = 131072 }
 enum { F_LSTM_MFMA_ = 0 };   // OP_LSTM: W_hh^T in MFMA fragment order, H = 256 (lstm.hip); p[P_REVERSE] = 2: both directions, in1 = reverse gates
 enum { F_RES = 1, F_PIXSHUF = 2, F_OUT_F32 = 4, F_PATCH = 8, F_DOT1 = 16, F_SRC2 = 32, F_UP2HEAD = 64, F_WK32 = 128, F_GATE = 256, F_STEM = 512, F_HILO = 1024, F_COL = 2048, F_PW = 4096, F_IMGW = 8192 };
 // p[] slots (keep in sync with ir.py)
-enum { P_KH = 0, P_KW, P_SH, P_SW, P_PH, P_PW, P_ACT, P_ACT2, P_COUT, P_KTOT, P_INSHIFT, P_RESSHIFT, P_CINP, P_DOTACT, P_IN2SHIFT, P_LO_OUT };
+enum { P_KH = 0, P_KW, P_SH, P_SW, P_PH, P_PW, P_ACT, P_ACT2, P_COUT, P_KTOT, P_INSHIFT, P_RESSHIFT, P_CINP, P_DOTACT, P_IN2SHIFT, P_LO_OUT, P_LO_RES };
 enum { P_POOL_MAX = 6, P_POOL_CEIL = 7, P_POOL_EXCL = 8 };
 // ragged plans: 1 + width level of in0 / of the output (0 = no per-sample width); the run supplies widths[level][n]
 enum { P_WLIN = 20, P_WLOUT = 21 };
@@ -59,6 +59,7 @@ struct ConvArgs {
     // ragged plans: per-sample output widths (device, [n]); output pixels at x >= wl_out[n] are written as zeros
     const int* wl_out;
     int lo_off;           // P_LO_OUT: channel offset of the lo half of an fp16 hi + lo pair output (0 = plain fp16)
+    int res_lo_off;       // P_LO_RES: ... of the residual
     // F_U8SRC: the uint8 BGR frames the stem conv pre-processes itself (vse_plan_set_source)
     const uint8_t* u8src;
     int u8_h, u8_w;

@@ -34,6 +34,7 @@ struct ConvParams {
     long wimg_stride;       // F_IMGW: weight elements per image (Kp * Np); M tiles are then aligned to images
     int hw_img, tiles_img;  // F_IMGW: output pixels per image, M tiles per image
     const int* wl_out;      // ragged plans: per-image output width; pixels at ow >= wl_out[n] are stored as zeros
+    int res_lo_off;         // != 0: the residual is an fp16 hi + lo pair: its lo half sits res_lo_off channels behind the hi half
     int lo_off;             // != 0: fp16 hi + lo pair output: fp16(v - fp16(v)) goes lo_off channels behind the hi value
     const half_t* ogate;    // F_OGATE: per-(image, cout) gate [n][ogate_ld] fp16; the value is multiplied by (1 + gate) ahead of the residual
     int ogate_ld;
@@ -235,6 +236,11 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
                 const half8 r8 = *reinterpret_cast<const half8*>(rp);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[g * 8 + e] += (float)r8[e];
+                if (p.res_lo_off) {
+                    const half8 l8 = *reinterpret_cast<const half8*>(rp + p.res_lo_off);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[g * 8 + e] += (float)l8[e];
+                }
             } else {
                 const half4 r0 = *reinterpret_cast<const half4*>(rp), r1 = *reinterpret_cast<const half4*>(rp + 4);
 #pragma unroll

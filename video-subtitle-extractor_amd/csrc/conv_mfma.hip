@@ -288,6 +288,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.wimg_stride = 0; p.hw_img = 0; p.tiles_img = 0;
     p.wl_out = a.wl_out;
     p.lo_off = a.lo_off;
+    p.res_lo_off = (a.flags & F_RES) ? a.res_lo_off : 0;
+    if (p.res_lo_off && (!p.vec16 || a.resshift || (p.res_lo_off & 7))) return VSE_E_INVAL;
     if (a.lo_off && (!p.vec16 || (a.flags & (F_OUT_F32 | F_ONECH | F_DOT1 | F_UP2HEAD)) || (a.lo_off & 7) || a.out.ld < a.lo_off + a.Np / ((a.flags & F_PIXSHUF) ? 4 : 1)))
         return VSE_E_INVAL;
     p.ogate = nullptr; p.ogate_ld = 0;

@@ -50,6 +50,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
                                                      int ph, int pw, int act, float act_a, float act_b, float post_a,
                                                      float post_b, const int* __restrict__ wl_out) {
     const int gated = gate.ptr != nullptr ? gmode : 0;
+    const int lo_off = ((hilo >> 1) & 0xfff) << 3;   // != 0: the output is an fp16 hi + lo pair (P_LO_OUT): fp16(v - fp16(v)) lo_off channels behind
+    const int lo_in = ((hilo >> 13) & 0xfff) << 3;   // != 0: the INPUT is a pair: its lo half sits lo_in channels behind the hi half
+    hilo &= 1;
     const int cg = in.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
                 const int iw = ow * sw - pw + dx;
                 if (iw < 0 || iw >= in.w) continue;
                 const half8 x = dw_gate(ld8(in, (n * in.h + ih) * in.w + iw, g * 8), gv, gated);
+                const half8 xl = lo_in ? ld8(in, (n * in.h + ih) * in.w + iw, g * 8 + lo_in) : half8{0, 0, 0, 0, 0, 0, 0, 0};
                 const half8 k = *reinterpret_cast<const half8*>(w + (long)(dy * kw + dx) * in.c + g * 8);
                 float kf[8];
 #pragma unroll
@@ -80,14 +84,19 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
                     for (int e = 0; e < 8; ++e) kf[e] += (float)kl[e];
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (float)x[e] * kf[e];
+                for (int e = 0; e < 8; ++e) acc[e] += ((float)x[e] + (float)xl[e]) * kf[e];
             }
         }
-        half8 o;
+        half8 o, ol;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)(vse_act(acc[e], act, act_a, act_b) * post_a + post_b);
+        for (int e = 0; e < 8; ++e) {
+            const float v = vse_act(acc[e], act, act_a, act_b) * post_a + post_b;
+            o[e] = (half_t)v;
+            ol[e] = (half_t)(v - (float)o[e]);
+        }
         if (wl_out != nullptr && ow >= wl_out[n]) o = half8{0, 0, 0, 0, 0, 0, 0, 0};      // ragged batch: right of the sample's width
         st8(out, pix, g * 8, o);
+        if (lo_off) st8(out, pix, g * 8 + lo_off, ol);
     }
 }
 
@@ -101,6 +110,8 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
                                                          int act, float act_a, float act_b, float post_a, float post_b,
                                                          const int* __restrict__ wl_out) {
     constexpr int OUTW = 4, WIN = (OUTW - 1) * SW + KW;
+    const int lo_off = ((hilo >> 1) & 0xfff) << 3, lo_in = ((hilo >> 13) & 0xfff) << 3;          // (see dwconv_kernel)
+    hilo &= 1;
     const int cg = in.c >> 3;
     const int owq = (out.w + OUTW - 1) / OUTW;
     const long total = (long)out.n * out.h * owq * cg;
@@ -118,7 +129,10 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[o][e] = bias[g * 8 + e];
         const half8 gv = GM ? ld8(gate, n, g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-        for (int dy = 0; dy < kh; ++dy) {
+        for (int dyp = 0; dyp < (lo_in ? 2 * kh : kh); ++dyp) {
+            // (a pair input: every filter row is walked twice, over the hi and over the lo half of the same pixels)
+            const int dy = dyp < kh ? dyp : dyp - kh;
+            const int coff = dyp < kh ? 0 : lo_in;
             const int ih = oh * sh - ph + dy;
             if (ih < 0 || ih >= in.h) continue;
             const long rowpix = (n * in.h + ih) * in.w;
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
 #pragma unroll
             for (int c = 0; c < WIN; ++c) {
                 const int iw = iw0 + c;
-                x[c] = (iw >= 0 && iw < in.w) ? ld8(in, rowpix + iw, g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+                x[c] = (iw >= 0 && iw < in.w) ? ld8(in, rowpix + iw, g * 8 + coff) : half8{0, 0, 0, 0, 0, 0, 0, 0};
             }
             // all loads of the row first, arithmetic afterwards: multiplying each vector as it arrives serialises the loads
             // (the kernel is HBM-bound on the detector's maps: 0.52 ms gated against 0.32 ms with the loads batched)
@@ -158,11 +172,16 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
 #pragma unroll
         for (int o = 0; o < OUTW; ++o) {
             if (ow0 + o >= out.w) continue;
-            half8 r;
+            half8 r, rl;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) r[e] = (half_t)(vse_act(acc[o][e], act, act_a, act_b) * post_a + post_b);
+            for (int e = 0; e < 8; ++e) {
+                const float v = vse_act(acc[o][e], act, act_a, act_b) * post_a + post_b;
+                r[e] = (half_t)v;
+                rl[e] = (half_t)(v - (float)r[e]);
+            }
             if (wl_out != nullptr && ow0 + o >= wl_out[n]) r = half8{0, 0, 0, 0, 0, 0, 0, 0};
             st8(out, (n * out.h + oh) * out.w + ow0 + o, g * 8, r);
+            if (lo_off) st8(out, (n * out.h + oh) * out.w + ow0 + o, g * 8 + lo_off, rl);
         }
     }
 }
@@ -632,7 +651,10 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             const int kw = p[P_KW], sw = p[P_SW];
             TView gate = in1;
             const int gmode = (op.flags & F_RES) ? 2 : 1;
-            const int hilo = (op.flags & F_HILO) ? 1 : 0;
+            if (p[P_LO_OUT] && ((p[P_LO_OUT] & 7) || out.ld < p[P_LO_OUT] + out.c || wl_out)) return VSE_E_INVAL;
+            if (p[P_LO_RES] && ((p[P_LO_RES] & 7) || in0.ld < p[P_LO_RES] + in0.c || (op.flags & F_GATE))) return VSE_E_INVAL;
+            // (the pair offsets of the output / of the input ride in the upper bits of `hilo`, in units of 8 channels)
+            const int hilo = ((op.flags & F_HILO) ? 1 : 0) | ((p[P_LO_OUT] >> 3) << 1) | ((p[P_LO_RES] >> 3) << 13);
             if (!(op.flags & F_GATE)) gate.ptr = nullptr;
             else if (!in1.ptr || in1.c != in0.c || in1.n != in0.n || in1.esize != 2) return VSE_E_INVAL;
             if ((kw == 3 || kw == 5) && (sw == 1 || sw == 2)) {

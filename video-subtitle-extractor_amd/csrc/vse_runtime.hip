@@ -211,6 +211,7 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, const int32_t*
         if (o.flags & F_IMGW) a.w = reinterpret_cast<const half_t*>(in2.ptr);      // per-image weights in the workspace
         a.wl_out = wl_out;
         a.lo_off = o.p[P_LO_OUT];
+        a.res_lo_off = o.p[P_LO_RES];
         a.u8src = nullptr; a.u8_h = a.u8_w = 0; a.u8_pitch = a.u8_fstride = 0;
         if (o.flags & F_U8SRC) {
             a.u8src = reinterpret_cast<const uint8_t*>(ext[0]);

@@ -57,6 +57,7 @@ P_KTOT = 9          # padded K (multiple of KT)
 P_INSHIFT = 10      # nearest-upsample shift applied when gathering the input
 P_RESSHIFT = 11     # nearest-upsample shift applied when reading the residual
 P_CINP = 12         # physical input channels (multiple of 8)
+P_LO_RES = 16       # != 0: the residual (in1) is an fp16 hi + lo pair: both halves are added
 P_LO_OUT = 15       # != 0: the output is an fp16 hi + lo PAIR: fp16(v - fp16(v)) is stored P_LO_OUT channels behind the hi value
 # flags for OP_CONV
 F_RES = 1           # has residual (in1)

@@ -68,12 +68,16 @@ class OcrPipeline:
     def __init__(self, ctx, det_model, rec_model, charset, rec_batch_num=6, rec_h=48, rec_base_w=320,
                  limit_side_len=960, db_thresh=0.3, db_box_thresh=0.6, db_unclip_ratio=1.5, drop_score=0.0,
                  rec_mode="ragged", bucket=64, batch_round=1, max_rec_batch=64, det_weights="auto", min_rec_group=0,
-                 det_input="raw"):
+                 det_input="raw", det_chains=None):
         """det_model / rec_model: (descriptor, weights dict).
         det_weights: "fp16" | "fp16x2" | "auto".  fp16x2 stores the detector's conv weights as fp16 hi + lo pairs (two K
         passes into the same fp32 accumulators): the rounding of BN-folded weights to fp16 is what moves box borders against
         an fp32 reference.  "auto" uses it for the mobile detectors (< 4 M parameters), where the second pass
         hides behind the memory traffic, and plain fp16 for the server models.
+        det_chains: None (default) — detectors that run with fp16x2 weights (the mobile models) also run their 1x1 / depthwise runs as
+        LDS-resident chains with fp16 hi + lo pair tensors between ops (compiler chains.py, csrc/chain.hip): a tensor is rounded to 11
+        bits a handful of times per network instead of once per layer — the box parity of DESIGN 4 — at 1.2-1.3x the detector time;
+        False keeps the layer-by-layer program (faster, 2-3 boxes per 400 a pixel row off the fp32 reference).
         det_input: "raw" — the detector is fed the resized uint8 pixels themselves (+ a ones channel) and its stem conv carries
         paddleocr's (x/255 - mean)/std, so it computes on the reference's exact input values; the resize itself happens inside
         the stem kernel's patch staging (no pre-processing pass, no fp16 input tensor); "normalized" — the fp16 rounding
@@ -83,7 +87,7 @@ class OcrPipeline:
         self.det_input = det_input
         self.det_weights = det_weights = resolve_det_weights(det_weights, det_model[1])
         self.det = engine.Net(ctx, det_model[0], det_model[1], fetch_cols=(0,), hilo=det_weights == "fp16x2",
-                              input_norm=DET_NORM if det_input == "raw" else None, fuse_preprocess=det_input == "raw")
+                              input_norm=DET_NORM if det_input == "raw" else None, fuse_preprocess=det_input == "raw", chain=det_chains)
         # ragged plans for every mode: "reference" runs them with uniform widths, so the modes share kernels and summation orders
         self.rec = engine.Net(ctx, rec_model[0], rec_model[1], want_probs=False, ragged=True)
         self.charset = charset
