@@ -32,7 +32,9 @@ if os.environ.get("VSE_CHAIN_TILE"):                  # experiments: force the t
     CHAIN_TILES = [tuple(int(v) for v in os.environ["VSE_CHAIN_TILE"].split(","))]
 CHAIN_TILE_CYC = float(os.environ.get("VSE_CHAIN_TILECYC", "2400"))    # fixed cycles of a tile (input store, prefetch issue, turn-over)
 CHAIN_STAGE_CYC = float(os.environ.get("VSE_CHAIN_STAGECYC", "600"))   # fixed cycles of a stage (descriptor lanes, barrier)
+CHAIN_BLOCKS_CU = int(os.environ.get("VSE_CHAIN_BLOCKS", "3"))         # blocks per CU the kernel's registers allow (VSE_CHAIN_LB in chain.hip)
 CHAIN_ONE_BLOCK = float(os.environ.get("VSE_CHAIN_ONEBLOCK", "1.6"))   # cost factor of a plan that leaves one block per CU
+CHAIN_TWO_BLOCKS = float(os.environ.get("VSE_CHAIN_TWOBLOCKS", "1.2"))  # ... two
 # segmentation: a chain's estimated time is weighted against the layer-by-layer ops it replaces; < 1 prefers chains (they round a
 # tensor to fp16 once per chain instead of once per layer: the detector's box parity) even where they are not faster
 CHAIN_TIME_WEIGHT = float(os.environ.get("VSE_CHAIN_WEIGHT", "0.5"))
@@ -243,8 +245,8 @@ class ChainMixin:
                 else:
                     items, per = -(-rp // 64) * (st["cin"] // 8), 700.0 + 210.0 * st["k"] ** 2
                 cyc += CHAIN_STAGE_CYC + -(-items // 4) * per
-            blocks_cu = min(2, (160 * 1024) // (total + 2048))         # 197-240 VGPRs: two 4-wave blocks per CU at most
-            cost = cyc / float(th * tw) * (CHAIN_ONE_BLOCK if blocks_cu < 2 else 1.0)
+            blocks_cu = min(CHAIN_BLOCKS_CU, (160 * 1024) // (total + 2048))         # 146 VGPRs: three 4-wave blocks per CU at most
+            cost = cyc / float(th * tw) * {1: CHAIN_ONE_BLOCK, 2: CHAIN_TWO_BLOCKS}.get(blocks_cu, 1.0)
             if best is None or cost < best["cost"]:
                 best = dict(cost=cost, th=th, tw=tw, regs=regs, bufs=[dict(b) for b in bufs], lds_total=total, wbytes=wbytes, dims=dims)
         return best
@@ -295,7 +297,7 @@ class ChainMixin:
         ext = [any(c not in inside_all for c in self._live_consumers(st["out_name"])) or st["out_name"] in self.fetched_names
                or st["out_name"] in self.placement for st in path]
         INF = float("inf")
-        nimg = inv.n
+        nimg = 64          # a NOMINAL batch: the cut must not depend on the batch a frame rides in (its values would)
 
         def seg_cost(i, j):               # estimated microseconds of stages i..j inclusive (0-based) as ONE op
             if i == j:
@@ -319,8 +321,10 @@ class ChainMixin:
                 return INF
             oh_, ow_ = dims[j + 1]
             ntiles = nimg * -(-oh_ // plan["th"]) * -(-ow_ // plan["tw"])
-            blocks = 256 * min(2, (160 * 1024) // (plan["lds_total"] + 2048))
-            us = -(-ntiles // blocks) * plan["cost"] * plan["th"] * plan["tw"] / (CHAIN_ONE_BLOCK if blocks < 512 else 1.0) / 2100.0
+            bcu = min(CHAIN_BLOCKS_CU, (160 * 1024) // (plan["lds_total"] + 2048))
+            blocks = 256 * bcu
+            # (plan["cost"] carries the occupancy factor of its block count: undo it, the rounds of tiles below account for the blocks)
+            us = -(-ntiles // blocks) * plan["cost"] * plan["th"] * plan["tw"] / {1: CHAIN_ONE_BLOCK, 2: CHAIN_TWO_BLOCKS}.get(bcu, 1.0) / 2100.0
             return CHAIN_TIME_WEIGHT * us + 6.0
 
         best = [0.0] * (n + 1)

@@ -77,7 +77,10 @@ __device__ __forceinline__ void dw_taps(const float* __restrict__ plane, int ew_
         for (int dx = 0; dx < K; ++dx) acc = fmaf(w[dy * K + dx], plane[dy * ew_in + dx], acc);
 }
 
-__global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
+#ifndef VSE_CHAIN_LB
+#define VSE_CHAIN_LB 3        // blocks per CU the register budget is sized for (146 VGPRs: 3 without spills; 4 spills 10 VGPRs)
+#endif
+__global__ __launch_bounds__(256, VSE_CHAIN_LB) void chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // The descriptor (<= 400 words) is copied into LDS once per block and read from there.  Read from global memory, hipcc turned the
     // per-stage reads into VECTOR loads + v_readfirstlane (the stage index is a loop variable): two or three DEPENDENT global round
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
 
     // ---- chain input: region of buffer 0 from global NHWC fp16 (zeros outside the image) -------------------------------------------
     // Loads come from CLAMPED addresses (an `if` around a load makes hipcc branch and wait per element) and are selected afterwards.
-    constexpr int LU = 4;
+    constexpr int LU = 2;
     const int b0_kind = BF[B_KIND], b0_C = BF[B_C], b0_Cp = BF[B_CP], b0_stride = BF[B_STRIDE], b0_P = BF[B_P], b0_ew = BF[B_EW];
     const int b0_hi = BF[B_OFF_HI], b0_lo = BF[B_OFF_LO], b0_th = BF[B_TH], b0_ah = BF[B_AH], b0_tw = BF[B_TW], b0_aw = BF[B_AW];
     const int b0_H = BF[B_HIMG], b0_W = BF[B_WIMG];
@@ -398,17 +401,19 @@ __global__ __launch_bounds__(256, 2) void chain_kernel(const ChainArgs a) {
                         v[j] = acc;
                     }
                 } else {
+                    // 5 x 5: the record is read row by row (25 weights + bias in registers at once cost 28 VGPRs per channel in flight)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float4v* wr = reinterpret_cast<const float4v*>(wl + (cg * 8 + j) * 28);
-                        float w[28];
+                        const float* wr = wl + (cg * 8 + j) * 28;
+                        const float* pl = base + (size_t)j * pstride;
+                        float acc = wr[25];
+                        if (!(VSE_CHAIN_ABL & 2)) {
 #pragma unroll
-                        for (int q = 0; q < 7; ++q) {
-                            const float4v t4 = wr[q];
-                            w[4 * q] = t4[0]; w[4 * q + 1] = t4[1]; w[4 * q + 2] = t4[2]; w[4 * q + 3] = t4[3];
+                            for (int dy = 0; dy < 5; ++dy) {
+#pragma unroll
+                                for (int dx = 0; dx < 5; ++dx) acc = fmaf(wr[dy * 5 + dx], pl[dy * ew_in + dx], acc);
+                            }
                         }
-                        float acc = w[25];
-                        if (!(VSE_CHAIN_ABL & 2)) dw_taps<5>(base + (size_t)j * pstride, ew_in, w, acc);
                         v[j] = acc;
                     }
                 }
@@ -494,7 +499,7 @@ int launch_chain(const vse_op& o, const TView& in0, const TView& out, const TVie
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return VSE_E_HIP;
         n_cu = prop.multiProcessorCount;
     }
-    const int per_cu = std::max(1, std::min(2, (160 * 1024) / (lds_bytes + 2048)));      // (229 VGPRs: two 4-wave blocks per CU)
+    const int per_cu = std::max(1, std::min(VSE_CHAIN_LB, (160 * 1024) / (lds_bytes + 2048)));
     unsigned grid = (unsigned)std::min<unsigned long long>(blocks, (unsigned long long)n_cu * per_cu);
     if (grid > 8) grid &= ~7u;
 #ifdef VSE_CHAIN_TRACE
