@@ -427,6 +427,18 @@ class Emulator:
     def _op7(self, r):   # RESIZE
         x = self._up(self.read(r["in0"]), int(r["p"][0]))
         oc = int(r["out"]["c"])
+        flags = int(r["flags"])
+        if flags & (ir.F_GATE | ir.F_SRC2):      # gated form: up(x) * (1 + gate) (F_RES) per source; F_SRC2: a second source beside it
+            def gated(t, gview):
+                if not (flags & ir.F_GATE):
+                    return t
+                g = self.read(gview)[..., :t.shape[3]]
+                return t * ((1.0 if flags & ir.F_RES else 0.0) + g)
+            parts = [gated(x, r["in1"])]
+            if flags & ir.F_SRC2:
+                parts.append(gated(self._up(self.read(r["in2"]), int(r["p"][1])), r["out2"]))
+            x = torch.cat(parts, dim=3)
+            assert x.shape[3] == oc
         self.write(r["out"], x[..., :oc])
 
     def _op8(self, r):   # UNARY

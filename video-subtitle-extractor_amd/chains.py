@@ -33,8 +33,8 @@ if os.environ.get("VSE_CHAIN_TILE"):                  # experiments: force the t
 CHAIN_TILE_CYC = float(os.environ.get("VSE_CHAIN_TILECYC", "2400"))    # fixed cycles of a tile (input store, prefetch issue, turn-over)
 CHAIN_STAGE_CYC = float(os.environ.get("VSE_CHAIN_STAGECYC", "600"))   # fixed cycles of a stage (descriptor lanes, barrier)
 CHAIN_BLOCKS_CU = int(os.environ.get("VSE_CHAIN_BLOCKS", "3"))         # blocks per CU the kernel's registers allow (VSE_CHAIN_LB in chain.hip)
-CHAIN_ONE_BLOCK = float(os.environ.get("VSE_CHAIN_ONEBLOCK", "1.6"))   # cost factor of a plan that leaves one block per CU
-CHAIN_TWO_BLOCKS = float(os.environ.get("VSE_CHAIN_TWOBLOCKS", "1.2"))  # ... two
+CHAIN_ONE_BLOCK = float(os.environ.get("VSE_CHAIN_ONEBLOCK", "2.4"))   # cost factor of a plan that leaves one block per CU
+CHAIN_TWO_BLOCKS = float(os.environ.get("VSE_CHAIN_TWOBLOCKS", "1.4"))  # ... two
 # segmentation: a chain's estimated time is weighted against the layer-by-layer ops it replaces; < 1 prefers chains (they round a
 # tensor to fp16 once per chain instead of once per layer: the detector's box parity) even where they are not faster
 CHAIN_TIME_WEIGHT = float(os.environ.get("VSE_CHAIN_WEIGHT", "0.5"))

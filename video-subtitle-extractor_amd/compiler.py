@@ -69,6 +69,8 @@ class View:
     up: int = 0                    # virtual nearest-upsample shift (logical h,w already upsampled)
     tag: str = "nchw"              # logical layout of the Paddle tensor this view stands for
     parts: Optional[list] = None   # virtual 2-way concat: [View, View] gathered by the consumer conv (no copy)
+    gate: Optional[tuple] = None   # (gate View, flags): the tensor is  this * gate  (F_RES: this * (1 + gate)), not yet multiplied — an SE
+                                   # output whose only reader is a concat: the copy into the slot applies it (lower_concat)
 
     @property
     def c(self):
@@ -198,6 +200,7 @@ COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
 # ACROSS plans of one process; a different value is a different set of summation orders)
 RAGGED_SEL_W = int(os.environ.get("VSE_RAGGED_SELW", "768"))
 ONECH = os.environ.get("VSE_ONECH", "1") != "0"             # DB head: last transposed conv stores the fp32 map directly
+GATE_CONCAT = os.environ.get("VSE_GATE_CONCAT", "1") != "0"   # SE output that only feeds a concat: multiplied by the copy into the slot
 SE_LATERAL = os.environ.get("VSE_SE_LATERAL", "1") != "0"   # 1x1 conv + SE block with shortcut -> one gated conv (F_OGATE)
 LSTM_MFMA = os.environ.get("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
 LSTM_WAVES = int(os.environ.get("VSE_LSTM_WAVES", "16"))    # 8: lstm_mfma_kernel, 16: lstm_mfma16_kernel (twice the loads in flight)
@@ -793,7 +796,7 @@ class Compiler(ChainMixin):
         if src is None:
             return False
         outname = op["out"]["Out"][0]
-        v = View(src.buf, src.coff, src.n, src.h, src.w, list(src.segs), src.span, src.up, src.tag)
+        v = View(src.buf, src.coff, src.n, src.h, src.w, list(src.segs), src.span, src.up, src.tag, gate=src.gate)
         if t == "nearest_interp_v2":
             s = a["scale"]
             assert s[0] == s[1] and s[0] in (2.0, 4.0, 8.0), s
@@ -1635,6 +1638,11 @@ class Compiler(ChainMixin):
                         self.pending_wgate[outname] = gate
                 self.env[outname] = big
                 return
+            if GATE_CONCAT and self._only_feeds_concat(outname) and big.c % 8 == 0 and gate.c == big.c:
+                # the SE output is read by a concat only (directly or through a nearest up-sampling): the copy into the concat slot
+                # multiplies (lower_concat, gated OP_RESIZE) — no separate scale pass, one rounding instead of two
+                self.env[outname] = View(big.buf, big.coff, big.n, big.h, big.w, list(big.segs), big.span, big.up, big.tag, gate=(gate, flags))
+                return
             out = self.alloc_out(outname, big.n, big.h, big.w, big.c)
             self.emit(ir.OP_SCALE, outname, [big, gate], out, flags=flags)
             self.env[outname] = out
@@ -1656,6 +1664,20 @@ class Compiler(ChainMixin):
         out.tag = x.tag
         self.emit(ir.OP_BINARY, outname, [x, y], out, p={ir.P_BIN_MUL: 0, ir.P_BIN_SHIFT: y.up, ir.P_BIN_ACT: act})
         self.env[outname] = out
+
+    def _only_feeds_concat(self, name):
+        """`name` is read by exactly one op: a non-virtual concat, or a nearest_interp whose only reader is one."""
+        cons = self._live_consumers(name)
+        if len(cons) != 1 or name in self.fetched_names:
+            return False
+        o = self.ops[cons[0]]
+        if o["type"] == "nearest_interp_v2":
+            nm = o["out"]["Out"][0]
+            cons = self._live_consumers(nm)
+            if len(cons) != 1 or nm in self.fetched_names:
+                return False
+            o = self.ops[cons[0]]
+        return o["type"] == "concat" and o["out"]["Out"][0] not in self.virtual_concats and o["attrs"].get("axis") == 1
 
     def lower_unary(self, i):
         op = self.ops[i]
@@ -1697,23 +1719,50 @@ class Compiler(ChainMixin):
         lay = self._concat_buf(name, v0.n, v0.h, v0.w)
         b = lay["buf"]
         segs = []
+        copies = []                     # (input view, destination channel offset, channels) of the inputs that are not in place
         for nm, v, (off, c) in zip(op["in"]["X"], ins, lay["offs"]):
             assert (v.n, v.h, v.w, v.c) == (b.n, b.h, b.w, c), (name, nm, v, c)
-            if not (v.buf is b and v.coff == off and v.up == 0):
+            if not (v.buf is b and v.coff == off and v.up == 0 and v.gate is None):
                 if v.parts is not None:
                     v = self.materialize(v, name + ":" + nm)
-                # a multi-segment input (a nested concat whose parts are not multiples of 8 channels) is copied piece by piece;
-                # every piece must land on an 8-channel boundary of the destination (the copy kernel moves 8-channel groups)
-                done_c = 0
-                for st, cnt in v.segs:
-                    if done_c % 8:
-                        raise UnsupportedGraph(f"concat {name}: input {nm} has channel segments {v.segs} that do not fall on "
-                                               "8-channel boundaries")
-                    piece = View(v.buf, v.coff + st, v.n, v.h, v.w, [(0, cnt)], rup(cnt, 8), v.up, v.tag)
-                    dst = View(b, off + done_c, v.n, v.h, v.w, [(0, cnt)], rup(cnt, 8))
-                    self.emit(ir.OP_RESIZE, name + ":" + nm, [piece], dst, p={0: v.up})
-                    done_c += cnt
+                if v.gate is not None or (v.segs == [(0, v.c)] and v.c % 8 == 0):
+                    copies.append((nm, v, off, c))
+                else:
+                    # a multi-segment input (a nested concat whose parts are not multiples of 8 channels) is copied piece by piece;
+                    # every piece must land on an 8-channel boundary of the destination (the copy kernel moves 8-channel groups)
+                    done_c = 0
+                    for st, cnt in v.segs:
+                        if done_c % 8:
+                            raise UnsupportedGraph(f"concat {name}: input {nm} has channel segments {v.segs} that do not fall on "
+                                                   "8-channel boundaries")
+                        piece = View(v.buf, v.coff + st, v.n, v.h, v.w, [(0, cnt)], rup(cnt, 8), v.up, v.tag)
+                        dst = View(b, off + done_c, v.n, v.h, v.w, [(0, cnt)], rup(cnt, 8))
+                        self.emit(ir.OP_RESIZE, name + ":" + nm, [piece], dst, p={0: v.up})
+                        done_c += cnt
             segs.append((off, c))
+        # dense inputs: plain / gated copies; two inputs with ADJACENT slots share a launch (2 x C contiguous channels per pixel)
+        k = 0
+        while k < len(copies):
+            nm, v, off, c = copies[k]
+            pair = (k + 1 < len(copies) and copies[k + 1][2] == off + c and c % 8 == 0
+                    and (v.gate is None) == (copies[k + 1][1].gate is None)
+                    and (v.gate is None or v.gate[1] == copies[k + 1][1].gate[1]))
+            src = View(v.buf, v.coff, v.n, v.h, v.w, [(0, c)], rup(c, 8), v.up, v.tag)
+            fl = 0 if v.gate is None else (ir.F_GATE | (v.gate[1] & ir.F_RES))
+            if pair:
+                nm2, v2, off2, c2 = copies[k + 1]
+                src2 = View(v2.buf, v2.coff, v2.n, v2.h, v2.w, [(0, c2)], rup(c2, 8), v2.up, v2.tag)
+                dst = View(b, off, v.n, v.h, v.w, [(0, c + c2)], rup(c + c2, 8))
+                self.emit(ir.OP_RESIZE, name + ":" + nm + "+" + nm2, [src, v.gate[0] if v.gate else None, src2], dst, flags=fl | ir.F_SRC2,
+                          p={0: v.up, 1: v2.up}, out2=v2.gate[0] if v2.gate else None)
+                k += 2
+            else:
+                dst = View(b, off, v.n, v.h, v.w, [(0, c)], rup(c, 8))
+                if fl:
+                    self.emit(ir.OP_RESIZE, name + ":" + nm, [src, v.gate[0]], dst, flags=fl, p={0: v.up})
+                else:
+                    self.emit(ir.OP_RESIZE, name + ":" + nm, [src], dst, p={0: v.up})
+                k += 1
         out = View(b, 0, v0.n, v0.h, v0.w, merge_segs(segs), b.ld)
         self.env[name] = out
 
