@@ -291,6 +291,23 @@ class Emulator:
             oc2 = int(r["out2"]["c"])
             self.write(r["out2"], z if oc2 == 1 else F.pad(z, (0, oc2 - 1)))
             return
+        if int(r["flags"]) & ir.F_DWPRE:
+            # depthwise conv in front of the 1x1 conv (csrc/conv_dwpw.hip): decoded from the aux blob; the 1x1 part below is a plain F_PW conv
+            assert int(r["flags"]) & ir.F_PW and int(r["flags"]) & ir.F_HILO and kh == kw and sh == sw and ph == pw
+            hdr = self.wread(int(r["aux_off"]), 8, np.float32)
+            hi_ = hdr.view(np.int32)
+            assert (int(hi_[0]), int(hi_[1]), int(hi_[2])) == (kh, sh, ph)
+            tab = self.wread(int(r["aux_off"]) + 32, (kh * kw + 1) * Kp, np.float32).reshape(kh * kw + 1, Kp)
+            if int(p[ir.P_LO_IN]):                # the input is an fp16 hi + lo pair
+                lv = r["in0"].copy()
+                lv["off"] = int(lv["off"]) + int(p[ir.P_LO_IN]) * int(lv["esize"])
+                x = x + self.read(lv)
+            wd = torch.from_numpy(np.ascontiguousarray(tab[:kh * kw, :cinp].T.reshape(cinp, 1, kh, kw)))
+            xd = F.conv2d(x.permute(0, 3, 1, 2), wd, torch.from_numpy(tab[kh * kw, :cinp].copy()), (sh, sw), (ph, pw), groups=cinp)
+            xd = _act(xd, int(hi_[3]), float(hdr[4]), float(hdr[5])) * float(hdr[6]) + float(hdr[7])
+            x = xd.permute(0, 2, 3, 1)            # (the kernel keeps this as an fp16 hi + lo pair in registers: ~fp32)
+            kh = kw = sh = sw = 1
+            ph = pw = 0
         if int(r["flags"]) & ir.F_PW:
             assert (kh, kw) == (1, 1) and Kp == (cinp + 15) // 16 * 16
             wmat = self.wread(int(r["w_off"]), Np * Kp, np.float16).astype(np.float32).reshape(Np, Kp)

@@ -389,7 +389,7 @@ def test_mobile_detector_chains_and_gated_laterals(mid):
     plain = compiler.compile_model(desc, w, 2, 96, 160, hilo=True, chain=False)
     kinds = [int(o["kind"]) for o in prog.ops]
     chains = [o for o in prog.ops if int(o["kind"]) == ir.OP_CHAIN]
-    assert len(chains) >= 3 and len(prog.ops) < len(plain.ops) - 5          # (where the path is cut follows the time model: chains.py)
+    assert len(chains) >= 3 and len(prog.ops) < len(plain.ops)              # (where the path is cut follows the time model: chains.py)
     gated = [o for o in prog.ops if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_OGATE]
     assert len(gated) == 4 and sum(bool(int(o["flags"]) & ir.F_RES) for o in gated) == 3      # four laterals, three top-down adds
     assert ir.OP_SCALE not in [int(o["kind"]) for o in prog.ops if int(o["out"]["c"]) == 96]        # no 96-channel SE multiply is left

@@ -109,6 +109,8 @@ class ChainMixin:
         ph, pw = (pads[0], pads[1]) if len(pads) == 2 else (pads[0], pads[2])
         groups = a.get("groups", 1)
         if t == "depthwise_conv2d" or (groups > 1 and groups == w.shape[0] and w.shape[1] == 1):
+            if self.dwpw_eligible(i):
+                return None          # depthwise -> 1x1 runs as ONE streaming kernel (conv_dwpw.hip): faster than an LDS-resident chain
             k = w.shape[2]
             if w.shape[2] == w.shape[3] and k in (3, 5) and sh == sw and sh in (1, 2) and ph == pw == k // 2 and w.shape[0] % 8 == 0:
                 return dict(type="dw", k=int(k), s=int(sh), cin=int(w.shape[0]), cout=int(w.shape[0]))

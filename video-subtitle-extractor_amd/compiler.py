@@ -201,6 +201,7 @@ COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
 RAGGED_SEL_W = int(os.environ.get("VSE_RAGGED_SELW", "768"))
 ONECH = os.environ.get("VSE_ONECH", "1") != "0"             # DB head: last transposed conv stores the fp32 map directly
 GATE_CONCAT = os.environ.get("VSE_GATE_CONCAT", "1") != "0"   # SE output that only feeds a concat: multiplied by the copy into the slot
+DWPW = os.environ.get("VSE_DWPW", "1") != "0"                 # depthwise conv fused in front of its 1x1 consumer (hi + lo nets: conv_dwpw.hip)
 SE_LATERAL = os.environ.get("VSE_SE_LATERAL", "1") != "0"   # 1x1 conv + SE block with shortcut -> one gated conv (F_OGATE)
 LSTM_MFMA = os.environ.get("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
 LSTM_WAVES = int(os.environ.get("VSE_LSTM_WAVES", "16"))    # 8: lstm_mfma_kernel, 16: lstm_mfma16_kernel (twice the loads in flight)
@@ -1432,6 +1433,130 @@ class Compiler(ChainMixin):
         self.add_gmacs(inv.n * oh * ow * c * kh * kw / 1e9)
         self.env[ep["out_name"]] = out
 
+    def dwpw_eligible(self, i):
+        """Structural half of try_lower_dwpw, without side effects: op i is a depthwise conv (3x3 / 5x5, stride 1 / 2, <= 96 channels)
+        whose only reader — behind its own BN / activation — is a plain 1x1 conv with <= 192 couts."""
+        if not (DWPW and self.hilo) or self.ragged or i in self.done or not self.live[i]:
+            return False
+        op = self.ops[i]
+        if op["type"] not in ("conv2d", "depthwise_conv2d"):
+            return False
+        w = self.W[op["in"]["Filter"][0]]
+        a = op["attrs"]
+        groups = a.get("groups", 1)
+        if not (op["type"] == "depthwise_conv2d" or (groups > 1 and groups == w.shape[0] and w.shape[1] == 1)):
+            return False
+        c, _, kh, kw = w.shape
+        sh, sw = a["strides"]
+        pads = a["paddings"]
+        ph, pw = (pads[0], pads[1]) if len(pads) == 2 else (pads[0], pads[2])
+        if kh != kw or kh not in (3, 5) or sh != sw or sh not in (1, 2) or ph != pw or ph != kh // 2 or c % 8 or c > 96:
+            return False
+        snapshot = set(self.done)
+        try:
+            ep_d = self.absorb_epilogue(op["out"]["Output"][0], i, c, allow_res=False)
+        finally:
+            self.done = snapshot
+        dname = ep_d["out_name"]
+        cons = self._live_consumers(dname)
+        if len(cons) != 1 or dname in self.placement or dname in self.fetched_names or ep_d["act2"] != ir.ACT_NONE:
+            return False
+        o2 = self.ops[cons[0]]
+        if o2["type"] != "conv2d" or o2["in"]["Input"][0] != dname or o2["attrs"].get("out_gate") is not None:
+            return False
+        w2 = self.W[o2["in"]["Filter"][0]]
+        a2 = o2["attrs"]
+        return (a2.get("groups", 1) == 1 and tuple(w2.shape[1:]) == (c, 1, 1) and list(a2["strides"]) == [1, 1] and not any(a2["paddings"])
+                and rup(w2.shape[0], 8) <= 192)
+
+    def try_lower_dwpw(self, i):
+        """depthwise k x k conv whose only reader is a 1x1 stride-1 conv (the PP-LCNetV3 unit, the depthwise -> project half of a
+        MobileNetV3 unit) in a hi + lo net -> ONE conv op (F_DWPRE, csrc/conv_dwpw.hip): the lane that needs 8 channels of a pixel as
+        its MFMA B fragment COMPUTES them from the k x k neighbourhood (fp32, split into an fp16 hi + lo pair) instead of loading
+        them.  The depthwise output — the widest tensor of the unit — is never written, read back or rounded."""
+        if not self.dwpw_eligible(i):
+            return False
+        op = self.ops[i]
+        w = self.W[op["in"]["Filter"][0]]
+        a = op["attrs"]
+        groups = a.get("groups", 1)
+        if not (op["type"] == "depthwise_conv2d" or (op["type"] == "conv2d" and groups > 1 and groups == w.shape[0] and w.shape[1] == 1)):
+            return False
+        c, _, kh, kw = w.shape
+        sh, sw = a["strides"]
+        pads = a["paddings"]
+        ph, pw = (pads[0], pads[1]) if len(pads) == 2 else (pads[0], pads[2])
+        if kh != kw or kh not in (3, 5) or sh != sw or sh not in (1, 2) or ph != pw or c % 8 or c > 96:
+            return False
+        inname = op["in"]["Input"][0]
+        inv = self.resolve(inname)
+        if (inv is None or inv.tag != "nchw" or inv.parts is not None or inv.up or inv.segs != [(0, inv.c)] or inv.c != c or inv.buf.esize != 2
+                or inv.coff % 8 or inname in self.pending_gate or inname in self.pending_wgate):
+            return False
+        snapshot = set(self.done)
+        ep_d = self.absorb_epilogue(op["out"]["Output"][0], i, c, allow_res=False)
+        dname = ep_d["out_name"]
+        cons = self._live_consumers(dname)
+        ok = len(cons) == 1 and dname not in self.placement and dname not in self.fetched_names and ep_d["act2"] == ir.ACT_NONE
+        if ok:
+            o2 = self.ops[cons[0]]
+            ok = o2["type"] == "conv2d" and o2["in"]["Input"][0] == dname and o2["attrs"].get("out_gate") is None
+        if ok:
+            w2 = self.W[o2["in"]["Filter"][0]]
+            a2 = o2["attrs"]
+            ok = (a2.get("groups", 1) == 1 and tuple(w2.shape[1:]) == (c, 1, 1) and list(a2["strides"]) == [1, 1] and not any(a2["paddings"])
+                  and rup(w2.shape[0], 8) <= 192)
+        if not ok:
+            self.done = snapshot
+            return False
+        j = cons[0]
+        cout = int(w2.shape[0])
+        oh = (inv.h + 2 * ph - kh) // sh + 1
+        ow = (inv.w + 2 * pw - kw) // sw + 1
+        ep = self.absorb_epilogue(o2["out"]["Output"][0], j, cout, out_dims=(inv.n, oh, ow))
+        res = ep["res"]
+        if res is not None and (res.up or (res.n, res.h, res.w, res.c) != (inv.n, oh, ow, cout) or res.segs != [(0, cout)]):
+            self.done = snapshot
+            return False
+        self.done.add(i)
+        self.done.add(j)
+        coutp, ks = rup(cout, 8), rup(c, 16) // 16
+        cp = ks * 16
+        # the 1x1 weights: conv_pw's plain [Np][Kp] layout, hi table then lo table
+        mat = np.zeros((coutp, cp), np.float64)
+        mat[:cout, :c] = w2[:, :, 0, 0].astype(np.float64) * ep["scale"].reshape(-1, 1)
+        bias = np.zeros(coutp, np.float32)
+        bias[:cout] = ep["shift"]
+        # the depthwise table: [k*k + 1][Kp] fp32 (BN / affine folded; last row = bias), behind 8 header words
+        k2 = kh * kw
+        tab = np.zeros((k2 + 1, cp), np.float32)
+        tab[:k2, :c] = (w.astype(np.float64)[:, 0] * ep_d["scale"].reshape(-1, 1, 1)).reshape(c, k2).T
+        tab[k2, :c] = ep_d["shift"]
+        hdr = np.zeros(8, np.float32)
+        hdr.view(np.int32)[:4] = [kh, sh, ph, ep_d["act"]]
+        hdr[4:] = [ep_d["act_a"], ep_d["act_b"], ep_d["post_a"], ep_d["post_b"]]
+        wname, dwname = o2["in"]["Filter"][0], op["in"]["Filter"][0]
+        w_off = self.add_weights(("dwpw_w", wname, ep["out_name"]), lambda: self.pw_weights(mat, True))
+        b_off = self.add_weights(("dwpw_b", wname, ep["out_name"]), bias)
+        aux_off = self.add_weights(("dwpw_t", dwname, dname), np.concatenate([hdr, tab.reshape(-1)]))
+        out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout, lo=self.wants_lo(ep["out_name"]))
+        flags = ir.F_PW | ir.F_HILO | ir.F_DWPRE
+        ins = [inv]
+        if res is not None:
+            flags |= ir.F_RES
+            ins.append(res)
+        self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
+                  p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw, ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"],
+                     ir.P_COUT: coutp, ir.P_KTOT: cp, ir.P_INSHIFT: 0, ir.P_RESSHIFT: 0, ir.P_CINP: inv.span,
+                     ir.P_LO_OUT: out.buf.lo_off,
+                     ir.P_LO_IN: inv.buf.lo_off if (inv.coff == 0 and getattr(self, "chain_lo", True)) else 0,
+                     ir.P_LO_RES: (res.buf.lo_off if (res is not None and res.buf is not None and res.coff == 0) else 0)},
+                  f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"], ir.FS_POST_B: ep["post_b"]},
+                  w_off=w_off, b_off=b_off, aux_off=aux_off)
+        self.add_gmacs(inv.n * oh * ow * (c * k2 + c * cout) / 1e9)
+        self.env[ep["out_name"]] = out
+        return True
+
     def lower_linear(self, i):
         """matmul_v2 with a parameter RHS = 1x1 conv over [B,1,T,C]."""
         op = self.ops[i]
@@ -1907,7 +2032,7 @@ class Compiler(ChainMixin):
             elif t == "fetch":
                 self._lower_fetch(i)
             elif t in ("conv2d", "depthwise_conv2d", "conv2d_transpose"):
-                if not self.try_lower_chain(i) and not self.try_lower_head_tail(i):
+                if not self.try_lower_dwpw(i) and not self.try_lower_chain(i) and not self.try_lower_head_tail(i):
                     self.lower_conv(i)
             elif t == "batch_norm":
                 raise NotImplementedError(f"stand-alone batch_norm at op {i}")

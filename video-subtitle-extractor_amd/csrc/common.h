@@ -13,11 +13,11 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_SWISH = 3, ACT_SIGMOID = 4, ACT_HSIGMOID = 5 };
 enum { OP_CONV = 1, OP_DWCONV, OP_POOL, OP_GAP, OP_SCALE, OP_BINARY, OP_RESIZE, OP_UNARY, OP_LAYERNORM, OP_ATTN,
        OP_SOFTMAX, OP_LSTM, OP_WSCALE, OP_CHAIN };   // OP_CHAIN: 1x1 / depthwise conv chain with LDS-resident intermediates (chain.hip)
-enum { F_LSTM_MFMA = 16384, F_ONECH = 32768, F_U8SRC = 65536, F_OGATE = 131072 };   // F_OGATE: in2 = per-image output gate (see ir.py)   // F_U8SRC: the stem conv resizes the uint8 BGR frames itself (see ir.py)   // F_ONECH: pixel-shuffle conv to one channel stores the fp32 map itself (see ir.py)
+enum { F_LSTM_MFMA = 16384, F_ONECH = 32768, F_U8SRC = 65536, F_OGATE = 131072, F_DWPRE = 262144 };   // F_DWPRE: depthwise conv fused in front of a 1x1 conv (conv_dwpw.hip)   // F_OGATE: in2 = per-image output gate (see ir.py)   // F_U8SRC: the stem conv resizes the uint8 BGR frames itself (see ir.py)   // F_ONECH: pixel-shuffle conv to one channel stores the fp32 map itself (see ir.py)
 enum { F_LSTM_MFMA_ = 0 };   // OP_LSTM: W_hh^T in MFMA fragment order, H = 256 (lstm.hip); p[P_REVERSE] = 2: both directions, in1 = reverse gates
 enum { F_RES = 1, F_PIXSHUF = 2, F_OUT_F32 = 4, F_PATCH = 8, F_DOT1 = 16, F_SRC2 = 32, F_UP2HEAD = 64, F_WK32 = 128, F_GATE = 256, F_STEM = 512, F_HILO = 1024, F_COL = 2048, F_PW = 4096, F_IMGW = 8192 };
 // p[] slots (keep in sync with ir.py)
-enum { P_KH = 0, P_KW, P_SH, P_SW, P_PH, P_PW, P_ACT, P_ACT2, P_COUT, P_KTOT, P_INSHIFT, P_RESSHIFT, P_CINP, P_DOTACT, P_IN2SHIFT, P_LO_OUT, P_LO_RES };
+enum { P_KH = 0, P_KW, P_SH, P_SW, P_PH, P_PW, P_ACT, P_ACT2, P_COUT, P_KTOT, P_INSHIFT, P_RESSHIFT, P_CINP, P_DOTACT, P_IN2SHIFT, P_LO_OUT, P_LO_RES, P_LO_IN };
 enum { P_POOL_MAX = 6, P_POOL_CEIL = 7, P_POOL_EXCL = 8 };
 // ragged plans: 1 + width level of in0 / of the output (0 = no per-sample width); the run supplies widths[level][n]
 enum { P_WLIN = 20, P_WLOUT = 21 };
@@ -60,6 +60,7 @@ struct ConvArgs {
     const int* wl_out;
     int lo_off;           // P_LO_OUT: channel offset of the lo half of an fp16 hi + lo pair output (0 = plain fp16)
     int res_lo_off;       // P_LO_RES: ... of the residual
+    int in_lo_off;        // P_LO_IN: ... of the input (F_DWPRE)
     // F_U8SRC: the uint8 BGR frames the stem conv pre-processes itself (vse_plan_set_source)
     const uint8_t* u8src;
     int u8_h, u8_w;

@@ -34,6 +34,7 @@ struct ConvParams {
     long wimg_stride;       // F_IMGW: weight elements per image (Kp * Np); M tiles are then aligned to images
     int hw_img, tiles_img;  // F_IMGW: output pixels per image, M tiles per image
     const int* wl_out;      // ragged plans: per-image output width; pixels at ow >= wl_out[n] are stored as zeros
+    int in_lo_off;          // F_DWPRE: != 0: the INPUT is an fp16 hi + lo pair (both halves are filtered)
     int res_lo_off;         // != 0: the residual is an fp16 hi + lo pair: its lo half sits res_lo_off channels behind the hi half
     int lo_off;             // != 0: fp16 hi + lo pair output: fp16(v - fp16(v)) goes lo_off channels behind the hi value
     const half_t* ogate;    // F_OGATE: per-(image, cout) gate [n][ogate_ld] fp16; the value is multiplied by (1 + gate) ahead of the residual
@@ -330,6 +331,9 @@ int launch_conv_patch(const ConvParams& p, int n_img, hipStream_t st);
 // one filter column per step over a 16-channel patch (conv_col.hip, F_COL): 9x9 / 7x7 / 5x5, <= 64 couts
 int launch_conv_col(const ConvParams& p, int n_img, hipStream_t st);
 int launch_conv_col3w(const ConvParams& p, int n_img, hipStream_t st);
+// depthwise k x k conv fused in front of a 1x1 conv (conv_dwpw.hip, F_DWPRE): p.kh / sh / ph = the depthwise geometry, p.dotw = its table
+int launch_conv_dwpw(const ConvParams& p, hipStream_t st);
+bool conv_dwpw_ok(int k, int s, int cinp, int Np, int flags);
 // 3x3 sibling, two blocks per CU (conv_c3.hip, F_COL with kh = kw = 3)
 int launch_conv_c3(const ConvParams& p, int n_img, hipStream_t st);
 double conv_c3_plan(int OH, int OW, int* rw_out);

@@ -1,0 +1,171 @@
+// Depthwise k x k conv FUSED INTO the 1x1 conv that follows it (F_DWPRE): the PP-LCNetV3 unit  depthwise -> pointwise  of the mobile
+// models, and the  depthwise -> project  half of a MobileNetV3 unit, as ONE streaming kernel.
+//
+// conv_pw_kernel's observation carries over: with <= 96 input channels the activations of a 1x1 conv need no staging — the MFMA B fragment
+// of lane (pixel, k-half) is 8 consecutive channels of its pixel.  Here those 8 channels are not LOADED but COMPUTED: the lane gathers the
+// k x k neighbourhood of its pixel for its 8 channels (16-byte loads straight from global memory, clamped addresses, served by L1 / L2:
+// HBM sees the input once), applies the depthwise filter + bias + activation in fp32 and splits the result into an fp16 hi + lo pair —
+// exactly the B operands of  W_hi x_hi + W_lo x_hi + W_hi x_lo.  The depthwise output (the widest tensor of the unit at 272 x 480 ...
+// 68 x 120) is never written, never read back and never rounded to 11 bits; there is no LDS tile, no halo recompute and no barrier
+// beyond the one behind the weight staging (contrast csrc/chain.hip, whose LDS-resident tiles lose to the layers they fuse).
+//   block = 256 threads = 4 waves x 64 output pixels; 1x1 weights hi + lo [Np][KS * 16 (+ 8 pad)] and the depthwise table
+//           [k * k + 1][KS * 16] fp32 (last row = bias) staged once per block (dynamic LDS)
+//   input  = NHWC fp16, optionally an fp16 hi + lo pair (p.in_lo_off: both halves are filtered)
+//   output = the shared conv epilogue (bias, activation, residual, gate, pair store)
+// Bound: HBM (input once + output); L1 serves k * k x the input bytes.
+#include "conv_common.h"
+
+// aux blob (fp32 words, ints by bit pattern): [0] k  [1] stride  [2] pad  [3] act  [4] act_a  [5] act_b  [6] post_a  [7] post_b, then the
+// depthwise table [k * k + 1][KS * 16]
+template <int KS, int K, bool LO>
+__global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_dwpw_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char dlds[];
+    constexpr int ROWH = KS * 16 + 8, CP = KS * 16, K2 = K * K;
+    const int ntile = (p.Np + 31) >> 5;
+    half_t* swt = reinterpret_cast<half_t*>(dlds);                              // [2][ntile * 32][ROWH]
+    float* sdw = reinterpret_cast<float*>(dlds + (size_t)2 * ntile * 32 * ROWH * 2);     // [K2 + 1][CP]
+    float* sbias = sdw + (K2 + 1) * CP;                                          // [ntile * 32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fx = lane & 31, fj = lane >> 5;
+    for (int v = tid; v < ntile * 32 * KS * 2; v += 256) {
+        const int r = v / (KS * 2), c = v - r * (KS * 2);
+        half8 x = half8{0, 0, 0, 0, 0, 0, 0, 0}, y = x;
+        if (r < p.Np) {
+            x = *reinterpret_cast<const half8*>(p.w + (long)r * CP + c * 8);
+            y = *reinterpret_cast<const half8*>(p.w + (long)(p.Np + r) * CP + c * 8);
+        }
+        *reinterpret_cast<half8*>(swt + r * ROWH + c * 8) = x;
+        *reinterpret_cast<half8*>(swt + (ntile * 32 + r) * ROWH + c * 8) = y;
+    }
+    const float* aux = p.dotw;
+    for (int v = tid; v < (K2 + 1) * CP; v += 256) sdw[v] = aux[8 + v];
+    for (int c = tid; c < ntile * 32; c += 256) sbias[c] = c < p.Np ? p.bias[c] : 0.f;
+    const int S = p.sh, PAD = p.ph, dact = __float_as_int(aux[3]);
+    const float dact_a = aux[4], dact_b = aux[5], dpost_a = aux[6], dpost_b = aux[7];
+    const int lo_in = p.in_lo_off;
+
+    __syncthreads();
+    const int wr = conv_wrow(fx);
+    const long m0 = (long)blockIdx.x * 256 + wave * 64;
+    // one 32-pixel MFMA tile at a time (a rolled loop: the two tiles of a wave share no registers — unrolled, hipcc kept both tiles' loads,
+    // fragments and accumulators live and spilled hundreds of bytes per lane)
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {
+        const long mraw = m0 + i * 32 + fx;
+        const long m = mraw < p.M ? mraw : 0;
+        const int ow = (int)(m % p.OW);
+        const long t = m / p.OW;
+        const int oh = (int)(t % p.OH);
+        const long n = t / p.OH;
+        half8 xh[KS], xl[KS];
+        const half_t* img = p.in + n * (long)p.H * p.W * p.in_ld;
+        const int iy0 = oh * S - PAD, ix0 = ow * S - PAD;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int c0 = ks * 16 + fj * 8;
+            const int cl = c0 < p.cinp ? c0 : 0;                      // (a half slice behind the channels: computed on channel 0.., zeroed below)
+            float a8[8];
+            {
+                const float4v b0 = *reinterpret_cast<const float4v*>(sdw + K2 * CP + c0), b1 = *reinterpret_cast<const float4v*>(sdw + K2 * CP + c0 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a8[e] = b0[e]; a8[4 + e] = b1[e]; }
+            }
+#pragma unroll 1
+            for (int dy = 0; dy < K; ++dy) {
+                // one filter ROW per iteration of a ROLLED loop: its K loads are issued together, then its multiply-adds.  Unrolled, hipcc
+                // hoisted the weight reads and loads of every row to the top of the slice (a 5 x 5 filter: 200+ VGPRs, over a
+                // kilobyte of scratch per lane) — scheduling barriers alone did not stop it
+                const int iy = iy0 + dy;
+                const int cy = min(max(iy, 0), p.H - 1);
+                const half_t* rowp = img + (long)cy * p.W * p.in_ld + cl;
+                half8 xr[K], lr[K];
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    const int cx = min(max(ix0 + dx, 0), p.W - 1);                   // clamped: the load is unconditional, the tap is selected
+                    xr[dx] = *reinterpret_cast<const half8*>(rowp + (long)cx * p.in_ld);
+                    if constexpr (LO) lr[dx] = *reinterpret_cast<const half8*>(rowp + (long)cx * p.in_ld + lo_in);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    const int ix = ix0 + dx;
+                    // (unsigned compares, bitwise and: a short-circuit && compiles to branches, which split the block the scheduling
+                    // barriers work in — hipcc then hoisted every tap's weight read to the top and spilled 200 VGPRs of them)
+                    const float sel = (((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W)) ? 1.0f : 0.0f;
+                    const float4v w0 = *reinterpret_cast<const float4v*>(sdw + (dy * K + dx) * CP + c0);
+                    const float4v w1 = *reinterpret_cast<const float4v*>(sdw + (dy * K + dx) * CP + c0 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x0 = (float)xr[dx][e], x1 = (float)xr[dx][4 + e];
+                        if constexpr (LO) { x0 += (float)lr[dx][e]; x1 += (float)lr[dx][4 + e]; }
+                        a8[e] = fmaf(x0 * sel, w0[e], a8[e]);
+                        a8[4 + e] = fmaf(x1 * sel, w1[e], a8[4 + e]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            vse_act_n<8>(a8, dact, dact_a, dact_b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (c0 < p.cinp) ? a8[e] * dpost_a + dpost_b : 0.f;
+                xh[ks][e] = (half_t)v;
+                xl[ks][e] = (half_t)(v - (float)xh[ks][e]);
+            }
+        }
+        for (int j = 0; j < ntile; ++j) {
+            float16v acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const half8 wh = *reinterpret_cast<const half8*>(swt + (j * 32 + wr) * ROWH + ks * 16 + fj * 8);
+                const half8 wl = *reinterpret_cast<const half8*>(swt + ((ntile + j) * 32 + wr) * ROWH + ks * 16 + fj * 8);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], acc, 0, 0, 0);
+            }
+            float bias[16];
+            conv_epilogue_consts(sbias, j * 32, lane, bias);
+            if (mraw < p.M) conv_epilogue_tile(p, acc, bias, mraw, n, oh, ow, j * 32, lane);
+        }
+    }
+}
+
+bool conv_dwpw_ok(int k, int s, int cinp, int Np, int flags) {
+    return (k == 3 || k == 5) && (s == 1 || s == 2) && (cinp & 7) == 0 && cinp <= 96 && Np <= 192 && (flags & F_HILO)
+           && !(flags & (F_SRC2 | F_DOT1 | F_PATCH | F_COL | F_PIXSHUF | F_IMGW | F_STEM));
+}
+
+template <int KS, int K, bool LO>
+static int launch_dwpw_t(const ConvParams& p, hipStream_t st) {
+    const int ntile = (p.Np + 31) >> 5;
+    const size_t lds = (size_t)2 * ntile * 32 * (KS * 16 + 8) * 2 + (size_t)(K * K + 1) * KS * 16 * 4 + (size_t)ntile * 32 * 4;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dwpw_kernel<KS, K, LO>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            return VSE_E_HIP;
+        attr = true;
+    }
+    const unsigned long long blocks = (unsigned long long)((p.M + 255) / 256);
+    if (blocks == 0 || blocks > 0x7fffffffull || lds > 128 * 1024) return VSE_E_INVAL;
+    hipLaunchKernelGGL((conv_dwpw_kernel<KS, K, LO>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}
+
+// p.kh / p.sh / p.ph describe the DEPTHWISE conv (the 1x1 conv has no geometry); p.dotw = the aux blob; p.in_lo_off = the input's pair offset
+int launch_conv_dwpw(const ConvParams& p, hipStream_t st) {
+    if (!conv_dwpw_ok(p.kh, p.sh, p.cinp, p.Np, p.flags) || p.kh != p.kw || p.sh != p.sw || p.ph != p.pw || !p.dotw) return VSE_E_UNSUPPORTED;
+    const int ks = (p.cinp + 15) / 16;
+#define DWPW(KS_) (p.in_lo_off ? (p.kh == 3 ? launch_dwpw_t<KS_, 3, true>(p, st) : launch_dwpw_t<KS_, 5, true>(p, st)) \
+                               : (p.kh == 3 ? launch_dwpw_t<KS_, 3, false>(p, st) : launch_dwpw_t<KS_, 5, false>(p, st)))
+    switch (ks) {
+        case 1: return DWPW(1);
+        case 2: return DWPW(2);
+        case 3: return DWPW(3);
+        case 4: return DWPW(4);
+        case 5: return DWPW(5);
+        case 6: return DWPW(6);
+        default: return VSE_E_UNSUPPORTED;
+    }
+#undef DWPW
+}

@@ -290,6 +290,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     p.lo_off = a.lo_off;
     p.res_lo_off = (a.flags & F_RES) ? a.res_lo_off : 0;
     if (p.res_lo_off && (!p.vec16 || a.resshift || (p.res_lo_off & 7))) return VSE_E_INVAL;
+    p.in_lo_off = (a.flags & F_DWPRE) ? a.in_lo_off : 0;
     if (a.lo_off && (!p.vec16 || (a.flags & (F_OUT_F32 | F_ONECH | F_DOT1 | F_UP2HEAD)) || (a.lo_off & 7) || a.out.ld < a.lo_off + a.Np / ((a.flags & F_PIXSHUF) ? 4 : 1)))
         return VSE_E_INVAL;
     p.ogate = nullptr; p.ogate_ld = 0;
@@ -309,6 +310,10 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
         p.wimg_stride = (long)a.Kp * a.Np;
         p.hw_img = p.OH * p.OW;
         return launch_conv_gemm(p, a.Kp, st);
+    }
+    if (a.flags & F_DWPRE) {
+        if (!(a.flags & F_PW) || a.inshift || !a.dotw || (p.in_lo_off && ((p.in_lo_off & 7) || a.in.ld < p.in_lo_off + a.cinp))) return VSE_E_INVAL;
+        return launch_conv_dwpw(p, st);
     }
     if ((a.flags & (F_DOT1 | F_SRC2)) && !(a.flags & (F_PATCH | F_COL))) return VSE_E_UNSUPPORTED;
     if (!a.zero) return VSE_E_INVAL;

@@ -212,6 +212,7 @@ static int run_op(vse_plan* p, int i, char* ws, void* const* ext, const int32_t*
         a.wl_out = wl_out;
         a.lo_off = o.p[P_LO_OUT];
         a.res_lo_off = o.p[P_LO_RES];
+        a.in_lo_off = o.p[P_LO_IN];
         a.u8src = nullptr; a.u8_h = a.u8_w = 0; a.u8_pitch = a.u8_fstride = 0;
         if (o.flags & F_U8SRC) {
             a.u8src = reinterpret_cast<const uint8_t*>(ext[0]);
@@ -385,6 +386,7 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if (o.kind != OP_CONV) return 0;
     if (o.flags & F_UP2HEAD) return 400000;   // conv_head_up2_kernel
     if (o.flags & F_STEM) return 500000;      // conv_stem_kernel
+    if (o.flags & F_DWPRE) return 850000 + 10 * ((o.p[P_CINP] + 15) / 16) + o.p[P_KH];   // conv_dwpw_kernel<KS, K, LO>
     if (o.flags & F_PW) return 800000 + (o.p[P_CINP] + 15) / 16;   // conv_pw_kernel<KS>
     if ((o.flags & F_COL) && o.p[P_KH] == 3 && o.p[P_KW] == 3) {   // conv_c3_kernel<RW, 8 / RW>
         int rw;
@@ -426,6 +428,7 @@ const char* vse_plan_op_kernel_name(vse_plan* p, int i) {
     }
     const int code = vse_plan_op_variant(p, i);
     if (code >= 900000) snprintf(buf, sizeof buf, "conv_smallm_kernel<%d>", code - 900000);
+    else if (code >= 850000) snprintf(buf, sizeof buf, "conv_dwpw_kernel<%d, %d, %s>", (code - 850000) / 10, code % 10, o.p[P_LO_IN] ? "true" : "false");
     else if (code >= 800000) snprintf(buf, sizeof buf, "conv_pw_kernel<%d>", code - 800000);
     else if (code >= 750000) snprintf(buf, sizeof buf, "conv_c3n32_kernel<%d, %d>", code - 750000, 8 / (code - 750000));
     else if (code >= 700000) snprintf(buf, sizeof buf, "conv_c3_kernel<%d, %d>", code - 700000, 8 / (code - 700000));

@@ -57,6 +57,7 @@ P_KTOT = 9          # padded K (multiple of KT)
 P_INSHIFT = 10      # nearest-upsample shift applied when gathering the input
 P_RESSHIFT = 11     # nearest-upsample shift applied when reading the residual
 P_CINP = 12         # physical input channels (multiple of 8)
+P_LO_IN = 17        # F_DWPRE: != 0: the input (in0) is an fp16 hi + lo pair
 P_LO_RES = 16       # != 0: the residual (in1) is an fp16 hi + lo pair: both halves are added
 P_LO_OUT = 15       # != 0: the output is an fp16 hi + lo PAIR: fp16(v - fp16(v)) is stored P_LO_OUT channels behind the hi value
 # flags for OP_CONV
@@ -81,6 +82,9 @@ F_U8SRC = 65536     # OP_CONV | F_STEM reading the plan input: the input is the 
                     # fixed-point bilinear, the bytes vse_det_preprocess writes in raw mode); frame geometry via vse_plan_set_source
 F_OGATE = 131072    # OP_CONV: in2 = gate [N,1,1,Cout] fp16; out = act(conv) * (1 + gate[n, c]) (+ residual): an SE block with shortcut
                     # behind a 1x1 conv folded into it (Compiler._rewrite_se_laterals)
+F_DWPRE = 262144    # OP_CONV | F_PW | F_HILO: a depthwise k x k conv (+ bias + activation) is applied to the input ON THE FLY in front of the
+                    # 1x1 conv (csrc/conv_dwpw.hip): p[P_KH..P_PW] = the depthwise geometry, aux_off = fp32 blob [k, s, pad, act, act_a, act_b,
+                    # post_a, post_b, table [k*k + 1][Kp] (last row = bias)], p[P_LO_IN] = pair offset of the INPUT
 F_ONECH = 32768     # OP_CONV with F_PIXSHUF | F_OUT_F32 and ONE real cout: the output is the 1-channel fp32 map itself (ld = 1); every
                     # lane's 8-channel run is one pixel-shuffle quad whose first channel is stored
 F_COL = 2048        # column-per-step LDS-patch kernel (conv_col.hip): weights packed [cinp/16][kw][kh][Np][16] + 3 zero stages
