@@ -202,6 +202,9 @@ RAGGED_SEL_W = int(os.environ.get("VSE_RAGGED_SELW", "768"))
 ONECH = os.environ.get("VSE_ONECH", "1") != "0"             # DB head: last transposed conv stores the fp32 map directly
 GATE_CONCAT = os.environ.get("VSE_GATE_CONCAT", "1") != "0"   # SE output that only feeds a concat: multiplied by the copy into the slot
 DWPW = os.environ.get("VSE_DWPW", "1") != "0"                 # depthwise conv fused in front of its 1x1 consumer (hi + lo nets: conv_dwpw.hip)
+# filter sizes sent there: 3x3 wins against depthwise + 1x1 launches (V4 16 -> 32 @272x480: 0.33 vs 0.44 ms), 5x5 loses (V3 64 -> 24
+# @68x120: 0.21 vs 0.14 ms: 25 taps of fp32 VALU work per 8 channels and lane, no window sharing between neighbouring pixels)
+DWPW_K = tuple(int(v) for v in os.environ.get("VSE_DWPW_K", "3").split(","))
 SE_LATERAL = os.environ.get("VSE_SE_LATERAL", "1") != "0"   # 1x1 conv + SE block with shortcut -> one gated conv (F_OGATE)
 LSTM_MFMA = os.environ.get("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
 LSTM_WAVES = int(os.environ.get("VSE_LSTM_WAVES", "16"))    # 8: lstm_mfma_kernel, 16: lstm_mfma16_kernel (twice the loads in flight)
@@ -1450,7 +1453,7 @@ class Compiler(ChainMixin):
         sh, sw = a["strides"]
         pads = a["paddings"]
         ph, pw = (pads[0], pads[1]) if len(pads) == 2 else (pads[0], pads[2])
-        if kh != kw or kh not in (3, 5) or sh != sw or sh not in (1, 2) or ph != pw or ph != kh // 2 or c % 8 or c > 96:
+        if kh != kw or kh not in DWPW_K or sh != sw or sh not in (1, 2) or ph != pw or ph != kh // 2 or c % 8 or c > 96:
             return False
         snapshot = set(self.done)
         try:

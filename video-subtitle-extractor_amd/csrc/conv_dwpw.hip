@@ -70,39 +70,56 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_dwpw_kernel(const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { a8[e] = b0[e]; a8[4 + e] = b1[e]; }
             }
-#pragma unroll 1
-            for (int dy = 0; dy < K; ++dy) {
-                // one filter ROW per iteration of a ROLLED loop: its K loads are issued together, then its multiply-adds.  Unrolled, hipcc
-                // hoisted the weight reads and loads of every row to the top of the slice (a 5 x 5 filter: 200+ VGPRs, over a
-                // kilobyte of scratch per lane) — scheduling barriers alone did not stop it
-                const int iy = iy0 + dy;
-                const int cy = min(max(iy, 0), p.H - 1);
+            // one filter ROW per iteration of a ROLLED loop, its loads issued ONE ITERATION AHEAD (xn: the next row's K vectors are in
+            // flight while this row's multiply-adds run).  Unrolled, hipcc hoisted the weight reads and loads of every row to the top of
+            // the slice (a 5 x 5 filter: 200+ VGPRs, over a kilobyte of scratch per lane) — scheduling barriers alone did not stop it.
+            half8 xr[K], lr[K];
+            auto load_row = [&](int dy, half8 (&xv)[K], half8 (&lv)[K]) {
+                const int cy = min(max(iy0 + dy, 0), p.H - 1);
                 const half_t* rowp = img + (long)cy * p.W * p.in_ld + cl;
-                half8 xr[K], lr[K];
 #pragma unroll
                 for (int dx = 0; dx < K; ++dx) {
                     const int cx = min(max(ix0 + dx, 0), p.W - 1);                   // clamped: the load is unconditional, the tap is selected
-                    xr[dx] = *reinterpret_cast<const half8*>(rowp + (long)cx * p.in_ld);
-                    if constexpr (LO) lr[dx] = *reinterpret_cast<const half8*>(rowp + (long)cx * p.in_ld + lo_in);
+                    xv[dx] = *reinterpret_cast<const half8*>(rowp + (long)cx * p.in_ld);
+                    if constexpr (LO) lv[dx] = *reinterpret_cast<const half8*>(rowp + (long)cx * p.in_ld + lo_in);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            };
+            load_row(0, xr, lr);
+#pragma unroll 1
+            for (int dy = 0; dy < K; ++dy) {
+                half8 xn[K], ln[K];
+                load_row(dy + 1 < K ? dy + 1 : dy, xn, ln);          // (the last iteration re-reads its own row: an L1 hit, no branch)
+                const int iy = iy0 + dy;
 #pragma unroll
                 for (int dx = 0; dx < K; ++dx) {
                     const int ix = ix0 + dx;
-                    // (unsigned compares, bitwise and: a short-circuit && compiles to branches, which split the block the scheduling
-                    // barriers work in — hipcc then hoisted every tap's weight read to the top and spilled 200 VGPRs of them)
-                    const float sel = (((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W)) ? 1.0f : 0.0f;
+                    // (unsigned compares, bitwise and: a short-circuit && compiles to branches, which split the block).  A tap outside
+                    // the image is zeroed on the PACKED halves (4 selects), and the multiply-add takes the fp16 value directly
+                    // (v_fma_mix_f32 converts on the fly): 12 VALU instructions per tap and 8 channels instead of 24
+                    const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                    const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const half8 xv = ok ? xr[dx] : z8;
                     const float4v w0 = *reinterpret_cast<const float4v*>(sdw + (dy * K + dx) * CP + c0);
                     const float4v w1 = *reinterpret_cast<const float4v*>(sdw + (dy * K + dx) * CP + c0 + 4);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x0 = (float)xr[dx][e], x1 = (float)xr[dx][4 + e];
-                        if constexpr (LO) { x0 += (float)lr[dx][e]; x1 += (float)lr[dx][4 + e]; }
-                        a8[e] = fmaf(x0 * sel, w0[e], a8[e]);
-                        a8[4 + e] = fmaf(x1 * sel, w1[e], a8[4 + e]);
+                        a8[e] = fmaf((float)xv[e], w0[e], a8[e]);
+                        a8[4 + e] = fmaf((float)xv[4 + e], w1[e], a8[4 + e]);
+                    }
+                    if constexpr (LO) {
+                        const half8 lv = ok ? lr[dx] : z8;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a8[e] = fmaf((float)lv[e], w0[e], a8[e]);
+                            a8[4 + e] = fmaf((float)lv[4 + e], w1[e], a8[4 + e]);
+                        }
                     }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dx = 0; dx < K; ++dx) {
+                    xr[dx] = xn[dx];
+                    if constexpr (LO) lr[dx] = ln[dx];
+                }
             }
             vse_act_n<8>(a8, dact, dact_a, dact_b);
 #pragma unroll
