@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--no-det-chains", dest="det_chains", action="store_false", help="mobile detectors layer by layer (no OP_CHAIN / pair tensors)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false", help="skip config.secondary (4K batch 32, fast mode)")
-    ap.add_argument("--secondary-steps", type=int, default=4)
+    ap.add_argument("--secondary-steps", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="finish batch k before the detector of batch k+1 starts")
     ap.add_argument("--det-priority", type=int, default=0, help="HIP stream priority of the detector streams (-1 = high)")
