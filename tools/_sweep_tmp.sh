@@ -1,3 +1,5 @@
-python -m pytest tests/test_gpu_pipeline.py -m gpu -x -q -s -k test_box_parity_rate_real_detector 2>&1 | grep -v amdgpu.ids | tail -30 > gpurun_out/r4_c27_test.log; cat gpurun_out/r4_c27_test.log
-for i in 1 2; do python bench.py --no-cpu-baseline > gpurun_out/r4_c27_bench$i.json 2> gpurun_out/r4_c27_bench$i.err; python -c "
-import json; d=json.load(open('gpurun_out/r4_c27_bench$i.json')); print(d['value'], d['ms_per_step'], {k:v.get('value') for k,v in d['config']['secondary'].items()})"; done
+python tools/chain_check.py --time > gpurun_out/r4_c32_check.log 2>&1; grep -E "chain_check|FAIL|64x544x960" gpurun_out/r4_c32_check.log | cut -c1-120
+python tools/gpu_profile_net.py V4_ch_det_fast 64 544 960 --hilo --top 40 2>&1 | grep -v amdgpu.ids | cut -c1-175 > gpurun_out/r4_c32_prof_V4_default.log
+python bench.py --no-cpu-baseline > gpurun_out/r4_c32_bench.json 2> gpurun_out/r4_c32_bench.err; python -c "
+import json; d=json.load(open('gpurun_out/r4_c32_bench.json')); print(d['value'], d['ms_per_step'], {k:v.get('value') for k,v in d['config']['secondary'].items()})"
+grep "per-net" gpurun_out/r4_c32_bench.err

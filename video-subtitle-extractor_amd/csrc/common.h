@@ -34,6 +34,16 @@ __device__ __forceinline__ float vse_act(float x, int code, float a, float b) {
     }
 }
 
+// XCD-aware block order for STREAMING kernels whose neighbouring outputs share input rows (depthwise / pooling windows, up-sampling
+// copies): the dispatcher places block b on XCD b % 8 and every XCD has a private L2, so with the plain order the blocks of
+// vertically adjacent rows land on different XCDs and every input row is fetched from memory once per XCD that needs it (counters,
+// round 4: 2.2 - 3.5 x the algorithmic bytes on the mobile detector's depthwise layers).  This bijection gives every XCD one CONTIGUOUS
+// run of logical blocks (the formula of conv_mfma.hip), so the window overlap is served by the L2 that already holds the row.
+__device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nblk) {
+    const unsigned q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+}
+
 // Resolved (pointer-carrying) tensor view handed to kernels.
 struct TView {
     char* ptr;

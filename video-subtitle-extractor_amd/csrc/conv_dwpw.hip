@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_dwpw_kernel(const
 
     __syncthreads();
     const int wr = conv_wrow(fx);
-    const long m0 = (long)blockIdx.x * 256 + wave * 64;
+    const long m0 = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + wave * 64;       // (XCD-contiguous block order: common.h)
     // one 32-pixel MFMA tile at a time (a rolled loop: the two tiles of a wave share no registers — unrolled, hipcc kept both tiles' loads,
     // fragments and accumulators live and spilled hundreds of bytes per lane)
 #pragma unroll 1

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
     }
     for (int c = tid; c < ntile * 32; c += 256) sbias[c] = c < p.Np ? p.bias[c] : 0.f;
 
-    const long m0 = (long)blockIdx.x * 256 + wave * 64;
+    const long m0 = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + wave * 64;       // (XCD-contiguous block order: common.h)
     half8 xf[2][KS];
     long mm[2];
 #pragma unroll

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
 
     // (one tile per block: a block that walks 8 consecutive tiles was measured 15 % slower — its tiles run back to back
     // and nothing overlaps inside it, while 4 resident blocks per CU overlap each other's load / compute / store phases)
-    unsigned t = blockIdx.x;
+    unsigned t = xcd_block(blockIdx.x, gridDim.x);          // (XCD-contiguous tile order: vertical neighbours share their halo rows in one L2)
     const int tx = t % p.tiles_w;  t /= p.tiles_w;
     const int ty = t % p.tiles_h;
     const long img = t / p.tiles_h;

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
     hilo &= 1;
     const int cg = in.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
         long pix = i / cg;
         const int ow = (int)(pix % out.w);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
     const int cg = in.c >> 3;
     const int owq = (out.w + OUTW - 1) / OUTW;
     const long total = (long)out.n * out.h * owq * cg;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
         long t = i / cg;
         const int q = (int)(t % owq);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void pool_kernel(TView in, TView out, int kh, 
                                                    const int* __restrict__ wl_out) {
     const int cg = in.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
         long pix = i / cg;
         const int ow = (int)(pix % out.w);
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void binary_kernel(TView x, TView y, TView out
 __global__ __launch_bounds__(256) void resize_kernel(TView in, TView out, int shift) {
     const int cg = out.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
         const long pix = i / cg;
         const int w = (int)(pix % out.w);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void resize_kernel(TView in, TView out, int sh
 __global__ __launch_bounds__(256) void resize_gate_kernel(TView inA, TView gateA, int shiftA, TView inB, TView gateB, int shiftB, TView out, int plus1) {
     const int cgA = inA.c >> 3, cg = out.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
         const long pix = i / cg;
         const int w = (int)(pix % out.w);
