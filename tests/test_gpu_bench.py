@@ -43,8 +43,10 @@ def test_bench_two_ranks_one_json_line(ctx):
     assert one["config"]["boxes_last_step"] > 0
 
 
-def test_bench_configuration_c2_against_the_oracle_in_one_piece(ctx):
-    """The EXACT path bench.py times (BASELINE configs[1]) against the CPU oracle, end to end on 4 x 1080p frames:
+@pytest.mark.parametrize("det_id,rec_id", [("V4_ch_det", "V4_ch_rec"), ("V4_ch_det_fast", "V4_ch_rec_fast")])
+def test_bench_configuration_c2_against_the_oracle_in_one_piece(ctx, det_id, rec_id):
+    """The EXACT path bench.py times (BASELINE configs[1]; and configs[0]'s models at the same frame size, the reference's default
+    `fast` mode — bench.py --models fast, config.secondary.fast_mode_1080p) against the CPU oracle, end to end on 4 x 1080p frames:
     V4_ch_det map (engine vs oracle/net_ref) max-overlaid with bench.text_kernel_maps ON BOTH SIDES -> DB post-processing
     -> boxes (identical integers) -> perspective crops -> V4_ch_rec in the benchmarked ragged mode vs the oracle's
     rec_batches chunks (backend/tools/ocr.py:24-27,88-113; paddleocr TextSystem): confidences within 1e-3 of the oracle's
@@ -58,9 +60,9 @@ def test_bench_configuration_c2_against_the_oracle_in_one_piece(ctx):
     from vse_amd import pipeline, shim, synth
     nf, H, W = 4, 1080, 1920
     from vse_amd import modelzoo
-    det = modelzoo.get_model("V4_ch_det", seed=0)                     # bench.py's own stand-in detector (seeded, uncalibrated) ...
+    det = modelzoo.get_model(det_id, seed=0)                          # bench.py's own stand-in detector (seeded, uncalibrated) ...
     det = (det[0], bench.empty_det_head(det[0], dict(det[1])))        # ... with its head pushed below the threshold, as bench.py does
-    rec = net_ref.get_weights("V4_ch_rec")                            # calibrated stand-in recogniser: a softmax that is not flat
+    rec = net_ref.get_weights(rec_id)                                 # calibrated stand-in recogniser: a softmax that is not flat
     charset = shim.standin_charset("ch", shim._ncls(rec[0]))
     ref_charset = P.standin_charset(shim._ncls(rec[0]))
     frames, truth = synth.make_frames(nf, H, W, seed=100, return_truth=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-op timing of one model on the GPU (HIP events inside vse_plan_profile).
-usage: python tools/gpu_profile_net.py MODEL N H W [--top K] [--hilo] [--ragged [--wmin W0]]
+usage: python tools/gpu_profile_net.py MODEL N H W [--top K] [--hilo [--no-chain]] [--ragged [--wmin W0]]
 --ragged: a recogniser plan for ragged batches; sample widths are spread evenly over [W0 (default 320), W]."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,7 +39,8 @@ def main():
     desc, wts = modelzoo.get_model(mid)
     ctx = engine.Context(0)
     ragged = "--ragged" in sys.argv
-    net = engine.Net(ctx, desc, wts, want_probs=False, hilo="--hilo" in sys.argv, ragged=ragged)
+    net = engine.Net(ctx, desc, wts, want_probs=False, hilo="--hilo" in sys.argv, ragged=ragged,
+                     chain=False if "--no-chain" in sys.argv else None)       # --no-chain: hi + lo weights, layer by layer, no pair tensors
     x = (torch.rand((n, h, w, 8), device="cuda") * 2 - 1).half()
     x[..., 3:] = 0
     widths = None

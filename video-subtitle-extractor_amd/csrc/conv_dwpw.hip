@@ -13,12 +13,25 @@
 //   input  = NHWC fp16, optionally an fp16 hi + lo pair (p.in_lo_off: both halves are filtered)
 //   output = the shared conv epilogue (bias, activation, residual, gate, pair store)
 // Bound: HBM (input once + output); L1 serves k * k x the input bytes.
+#include <stdlib.h>
 #include "conv_common.h"
 
 // aux blob (fp32 words, ints by bit pattern): [0] k  [1] stride  [2] pad  [3] act  [4] act_a  [5] act_b  [6] post_a  [7] post_b, then the
 // depthwise table [k * k + 1][KS * 16]
+#ifdef VSE_DEV_BUILD
+// ablation mask of tools/ablate_dwpw.sh (development builds only): 1 no output stores, 2 only the centre tap is loaded and multiplied,
+// 4 all taps loaded but only the centre one multiplied, 8 no MFMAs
+__device__ int dwpw_abl_dev = 0;
+#define DWPW_ABL(bit) (abl & (bit))
+#else
+#define DWPW_ABL(bit) false
+#endif
+
 template <int KS, int K, bool LO>
 __global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_dwpw_kernel(const ConvParams p) {
+#ifdef VSE_DEV_BUILD
+    const int abl = dwpw_abl_dev;
+#endif
     extern __shared__ __attribute__((aligned(16))) char dlds[];
     constexpr int ROWH = KS * 16 + 8, CP = KS * 16, K2 = K * K;
     const int ntile = (p.Np + 31) >> 5;
@@ -84,14 +97,20 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_dwpw_kernel(const
                     if constexpr (LO) lv[dx] = *reinterpret_cast<const half8*>(rowp + (long)cx * p.in_ld + lo_in);
                 }
             };
-            load_row(0, xr, lr);
+            const int dy_begin = DWPW_ABL(2) ? K / 2 : 0, dy_end = DWPW_ABL(2) ? K / 2 + 1 : K;
+            load_row(dy_begin, xr, lr);
 #pragma unroll 1
-            for (int dy = 0; dy < K; ++dy) {
+            for (int dy = dy_begin; dy < dy_end; ++dy) {
                 half8 xn[K], ln[K];
-                load_row(dy + 1 < K ? dy + 1 : dy, xn, ln);          // (the last iteration re-reads its own row: an L1 hit, no branch)
+                load_row(dy + 1 < dy_end ? dy + 1 : dy, xn, ln);          // (the last iteration re-reads its own row: an L1 hit, no branch)
                 const int iy = iy0 + dy;
 #pragma unroll
                 for (int dx = 0; dx < K; ++dx) {
+                    if (DWPW_ABL(4) && dy != K / 2) {
+                        asm volatile("" :: "v"(xr[dx]));
+                        if constexpr (LO) asm volatile("" :: "v"(lr[dx]));
+                        continue;
+                    }
                     const int ix = ix0 + dx;
                     // (unsigned compares, bitwise and: a short-circuit && compiles to branches, which split the block).  A tap outside
                     // the image is zeroed on the PACKED halves (4 selects), and the multiply-add takes the fp16 value directly
@@ -137,13 +156,14 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_dwpw_kernel(const
             for (int ks = 0; ks < KS; ++ks) {
                 const half8 wh = *reinterpret_cast<const half8*>(swt + (j * 32 + wr) * ROWH + ks * 16 + fj * 8);
                 const half8 wl = *reinterpret_cast<const half8*>(swt + ((ntile + j) * 32 + wr) * ROWH + ks * 16 + fj * 8);
+                if (DWPW_ABL(8)) { acc[0] += (float)xh[ks][0] + (float)xl[ks][1] + (float)wh[0] + (float)wl[1]; continue; }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], acc, 0, 0, 0);
             }
             float bias[16];
             conv_epilogue_consts(sbias, j * 32, lane, bias);
-            if (mraw < p.M) conv_epilogue_tile(p, acc, bias, mraw, n, oh, ow, j * 32, lane);
+            if (mraw < p.M && (!DWPW_ABL(1) || acc[3] == 1234.5678f)) conv_epilogue_tile(p, acc, bias, mraw, n, oh, ow, j * 32, lane);
         }
     }
 }
@@ -165,6 +185,13 @@ static int launch_dwpw_t(const ConvParams& p, hipStream_t st) {
     }
     const unsigned long long blocks = (unsigned long long)((p.M + 255) / 256);
     if (blocks == 0 || blocks > 0x7fffffffull || lds > 128 * 1024) return VSE_E_INVAL;
+#ifdef VSE_DEV_BUILD
+    static int abl_set = -1;
+    if (abl_set < 0) {
+        abl_set = getenv("VSE_DWPW_ABL") ? atoi(getenv("VSE_DWPW_ABL")) : 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(dwpw_abl_dev), &abl_set, sizeof(int)) != hipSuccess) return VSE_E_HIP;
+    }
+#endif
     hipLaunchKernelGGL((conv_dwpw_kernel<KS, K, LO>), dim3((unsigned)blocks), dim3(256), lds, st, p);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }
