@@ -1,2 +1,1 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > gpurun_out/r4_c34_tests.log; cat gpurun_out/r4_c34_tests.log
-python -m pytest tests/test_gpu_bench.py -m gpu -q -s -k c2_against 2>&1 | grep -E "C2 path|passed|failed|Error|assert" | head
+for t in 0 1 2; do VSE_DW_TILE=$t python tools/dw_tile_check.py 2>&1 | grep -v amdgpu.ids; done > gpurun_out/r4_c36_dwtile.log; sort -k2,4 gpurun_out/r4_c36_dwtile.log | cut -c1-150

@@ -44,6 +44,19 @@ __device__ __forceinline__ unsigned xcd_block(unsigned bid, unsigned nblk) {
     return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
 }
 
+// q = a / b and r = a % b for a flattened element index a >= 0 and an extent b > 0.  A 64-bit division by a runtime value expands to ~100
+// instructions and the element-wise / window kernels do three or four per thread; indices that fit 32 bits (every tensor the models produce;
+// one comparison, uniform in practice) take the 32-bit unsigned division instead.
+__device__ __forceinline__ long vse_divmod(long a, int b, int& r) {
+    if ((unsigned long)a <= 0xfffffffful) {
+        const unsigned au = (unsigned)a, q = au / (unsigned)b;
+        r = (int)(au - q * (unsigned)b);
+        return (long)q;
+    }
+    r = (int)(a % b);
+    return a / b;
+}
+
 // Resolved (pointer-carrying) tensor view handed to kernels.
 struct TView {
     char* ptr;

@@ -113,6 +113,15 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 // i.e. two runs of 8 consecutive channels = 16-byte NHWC stores (the natural order gives 4-channel / 8-byte runs, and
 // the 8-byte partial-line writes cost ~30 % of a whole 1x1 layer).  The permutation keeps the weight-fragment
 // ds_read_b128 bank-conflict free under both LDS swizzles (64-byte and 128-byte rows).
+// Flattened output pixel -> (image, row, column) by 32-BIT unsigned divisions: a 64-bit division by a runtime value expands to ~100
+// instructions, and the small-K streaming kernels (conv_pw, conv_dwpw) do two of them per 32-pixel tile.  Their launchers refuse M >= 2^31.
+__device__ __forceinline__ void conv_pix_coords(const ConvParams& p, long m, long& n, int& oh, int& ow) {
+    const unsigned mu = (unsigned)m, t = mu / (unsigned)p.OW, nn = t / (unsigned)p.OH;
+    ow = (int)(mu - t * (unsigned)p.OW);
+    oh = (int)(t - nn * (unsigned)p.OH);
+    n = (long)nn;
+}
+
 __device__ __forceinline__ int conv_wrow(int f) { return (f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1); }
 
 // One activation code applied to N values: ONE uniform switch per call (per-element switches blow the epilogue up to

@@ -66,10 +66,9 @@ __global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_dwpw_kernel(const
     for (int i = 0; i < 2; ++i) {
         const long mraw = m0 + i * 32 + fx;
         const long m = mraw < p.M ? mraw : 0;
-        const int ow = (int)(m % p.OW);
-        const long t = m / p.OW;
-        const int oh = (int)(t % p.OH);
-        const long n = t / p.OH;
+        int ow, oh;
+        long n;
+        conv_pix_coords(p, m, n, oh, ow);
         half8 xh[KS], xl[KS];
         const half_t* img = p.in + n * (long)p.H * p.W * p.in_ld;
         const int iy0 = oh * S - PAD, ix0 = ow * S - PAD;
@@ -184,7 +183,7 @@ static int launch_dwpw_t(const ConvParams& p, hipStream_t st) {
         attr = true;
     }
     const unsigned long long blocks = (unsigned long long)((p.M + 255) / 256);
-    if (blocks == 0 || blocks > 0x7fffffffull || lds > 128 * 1024) return VSE_E_INVAL;
+    if (blocks == 0 || p.M >= 0x7fffffffl || lds > 128 * 1024) return VSE_E_INVAL;          // (32-bit pixel arithmetic: conv_pix_coords)
 #ifdef VSE_DEV_BUILD
     static int abl_set = -1;
     if (abl_set < 0) {

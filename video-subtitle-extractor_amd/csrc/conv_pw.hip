@@ -61,10 +61,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const long m = mm[i] < p.M ? mm[i] : 0;
-        ow[i] = (int)(m % p.OW);
-        const long t = m / p.OW;
-        oh[i] = (int)(t % p.OH);
-        nn[i] = t / p.OH;
+        conv_pix_coords(p, m, nn[i], oh[i], ow[i]);
     }
     __syncthreads();
     const int wr = conv_wrow(fx);
@@ -105,7 +102,7 @@ bool conv_pw_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int Np
 int launch_conv_pw(const ConvParams& p, hipStream_t st) {
     if (!conv_pw_ok(p.kh, p.kw, p.sh, p.sw, p.ph, p.pw, p.cinp, p.Np, p.inshift, p.flags)) return VSE_E_UNSUPPORTED;
     const unsigned long long blocks = (unsigned long long)((p.M + 255) / 256);
-    if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
+    if (blocks == 0 || p.M >= 0x7fffffffl) return VSE_E_INVAL;          // (32-bit pixel arithmetic: conv_pix_coords)
     const dim3 grid((unsigned)blocks), block(256);
     if (p.flags & F_HILO) {
         switch ((p.cinp + 15) / 16) {

@@ -56,12 +56,12 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
     const int cg = in.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
     for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        long pix = i / cg;
-        const int ow = (int)(pix % out.w);
-        long t = pix / out.w;
-        const int oh = (int)(t % out.h);
-        const long n = t / out.h;
+        int g;
+        long pix = vse_divmod(i, cg, g);
+        int ow;
+        long t = vse_divmod(pix, out.w, ow);
+        int oh;
+        const long n = vse_divmod(t, out.h, oh);
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = bias[g * 8 + e];
@@ -116,12 +116,12 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
     const int owq = (out.w + OUTW - 1) / OUTW;
     const long total = (long)out.n * out.h * owq * cg;
     for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        long t = i / cg;
-        const int q = (int)(t % owq);
-        t /= owq;
-        const int oh = (int)(t % out.h);
-        const long n = t / out.h;
+        int g;
+        long t = vse_divmod(i, cg, g);
+        int q;
+        t = vse_divmod(t, owq, q);
+        int oh;
+        const long n = vse_divmod(t, out.h, oh);
         const int ow0 = q * OUTW, iw0 = ow0 * SW - pw;
         float acc[OUTW][8];
 #pragma unroll
@@ -186,6 +186,116 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
     }
 }
 
+#ifdef VSE_DEV_BUILD
+// (development builds only: measured, bit-identical to the row kernel and 10-25 % SLOWER on every model — DESIGN §3.2 log)
+// LDS-tile variant (round 4): the row kernel walks its kh filter rows as kh dependent global round trips per thread (loads of a row,
+// wait, ~200 VALU instructions, next row) at 3-4 waves per SIMD — on the mobile models' 5 x 5 layers it sits at 20 % of its bytes' time
+// (rec_fast: 14 depthwise layers = 39 % of the net).  Here a block of 256 threads owns TR output rows x 32 output columns x CGB 8-channel
+// groups (TR * CGB = 32): it pulls the input patch ((TR - 1) * sh + kh rows, 31 * SW + KW columns) into LDS with ONE batch of independent
+// 16-byte loads per thread (the SE gate applied on the way, once per element instead of once per use), and every thread then computes the
+// same four outputs as in the row kernel, its windows read from LDS.  Same arithmetic per output (bias, taps row-major, hi + lo weights
+// summed in fp32, padded taps skipped) -> bit-identical results.
+//   LDS layout: [plane hi | lo][row][column][CGB vectors of 16 bytes (+ pad)]; the pad (16 bytes for CGB = 4, 32 for CGB = 8) makes the 16
+//   lanes of a ds_read_b128 phase — CGB channel groups x 16 / CGB quads, quads 4 * SW columns apart — hit 16 distinct bank groups (SW = 1)
+template <int KW, int SW, int GM>
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(TView in, TView out, TView gate, int hilo, const half_t* __restrict__ w,
+                                                          const float* __restrict__ bias, int kh, int sh, int ph, int pw,
+                                                          int act, float act_a, float act_b, float post_a, float post_b,
+                                                          const int* __restrict__ wl_out, int trl, int tiles_w, int tiles_h, int cgblocks) {
+    extern __shared__ __attribute__((aligned(16))) char tlds[];
+    constexpr int OUTW = 4, TC = 32, WIN = (OUTW - 1) * SW + KW, IC = (TC - 1) * SW + KW;
+    const int lo_off = ((hilo >> 1) & 0xfff) << 3, lo_in = ((hilo >> 13) & 0xfff) << 3;          // (see dwconv_kernel)
+    hilo &= 1;
+    const int TR = 1 << trl, cgbl = 5 - trl, CGB = 1 << cgbl;
+    const int IR = (TR - 1) * sh + kh;
+    const int colstride = CGB * 16 + (CGB == 4 ? 16 : CGB == 8 ? 32 : 0), rowstride = IC * colstride, plane = IR * rowstride;
+    const int cg = in.c >> 3;
+    unsigned b = xcd_block(blockIdx.x, gridDim.x);
+    const int cgb = (int)(b % (unsigned)cgblocks);  b /= (unsigned)cgblocks;
+    const int tx = (int)(b % (unsigned)tiles_w);  b /= (unsigned)tiles_w;
+    const int ty = (int)(b % (unsigned)tiles_h);
+    const long n = b / (unsigned)tiles_h;
+    const int cg0 = cgb * CGB, oy0 = ty * TR, ox0 = tx * TC;
+    const int iy0 = oy0 * sh - ph, ix0 = ox0 * SW - pw;
+    const int tid = threadIdx.x;
+    const bool dead_tile = wl_out != nullptr && ox0 >= wl_out[n];          // (ragged batch: right of the sample — zeros, nothing to read)
+    if (!dead_tile) {
+        const int nvec = IR * IC * CGB;
+        for (int v = tid; v < nvec; v += 256) {
+            const int g = v & (CGB - 1), rc = v >> cgbl, r = rc / IC, c = rc - r * IC;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool ok = iy >= 0 && iy < in.h && ix >= 0 && ix < in.w && cg0 + g < cg;
+            half8 x = half8{0, 0, 0, 0, 0, 0, 0, 0}, xl = x;
+            if (ok) {
+                const long pix = (n * in.h + iy) * in.w + ix;
+                x = ld8(in, pix, (cg0 + g) * 8);
+                if constexpr (GM != 0) x = dw_gate_t<GM>(x, ld8(gate, n, (cg0 + g) * 8));
+                if (lo_in) xl = ld8(in, pix, (cg0 + g) * 8 + lo_in);
+            }
+            *reinterpret_cast<half8*>(tlds + r * rowstride + c * colstride + g * 16) = x;
+            if (lo_in) *reinterpret_cast<half8*>(tlds + plane + r * rowstride + c * colstride + g * 16) = xl;
+        }
+    }
+    __syncthreads();
+    const int g = tid & (CGB - 1), q = (tid >> cgbl) & 7, r = tid >> (cgbl + 3);
+    const int oh = oy0 + r, ow0 = ox0 + q * OUTW, gc = cg0 + g;
+    if (oh >= out.h || ow0 >= out.w || gc >= cg) return;
+    const int iw0 = ow0 * SW - pw;
+    float acc[OUTW][8];
+#pragma unroll
+    for (int o = 0; o < OUTW; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o][e] = bias[gc * 8 + e];
+    if (!dead_tile) {
+        const char* base = tlds + (r * sh) * rowstride + (q * OUTW * SW) * colstride + g * 16;
+        for (int dyp = 0; dyp < (lo_in ? 2 * kh : kh); ++dyp) {
+            // (a pair input: every filter row is walked twice, over the hi and over the lo half of the same pixels)
+            const int dy = dyp < kh ? dyp : dyp - kh;
+            const int ih = oh * sh - ph + dy;
+            if (ih < 0 || ih >= in.h) continue;
+            const char* rowp = base + (dyp < kh ? 0 : plane) + dy * rowstride;
+            half8 x[WIN];
+#pragma unroll
+            for (int c = 0; c < WIN; ++c) x[c] = *reinterpret_cast<const half8*>(rowp + c * colstride);
+#pragma unroll
+            for (int dx = 0; dx < KW; ++dx) {
+                const half8 k = *reinterpret_cast<const half8*>(w + (long)(dy * KW + dx) * in.c + gc * 8);
+                float kf[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) kf[e] = (float)k[e];
+                if (hilo) {
+                    const half8 kl = *reinterpret_cast<const half8*>(w + (long)(kh * KW + dy * KW + dx) * in.c + gc * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) kf[e] += (float)kl[e];
+                }
+#pragma unroll
+                for (int o = 0; o < OUTW; ++o) {
+                    const int iw = iw0 + o * SW + dx;
+                    if (iw < 0 || iw >= in.w) continue;           // the reference kernel skips padded taps (no +0 rounding issue, same sums)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[o][e] += (float)x[o * SW + dx][e] * kf[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < OUTW; ++o) {
+        if (ow0 + o >= out.w) continue;
+        half8 rr, rl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = vse_act(acc[o][e], act, act_a, act_b) * post_a + post_b;
+            rr[e] = (half_t)v;
+            rl[e] = (half_t)(v - (float)rr[e]);
+        }
+        if (wl_out != nullptr && ow0 + o >= wl_out[n]) rr = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        st8(out, (n * out.h + oh) * out.w + ow0 + o, gc * 8, rr);
+        if (lo_off) st8(out, (n * out.h + oh) * out.w + ow0 + o, gc * 8 + lo_off, rl);
+    }
+}
+
+#endif
+
 // ------------------------------------------------------------------------------------------------ pooling
 // wl_in / wl_out (ragged batch): the sample's own input / output width — the window is clipped to the sample, not to the
 // batch tensor, and outputs right of the sample are zeros.
@@ -195,12 +305,12 @@ __global__ __launch_bounds__(256) void pool_kernel(TView in, TView out, int kh, 
     const int cg = in.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
     for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        long pix = i / cg;
-        const int ow = (int)(pix % out.w);
-        long t = pix / out.w;
-        const int oh = (int)(t % out.h);
-        const long n = t / out.h;
+        int g;
+        long pix = vse_divmod(i, cg, g);
+        int ow;
+        long t = vse_divmod(pix, out.w, ow);
+        int oh;
+        const long n = vse_divmod(t, out.h, oh);
         const int inw = wl_in != nullptr ? wl_in[n] : in.w;
         if (wl_out != nullptr && ow >= wl_out[n]) {
             st8(out, pix, g * 8, half8{0, 0, 0, 0, 0, 0, 0, 0});
@@ -334,8 +444,8 @@ __global__ __launch_bounds__(256) void scale_kernel(TView x, TView s, TView out,
     const long hw = (long)x.h * x.w;
     const long total = (long)x.n * hw * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const long pix = i / cg;
+        int g;
+        const long pix = vse_divmod(i, cg, g);
         const long n = pix / hw;
         const half8 a = ld8(x, pix, g * 8);
         const half8 b = ld8(s, n, g * 8);
@@ -354,14 +464,14 @@ __global__ __launch_bounds__(256) void binary_kernel(TView x, TView y, TView out
     const int cg = x.c >> 3;
     const long total = (long)x.n * x.h * x.w * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const long pix = i / cg;
+        int g;
+        const long pix = vse_divmod(i, cg, g);
         long ypix = pix;
         if (shift) {
-            const int w = (int)(pix % x.w);
-            const long t = pix / x.w;
-            const int h = (int)(t % x.h);
-            const long n = t / x.h;
+            int w;
+            const long t = vse_divmod(pix, x.w, w);
+            int h;
+            const long n = vse_divmod(t, x.h, h);
             ypix = (n * y.h + (h >> shift)) * y.w + (w >> shift);
         }
         const half8 a = ld8(x, pix, g * 8);
@@ -381,12 +491,12 @@ __global__ __launch_bounds__(256) void resize_kernel(TView in, TView out, int sh
     const int cg = out.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
     for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const long pix = i / cg;
-        const int w = (int)(pix % out.w);
-        const long t = pix / out.w;
-        const int h = (int)(t % out.h);
-        const long n = t / out.h;
+        int g;
+        const long pix = vse_divmod(i, cg, g);
+        int w;
+        const long t = vse_divmod(pix, out.w, w);
+        int h;
+        const long n = vse_divmod(t, out.h, h);
         const long ipix = (n * in.h + (h >> shift)) * in.w + (w >> shift);
         st8(out, pix, g * 8, ld8(in, ipix, g * 8));
     }
@@ -400,12 +510,12 @@ __global__ __launch_bounds__(256) void resize_gate_kernel(TView inA, TView gateA
     const int cgA = inA.c >> 3, cg = out.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
     for (long i = xcd_block(blockIdx.x, gridDim.x) * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const long pix = i / cg;
-        const int w = (int)(pix % out.w);
-        const long t = pix / out.w;
-        const int h = (int)(t % out.h);
-        const long n = t / out.h;
+        int g;
+        const long pix = vse_divmod(i, cg, g);
+        int w;
+        const long t = vse_divmod(pix, out.w, w);
+        int h;
+        const long n = vse_divmod(t, out.h, h);
         const bool second = g >= cgA;
         const TView& in = second ? inB : inA;
         const TView& gate = second ? gateB : gateA;
@@ -431,8 +541,8 @@ __global__ __launch_bounds__(256) void unary_vec_kernel(TView in, TView out, int
     const int cg = out.c >> 3;
     const long total = (long)out.n * out.h * out.w * cg;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int g = (int)(i % cg);
-        const long pix = i / cg;
+        int g;
+        const long pix = vse_divmod(i, cg, g);
         const half8 a = ld8(in, pix, g * 8);
         half8 o;
 #pragma unroll
@@ -447,8 +557,8 @@ __global__ __launch_bounds__(256) void unary_scalar_kernel(TView in, TView out, 
                                                            const int* __restrict__ wl_out) {
     const long total = (long)out.n * out.h * out.w * out.c;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % out.c);
-        const long pix = i / out.c;
+        int c;
+        const long pix = vse_divmod(i, out.c, c);
         float x;
         if (in.esize == 2) x = (float)reinterpret_cast<const half_t*>(in.ptr)[pix * in.ld + c];
         else x = reinterpret_cast<const float*>(in.ptr)[pix * in.ld + c];
@@ -668,6 +778,37 @@ __global__ __launch_bounds__(256) void wscale_kernel(const half_t* __restrict__ 
     }
 }
 
+#ifdef VSE_DEV_BUILD
+// dwconv_tile_kernel: tile rows by the map height (least dead rows, then the taller tile), LDS by the patch; VSE_E_UNSUPPORTED -> row kernel
+template <int KW, int SW, int GM>
+static int launch_dw_tile(const TView& in0, const TView& out, const TView& gate, int hilo, const half_t* wk, const float* bk, const int* p,
+                          const float* f, const int* wl_out, hipStream_t st) {
+    const int kh = p[P_KH], sh = p[P_SH];
+    int trl = 3;
+    long best = -1;
+    for (int t = 3; t >= 1; --t) {
+        const long rows = (long)((out.h + (1 << t) - 1) >> t) << t;
+        if (best < 0 || rows < best) { best = rows; trl = t; }
+    }
+    const int TR = 1 << trl, CGB = 32 >> trl, IC = 31 * SW + KW, IR = (TR - 1) * sh + kh;
+    const int colstride = CGB * 16 + (CGB == 4 ? 16 : CGB == 8 ? 32 : 0);
+    const size_t lds = (size_t)(p[P_LO_RES] ? 2 : 1) * IR * IC * colstride;
+    if (lds > 150 * 1024) return VSE_E_UNSUPPORTED;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_tile_kernel<KW, SW, GM>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return VSE_E_HIP;
+        attr = true;
+    }
+    const int cg = in0.c >> 3, cgblocks = (cg + CGB - 1) / CGB, tiles_w = (out.w + 31) / 32, tiles_h = (out.h + TR - 1) / TR;
+    const unsigned long long blocks = (unsigned long long)out.n * tiles_h * tiles_w * cgblocks;
+    if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_UNSUPPORTED;
+    hipLaunchKernelGGL((dwconv_tile_kernel<KW, SW, GM>), dim3((unsigned)blocks), dim3(256), lds, st, in0, out, gate, hilo, wk, bk, kh, sh, p[P_PH], p[P_PW],
+                       p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B], wl_out, trl, tiles_w, tiles_h, cgblocks);
+    return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
+}
+#endif
+
 int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const TView& in2, const TView& out,
                      const TView& out2, const char* wbase, const int* wl_in, const int* wl_out, hipStream_t st) {
     const int* p = op.p;
@@ -688,6 +829,24 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             if (!(op.flags & F_GATE)) gate.ptr = nullptr;
             else if (!in1.ptr || in1.c != in0.c || in1.n != in0.n || in1.esize != 2) return VSE_E_INVAL;
             if ((kw == 3 || kw == 5) && (sw == 1 || sw == 2)) {
+#ifdef VSE_DEV_BUILD
+                // VSE_DW_TILE: 0 = row kernel only, 1 = LDS-tile kernel for 5 x 5 filters, 2 = for 3 x 3 filters too
+                static const int dw_tile = getenv("VSE_DW_TILE") ? atoi(getenv("VSE_DW_TILE")) : 0;
+                if (dw_tile >= (kw == 5 ? 1 : 2)) {
+                    int rc = VSE_E_UNSUPPORTED;
+#define DW_TILE(KW_, SW_) do { \
+                        if (!gate.ptr) rc = launch_dw_tile<KW_, SW_, 0>(in0, out, gate, hilo, wk, bk, p, f, wl_out, st); \
+                        else if (gmode == 1) rc = launch_dw_tile<KW_, SW_, 1>(in0, out, gate, hilo, wk, bk, p, f, wl_out, st); \
+                        else rc = launch_dw_tile<KW_, SW_, 2>(in0, out, gate, hilo, wk, bk, p, f, wl_out, st); } while (0)
+                    if (kw == 3 && sw == 1) DW_TILE(3, 1);
+                    else if (kw == 3) DW_TILE(3, 2);
+                    else if (sw == 1) DW_TILE(5, 1);
+                    else DW_TILE(5, 2);
+#undef DW_TILE
+                    if (rc == VSE_OK) break;
+                    if (rc != VSE_E_UNSUPPORTED) return rc;
+                }
+#endif
                 const long items4 = (long)out.n * out.h * ((out.w + 3) / 4) * (in0.c >> 3);
                 const dim3 g4(grid_for(items4, 256)), b4(256);
 #define DW_ROW(KW_, SW_) do { \
