@@ -508,7 +508,10 @@ def roofline(pipe, step, repeats=2, steps_per_call=1):
                 a[1] += float(prog.op_gmacs[k])
                 a[2] += 1
                 # algorithmic HBM bytes of the op: every tensor it touches once (input, residual / second source, output) + its weights
-                a[3] += sum(float(r[v]["n"]) * float(r[v]["h"]) * float(r[v]["w"]) * float(r[v]["c"]) * float(r[v]["esize"])
+                # (an fp16 hi + lo pair tensor — P_LO_OUT / P_LO_IN / P_LO_RES of the mobile detectors' box-exact mode — is two tensors)
+                pair = {"out": 2.0 if int(r["p"][ir.P_LO_OUT]) else 1.0, "in0": 2.0 if int(r["p"][ir.P_LO_IN]) else 1.0,
+                        "in1": 2.0 if int(r["p"][ir.P_LO_RES]) else 1.0}
+                a[3] += sum(float(r[v]["n"]) * float(r[v]["h"]) * float(r[v]["w"]) * float(r[v]["c"]) * float(r[v]["esize"]) * pair.get(v, 1.0)
                             for v in ("in0", "in1", "in2", "out", "out2") if int(r[v]["n"]) > 0) \
                     + 2.0 * float(r["p"][ir.P_COUT]) * float(r["p"][ir.P_KTOT])
         pipe_last_sink = pipe.profile_sink
@@ -537,8 +540,15 @@ def roofline(pipe, step, repeats=2, steps_per_call=1):
     print(f"[bench] per-net GPU ms (profiled pass over {steps_per_call} step(s)):", {k: round(v, 2) for k, v in per_net.items()},
           f"-> per step: det {per_net.get('det', 0.0) / steps_per_call:.2f}, rec {rec_ms:.2f}", file=sys.stderr)
     vendor = vendor_gemm_tflops()
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+    # the roofline that bounds the dominant kernel: the larger of flops / MFMA peak and algorithmic bytes / HBM peak (the server models'
+    # 3x3 kernels: MFMA; the mobile pair of --models fast: HBM)
+    hbm_bound = _bytes / (HBM_PEAK_GBS * 1e6) > 2.0 * gmac / MFMA_PEAK_TFLOPS
+    head = {"bound": "hbm", "achieved": round(_bytes / tms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(_bytes / tms / 1e6 / HBM_PEAK_GBS, 4), "traffic": traffic, "mfma_tflops": round(achieved, 2),
+            "algorithmic_bytes_per_launch": int(_bytes / cnt)} if hbm_bound else \
+           {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic}
+    return {**head,
             # context for `frac` (not a replacement for it): what the vendor's GEMM reaches on this box, measured now
             "vendor_gemm_tflops": vendor, "vendor_gemm": "torch.matmul (hipBLASLt) fp16 8192^3, random operands, 10 launches",
             "frac_of_vendor_gemm": round(achieved / vendor, 3) if vendor else None,

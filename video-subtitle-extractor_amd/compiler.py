@@ -202,6 +202,7 @@ RAGGED_SEL_W = int(os.environ.get("VSE_RAGGED_SELW", "768"))
 ONECH = os.environ.get("VSE_ONECH", "1") != "0"             # DB head: last transposed conv stores the fp32 map directly
 GATE_CONCAT = os.environ.get("VSE_GATE_CONCAT", "1") != "0"   # SE output that only feeds a concat: multiplied by the copy into the slot
 PAIR_MAX_PIX = int(os.environ.get("VSE_PAIR_MAXPIX", str(1 << 40)))     # experiments: tensors with more pixels per image stay plain fp16
+PAIR_MIN_PIX = int(os.environ.get("VSE_PAIR_MINPIX", "0"))                # ... and tensors with fewer
 DWPW = os.environ.get("VSE_DWPW", "1") != "0"                 # depthwise conv fused in front of its 1x1 consumer (hi + lo nets: conv_dwpw.hip)
 # filter sizes sent there: 3x3 wins against depthwise + 1x1 launches (V4 16 -> 32 @272x480: 0.33 vs 0.44 ms), 5x5 loses (V3 64 -> 24
 # @68x120: 0.21 vs 0.14 ms: 25 taps of fp32 VALU work per 8 channels and lane, no window sharing between neighbouring pixels)
@@ -593,7 +594,7 @@ class Compiler(ChainMixin):
     def alloc_out(self, name, n, h, w, c, esize=2, lo=False):
         """Output view for tensor `name`; lands inside a concat buffer slice when planned so.  lo: room for the lo half of an
         fp16 hi + lo pair behind the hi channels of every pixel (Buf.lo_off)."""
-        if lo and esize == 2 and self.placement.get(name) is None and h * w <= PAIR_MAX_PIX:
+        if lo and esize == 2 and self.placement.get(name) is None and PAIR_MIN_PIX <= h * w <= PAIR_MAX_PIX:
             span = rup(c, 8)
             b = self.new_buf(n, h, w, 2 * span, esize)
             b.lo_off = span

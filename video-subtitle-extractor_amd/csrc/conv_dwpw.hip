@@ -28,7 +28,7 @@ __device__ int dwpw_abl_dev = 0;
 #endif
 
 template <int KS, int K, bool LO>
-__global__ __launch_bounds__(256, (KS <= 4 ? 3 : 2)) void conv_dwpw_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (KS <= 2 ? 4 : KS <= 4 ? 3 : 2)) void conv_dwpw_kernel(const ConvParams p) {
 #ifdef VSE_DEV_BUILD
     const int abl = dwpw_abl_dev;
 #endif

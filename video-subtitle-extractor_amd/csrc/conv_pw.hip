@@ -19,7 +19,7 @@
 #define PW_MAXN_HILO 128
 
 template <int KS, bool HILO = false>       // 16-channel K slices
-__global__ __launch_bounds__(256) void conv_pw_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (KS <= 2 ? 4 : 3)) void conv_pw_kernel(const ConvParams p) {
     constexpr int ROWH = KS * 16 + 8;                    // halfs per staged weight row (16 bytes of padding)
     constexpr int ROWS = HILO ? PW_MAXN_HILO : PW_MAXN, NT = HILO ? 2 : 1;
     __shared__ __attribute__((aligned(16))) half_t swt[NT * ROWS * ROWH];
