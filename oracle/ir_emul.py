@@ -396,9 +396,7 @@ class Emulator:
             g = self.read(r["in1"])
             x = ((x * g + x) if int(r["flags"]) & ir.F_RES else x * g).half().float()
         cp = x.shape[3]
-        wk = self.wread(int(r["w_off"]), kh * kw * cp, np.float16).astype(np.float32)
-        if int(r["flags"]) & ir.F_HILO:
-            wk = wk + self.wread(int(r["w_off"]) + 2 * kh * kw * cp, kh * kw * cp, np.float16).astype(np.float32)
+        wk = self.wread(int(r["w_off"]), kh * kw * cp, np.float32).copy()        # fp32 [kh * kw][cp] (hi + lo summed by the compiler)
         wk = wk.reshape(kh, kw, cp)
         w4 = torch.from_numpy(np.ascontiguousarray(wk.transpose(2, 0, 1)[:, None]))
         bias = torch.from_numpy(self.wread(int(r["b_off"]), cp, np.float32).copy())

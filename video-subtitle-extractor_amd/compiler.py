@@ -1422,10 +1422,14 @@ class Compiler(ChainMixin):
         bias = np.zeros(cp, np.float32)
         bias[:c] = ep["shift"]
         out = self.alloc_out(ep["out_name"], inv.n, oh, ow, c, lo=self.wants_lo(ep["out_name"]))
+        # the filter table the kernels read is fp32 [taps][cp]: fp16(w) — with hi + lo weights fp16(w) + fp16(w - fp16(w)), an exact
+        # fp32 sum — so the depthwise kernels (VALU-bound) neither convert nor add weight halves per tap (round 4; the values are the
+        # ones the fp16 tables of rounds 1-3 produced)
         wk_hi = wk.astype(np.float16)
-        if self.hilo:       # [2][taps][cp]: hi table, then lo = fp16(w - hi)
-            wk_hi = np.concatenate([wk_hi.reshape(-1), (wk.astype(np.float64) - wk_hi.astype(np.float64)).astype(np.float16).reshape(-1)])
-        w_off = self.add_weights(("dw", wname, ep["out_name"], self.hilo), wk_hi)
+        wk32 = wk_hi.astype(np.float32)
+        if self.hilo:
+            wk32 = wk32 + (wk.astype(np.float64) - wk_hi.astype(np.float64)).astype(np.float16).astype(np.float32)
+        w_off = self.add_weights(("dw32", wname, ep["out_name"], self.hilo), wk32.reshape(-1))
         b_off = self.add_weights(("dwb", wname, ep["out_name"]), bias)
         self.emit(ir.OP_DWCONV, ep["out_name"], [inv] if gate is None else [inv, gate[0]], out,
                   flags=(0 if gate is None else (ir.F_GATE | gate[1])) | (ir.F_HILO if self.hilo else 0),

@@ -34,6 +34,33 @@ __device__ __forceinline__ float vse_act(float x, int code, float a, float b) {
     }
 }
 
+// acc[e] = fma((float)x[e], w[e], acc[e]) for the 8 fp16 values of x as EIGHT v_fma_mix_f32: the conversion rides in the multiply-add
+// (op_sel_hi marks src0 as fp16, op_sel picks the half of the packed register) — hipcc emits v_cvt_f32_f16 + v_fma_f32 for the same
+// source, and the depthwise kernels are VALU-bound (counters, round 4: the vector pipe 65-85 % busy at 2.4 TB/s of their bytes).
+// Same value as fmaf((float)x[e], w[e], acc[e]): the fp16 -> fp32 conversion is exact, the multiply-add fused in fp32.
+typedef unsigned vse_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float vse_fma_mix_lo(unsigned xp, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(xp), "v"(w), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ float vse_fma_mix_hi(unsigned xp, float w, float acc) {
+    float d;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(xp), "v"(w), "v"(acc));
+    return d;
+}
+__device__ __forceinline__ void vse_fma_h8(float (&acc)[8], const half8& x, const float4v& w0, const float4v& w1) {
+    const vse_u32x4 u = __builtin_bit_cast(vse_u32x4, x);
+    acc[0] = vse_fma_mix_lo(u[0], w0[0], acc[0]);
+    acc[1] = vse_fma_mix_hi(u[0], w0[1], acc[1]);
+    acc[2] = vse_fma_mix_lo(u[1], w0[2], acc[2]);
+    acc[3] = vse_fma_mix_hi(u[1], w0[3], acc[3]);
+    acc[4] = vse_fma_mix_lo(u[2], w1[0], acc[4]);
+    acc[5] = vse_fma_mix_hi(u[2], w1[1], acc[5]);
+    acc[6] = vse_fma_mix_lo(u[3], w1[2], acc[6]);
+    acc[7] = vse_fma_mix_hi(u[3], w1[3], acc[7]);
+}
+
 // XCD-aware block order for STREAMING kernels whose neighbouring outputs share input rows (depthwise / pooling windows, up-sampling
 // copies): the dispatcher places block b on XCD b % 8 and every XCD has a private L2, so with the plain order the blocks of
 // vertically adjacent rows land on different XCDs and every input row is fetched from memory once per XCD that needs it (counters,

@@ -14,6 +14,7 @@
 //   output = the shared conv epilogue (bias, activation, residual, gate, pair store)
 // Bound: HBM (input once + output); L1 serves k * k x the input bytes.
 #include <stdlib.h>
+#include <type_traits>
 #include "conv_common.h"
 
 // aux blob (fp32 words, ints by bit pattern): [0] k  [1] stride  [2] pad  [3] act  [4] act_a  [5] act_b  [6] post_a  [7] post_b, then the
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 4 : KS <= 4 ? 3 : 2)) void conv_dwp
         half8 xh[KS], xl[KS];
         const half_t* img = p.in + n * (long)p.H * p.W * p.in_ld;
         const int iy0 = oh * S - PAD, ix0 = ow * S - PAD;
+        const bool inside = __builtin_amdgcn_ballot_w64(!(iy0 >= 0 && iy0 + K - 1 < p.H && ix0 >= 0 && ix0 + K - 1 < p.W)) == 0;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int c0 = ks * 16 + fj * 8;
@@ -103,36 +105,30 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 4 : KS <= 4 ? 3 : 2)) void conv_dwp
                 half8 xn[K], ln[K];
                 load_row(dy + 1 < dy_end ? dy + 1 : dy, xn, ln);          // (the last iteration re-reads its own row: an L1 hit, no branch)
                 const int iy = iy0 + dy;
+                // A tap outside the image is zeroed on the PACKED halves (4 selects per vector) — only in tiles that touch the border:
+                // `inside` is wave-uniform (every lane's 3 x 3 window lies in the image: ~85 % of the tiles at 272 x 480), and the
+                // multiply-adds take the fp16 values directly (vse_fma_h8: v_fma_mix_f32, no conversions): 8 VALU instructions per tap
+                // and 8 channels instead of 20 — the kernel is VALU-bound (counters: the vector pipe 65-85 % busy)
+                auto taps = [&](auto sel) {
 #pragma unroll
-                for (int dx = 0; dx < K; ++dx) {
-                    if (DWPW_ABL(4) && dy != K / 2) {
-                        asm volatile("" :: "v"(xr[dx]));
-                        if constexpr (LO) asm volatile("" :: "v"(lr[dx]));
-                        continue;
-                    }
-                    const int ix = ix0 + dx;
-                    // (unsigned compares, bitwise and: a short-circuit && compiles to branches, which split the block).  A tap outside
-                    // the image is zeroed on the PACKED halves (4 selects), and the multiply-add takes the fp16 value directly
-                    // (v_fma_mix_f32 converts on the fly): 12 VALU instructions per tap and 8 channels instead of 24
-                    const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                    const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-                    const half8 xv = ok ? xr[dx] : z8;
-                    const float4v w0 = *reinterpret_cast<const float4v*>(sdw + (dy * K + dx) * CP + c0);
-                    const float4v w1 = *reinterpret_cast<const float4v*>(sdw + (dy * K + dx) * CP + c0 + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        a8[e] = fmaf((float)xv[e], w0[e], a8[e]);
-                        a8[4 + e] = fmaf((float)xv[4 + e], w1[e], a8[4 + e]);
-                    }
-                    if constexpr (LO) {
-                        const half8 lv = ok ? lr[dx] : z8;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            a8[e] = fmaf((float)lv[e], w0[e], a8[e]);
-                            a8[4 + e] = fmaf((float)lv[4 + e], w1[e], a8[4 + e]);
+                    for (int dx = 0; dx < K; ++dx) {
+                        if (DWPW_ABL(4) && dy != K / 2) {
+                            asm volatile("" :: "v"(xr[dx]));
+                            if constexpr (LO) asm volatile("" :: "v"(lr[dx]));
+                            continue;
                         }
+                        const int ix = ix0 + dx;
+                        // (unsigned compares, bitwise and: a short-circuit && compiles to branches, which split the block)
+                        const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                        const half8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                        const float4v w0 = *reinterpret_cast<const float4v*>(sdw + (dy * K + dx) * CP + c0);
+                        const float4v w1 = *reinterpret_cast<const float4v*>(sdw + (dy * K + dx) * CP + c0 + 4);
+                        vse_fma_h8(a8, (!decltype(sel)::value || ok) ? xr[dx] : z8, w0, w1);
+                        if constexpr (LO) vse_fma_h8(a8, (!decltype(sel)::value || ok) ? lr[dx] : z8, w0, w1);
                     }
-                }
+                };
+                if (inside) taps(std::false_type{});
+                else taps(std::true_type{});
 #pragma unroll
                 for (int dx = 0; dx < K; ++dx) {
                     xr[dx] = xn[dx];

@@ -45,7 +45,7 @@ template <int GM> __device__ __forceinline__ half8 dw_gate_t(half8 x, const half
     else if constexpr (GM == 2) return dw_gate(x, g, 2);
     else return x;
 }
-__global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView gate, int gmode, int hilo, const half_t* __restrict__ w,
+__global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView gate, int gmode, int hilo, const float* __restrict__ w,
                                                      const float* __restrict__ bias, int kh, int kw, int sh, int sw,
                                                      int ph, int pw, int act, float act_a, float act_b, float post_a,
                                                      float post_b, const int* __restrict__ wl_out) {
@@ -74,17 +74,11 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
                 if (iw < 0 || iw >= in.w) continue;
                 const half8 x = dw_gate(ld8(in, (n * in.h + ih) * in.w + iw, g * 8), gv, gated);
                 const half8 xl = lo_in ? ld8(in, (n * in.h + ih) * in.w + iw, g * 8 + lo_in) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-                const half8 k = *reinterpret_cast<const half8*>(w + (long)(dy * kw + dx) * in.c + g * 8);
-                float kf[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kf[e] = (float)k[e];
-                if (hilo) {                     // F_HILO: the lo table follows the kh*kw*C hi entries
-                    const half8 kl = *reinterpret_cast<const half8*>(w + (long)(kh * kw + dy * kw + dx) * in.c + g * 8);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) kf[e] += (float)kl[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += ((float)x[e] + (float)xl[e]) * kf[e];
+                // (the filter table is fp32 [kh * kw][C]: the compiler stores fp16(w) — or fp16 hi + fp16 lo with F_HILO — as ONE fp32 value)
+                const float4v k0 = *reinterpret_cast<const float4v*>(w + (long)(dy * kw + dx) * in.c + g * 8);
+                const float4v k1 = *reinterpret_cast<const float4v*>(w + (long)(dy * kw + dx) * in.c + g * 8 + 4);
+                vse_fma_h8(acc, x, k0, k1);
+                if (lo_in) vse_fma_h8(acc, xl, k0, k1);
             }
         }
         half8 o, ol;
@@ -105,7 +99,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
 // weight vector once per tap instead of once per output.  Same accumulation order per output as dwconv_kernel (bias, then
 // taps row-major) -> bit-identical results.  The mobile (PP-LCNetV3 / MobileNetV3) models spend half of their time here.
 template <int KW, int SW, int GM>
-__global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TView gate, int hilo, const half_t* __restrict__ w,
+__global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TView gate, int hilo, const float* __restrict__ w,
                                                          const float* __restrict__ bias, int kh, int sh, int ph, int pw,
                                                          int act, float act_a, float act_b, float post_a, float post_b,
                                                          const int* __restrict__ wl_out) {
@@ -151,21 +145,13 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
             }
 #pragma unroll
             for (int dx = 0; dx < KW; ++dx) {
-                const half8 k = *reinterpret_cast<const half8*>(w + (long)(dy * KW + dx) * in.c + g * 8);
-                float kf[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kf[e] = (float)k[e];
-                if (hilo) {
-                    const half8 kl = *reinterpret_cast<const half8*>(w + (long)(kh * KW + dy * KW + dx) * in.c + g * 8);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) kf[e] += (float)kl[e];
-                }
+                const float4v k0 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + g * 8);
+                const float4v k1 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + g * 8 + 4);
 #pragma unroll
                 for (int o = 0; o < OUTW; ++o) {
                     const int iw = iw0 + o * SW + dx;
                     if (iw < 0 || iw >= in.w) continue;           // the reference kernel skips padded taps (no +0 rounding issue, same sums)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[o][e] += (float)x[o * SW + dx][e] * kf[e];
+                    vse_fma_h8(acc[o], x[o * SW + dx], k0, k1);
                 }
             }
         }
@@ -198,7 +184,7 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
 //   LDS layout: [plane hi | lo][row][column][CGB vectors of 16 bytes (+ pad)]; the pad (16 bytes for CGB = 4, 32 for CGB = 8) makes the 16
 //   lanes of a ds_read_b128 phase — CGB channel groups x 16 / CGB quads, quads 4 * SW columns apart — hit 16 distinct bank groups (SW = 1)
 template <int KW, int SW, int GM>
-__global__ __launch_bounds__(256) void dwconv_tile_kernel(TView in, TView out, TView gate, int hilo, const half_t* __restrict__ w,
+__global__ __launch_bounds__(256) void dwconv_tile_kernel(TView in, TView out, TView gate, int hilo, const float* __restrict__ w,
                                                           const float* __restrict__ bias, int kh, int sh, int ph, int pw,
                                                           int act, float act_a, float act_b, float post_a, float post_b,
                                                           const int* __restrict__ wl_out, int trl, int tiles_w, int tiles_h, int cgblocks) {
@@ -259,21 +245,13 @@ __global__ __launch_bounds__(256) void dwconv_tile_kernel(TView in, TView out, T
             for (int c = 0; c < WIN; ++c) x[c] = *reinterpret_cast<const half8*>(rowp + c * colstride);
 #pragma unroll
             for (int dx = 0; dx < KW; ++dx) {
-                const half8 k = *reinterpret_cast<const half8*>(w + (long)(dy * KW + dx) * in.c + gc * 8);
-                float kf[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) kf[e] = (float)k[e];
-                if (hilo) {
-                    const half8 kl = *reinterpret_cast<const half8*>(w + (long)(kh * KW + dy * KW + dx) * in.c + gc * 8);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) kf[e] += (float)kl[e];
-                }
+                const float4v k0 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + gc * 8);
+                const float4v k1 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + gc * 8 + 4);
 #pragma unroll
                 for (int o = 0; o < OUTW; ++o) {
                     const int iw = iw0 + o * SW + dx;
                     if (iw < 0 || iw >= in.w) continue;           // the reference kernel skips padded taps (no +0 rounding issue, same sums)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[o][e] += (float)x[o * SW + dx][e] * kf[e];
+                    vse_fma_h8(acc[o], x[o * SW + dx], k0, k1);
                 }
             }
         }
@@ -781,7 +759,7 @@ __global__ __launch_bounds__(256) void wscale_kernel(const half_t* __restrict__ 
 #ifdef VSE_DEV_BUILD
 // dwconv_tile_kernel: tile rows by the map height (least dead rows, then the taller tile), LDS by the patch; VSE_E_UNSUPPORTED -> row kernel
 template <int KW, int SW, int GM>
-static int launch_dw_tile(const TView& in0, const TView& out, const TView& gate, int hilo, const half_t* wk, const float* bk, const int* p,
+static int launch_dw_tile(const TView& in0, const TView& out, const TView& gate, int hilo, const float* wk, const float* bk, const int* p,
                           const float* f, const int* wl_out, hipStream_t st) {
     const int kh = p[P_KH], sh = p[P_SH];
     int trl = 3;
@@ -817,7 +795,7 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
         case OP_DWCONV: {
             if ((in0.c & 7) || in0.esize != 2 || out.c != in0.c) return VSE_E_INVAL;
             const long items = (long)out.n * out.h * out.w * (in0.c >> 3);
-            const half_t* wk = reinterpret_cast<const half_t*>(wbase + op.w_off);
+            const float* wk = reinterpret_cast<const float*>(wbase + op.w_off);       // fp32 [kh * kw][C] (hi + lo summed by the compiler)
             const float* bk = reinterpret_cast<const float*>(wbase + op.b_off);
             const int kw = p[P_KW], sw = p[P_SW];
             TView gate = in1;

@@ -70,7 +70,8 @@ P_DOTACT = 13       # activation of the fused 1-channel projection
 F_SRC2 = 32         # in2 is a second input source: channels [in0.c, in0.c+in2.c) of a virtual concat, own shift p[P_IN2SHIFT]
 P_IN2SHIFT = 14
 F_HILO = 1024       # weights stored as fp16 hi + fp16 lo (w = hi + lo to ~22 bits): the kernel walks K twice over the same
-                    # activations, the lo tiles follow the hi tiles in the blob; OP_DWCONV: the lo table follows the hi table
+                    # activations, the lo tiles follow the hi tiles in the blob; OP_DWCONV: the filter table is fp32 [taps][C] either way
+                    # (fp16 hi + fp16 lo summed by the compiler: the depthwise kernels multiply-add fp16 activations with fp32 weights)
 F_STEM = 512        # 3x3 conv over an image-like input (<= 4 real channels): conv_stem_kernel, weights packed [Np][10 taps][8]
 F_GATE = 256        # OP_DWCONV: in1 = SE gate [N,1,1,C]; the input is multiplied by it (rounded to fp16) on load — the
                     # separate OP_SCALE pass of an SE block whose only consumer is this depthwise conv disappears
