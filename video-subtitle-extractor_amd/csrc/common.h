@@ -34,6 +34,34 @@ __device__ __forceinline__ float vse_act(float x, int code, float a, float b) {
     }
 }
 
+// One activation code applied to N values: ONE uniform switch per call (per-element switches blow the epilogue up to
+// thousands of scalar branches).
+template <int N> __device__ __forceinline__ void vse_act_n(float (&v)[N], int code, float a, float b) {
+    switch (code) {
+        case ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.f);
+            break;
+        case ACT_HSWISH:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+            break;
+        case ACT_SWISH:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+            break;
+        case ACT_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+            break;
+        case ACT_HSIGMOID:
+#pragma unroll
+            for (int e = 0; e < N; ++e) v[e] = fminf(fmaxf(v[e] * a + b, 0.f), 1.f);
+            break;
+        default: break;
+    }
+}
+
 // acc[e] = fma((float)x[e], w[e], acc[e]) for the 8 fp16 values of x as EIGHT v_fma_mix_f32: the conversion rides in the multiply-add
 // (op_sel_hi marks src0 as fp16, op_sel picks the half of the packed register) — hipcc emits v_cvt_f32_f16 + v_fma_f32 for the same
 // source, and the depthwise kernels are VALU-bound (counters, round 4: the vector pipe 65-85 % busy at 2.4 TB/s of their bytes).

@@ -124,34 +124,6 @@ __device__ __forceinline__ void conv_pix_coords(const ConvParams& p, long m, lon
 
 __device__ __forceinline__ int conv_wrow(int f) { return (f & ~12) | ((f & 4) << 1) | ((f & 8) >> 1); }
 
-// One activation code applied to N values: ONE uniform switch per call (per-element switches blow the epilogue up to
-// thousands of scalar branches).
-template <int N> __device__ __forceinline__ void vse_act_n(float (&v)[N], int code, float a, float b) {
-    switch (code) {
-        case ACT_RELU:
-#pragma unroll
-            for (int e = 0; e < N; ++e) v[e] = fmaxf(v[e], 0.f);
-            break;
-        case ACT_HSWISH:
-#pragma unroll
-            for (int e = 0; e < N; ++e) v[e] = v[e] * fminf(fmaxf(v[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
-            break;
-        case ACT_SWISH:
-#pragma unroll
-            for (int e = 0; e < N; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
-            break;
-        case ACT_SIGMOID:
-#pragma unroll
-            for (int e = 0; e < N; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
-            break;
-        case ACT_HSIGMOID:
-#pragma unroll
-            for (int e = 0; e < N; ++e) v[e] = fminf(fmaxf(v[e] * a + b, 0.f), 1.f);
-            break;
-        default: break;
-    }
-}
-
 // Per-cout epilogue constants (bias, F_DOT1 projection weights) are staged ONCE per block in LDS (conv_stage_consts;
 // visible after the K loop's first wait + barrier) and read back per accumulator
 // tile in the lane's register order.  Reading them from global memory inside the epilogue costs one dependent memory

@@ -136,11 +136,20 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 4 : KS <= 4 ? 3 : 2)) void conv_dwp
                 }
             }
             vse_act_n<8>(a8, dact, dact_a, dact_b);
+            // (uniform branches: the affine behind the activation is the identity for all but a handful of layers, and only a channel
+            // count that is not a multiple of 16 has a half slice behind its channels — the kernel is VALU-bound)
+            if (dpost_a != 1.f || dpost_b != 0.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] = a8[e] * dpost_a + dpost_b;
+            }
+            if ((p.cinp & 15) && c0 >= p.cinp) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a8[e] = 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = (c0 < p.cinp) ? a8[e] * dpost_a + dpost_b : 0.f;
-                xh[ks][e] = (half_t)v;
-                xl[ks][e] = (half_t)(v - (float)xh[ks][e]);
+                xh[ks][e] = (half_t)a8[e];
+                xl[ks][e] = (half_t)(a8[e] - (float)xh[ks][e]);
             }
         }
         for (int j = 0; j < ntile; ++j) {

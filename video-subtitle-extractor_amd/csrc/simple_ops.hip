@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
     constexpr int OUTW = 4, WIN = (OUTW - 1) * SW + KW;
     const int lo_off = ((hilo >> 1) & 0xfff) << 3, lo_in = ((hilo >> 13) & 0xfff) << 3;          // (see dwconv_kernel)
     hilo &= 1;
+    const bool affine = post_a != 1.f || post_b != 0.f;
     const int cg = in.c >> 3;
     const int owq = (out.w + OUTW - 1) / OUTW;
     const long total = (long)out.n * out.h * owq * cg;
@@ -155,15 +156,19 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
                 }
             }
         }
+        // ONE activation switch for the thread's 32 values (a per-element switch is a chain of scalar branches per element)
+#pragma unroll
+        for (int o = 0; o < OUTW; ++o) vse_act_n<8>(acc[o], act, act_a, act_b);
 #pragma unroll
         for (int o = 0; o < OUTW; ++o) {
             if (ow0 + o >= out.w) continue;
-            half8 r, rl;
+            half8 r, rl = half8{0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = vse_act(acc[o][e], act, act_a, act_b) * post_a + post_b;
+                float v = acc[o][e];
+                if (affine) v = v * post_a + post_b;          // (uniform: the identity for all but a handful of layers)
                 r[e] = (half_t)v;
-                rl[e] = (half_t)(v - (float)r[e]);
+                if (lo_off) rl[e] = (half_t)(v - (float)r[e]);
             }
             if (wl_out != nullptr && ow0 + o >= wl_out[n]) r = half8{0, 0, 0, 0, 0, 0, 0, 0};
             st8(out, (n * out.h + oh) * out.w + ow0 + o, g * 8, r);
