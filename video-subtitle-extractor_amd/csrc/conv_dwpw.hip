@@ -12,7 +12,8 @@
 //           [k * k + 1][KS * 16] fp32 (last row = bias) staged once per block (dynamic LDS)
 //   input  = NHWC fp16, optionally an fp16 hi + lo pair (p.in_lo_off: both halves are filtered)
 //   output = the shared conv epilogue (bias, activation, residual, gate, pair store)
-// Bound: HBM (input once + output); L1 serves k * k x the input bytes.
+// Bound: measured VALU (round 4 counters: ~500 vector instructions per 32-pixel tile and wave, the vector pipe 65-85 % busy) — by bytes it
+// would be HBM (input once + output; L1 serves k * k x the input bytes).  The taps are v_fma_mix_f32 (fp16 x fp32 + fp32, no conversions).
 #include <stdlib.h>
 #include <type_traits>
 #include "conv_common.h"
