@@ -25,6 +25,7 @@ from . import ir
 
 CHAIN = os.environ.get("VSE_CHAIN", "1") != "0"
 CHAIN_MAX_STAGES = int(os.environ.get("VSE_CHAIN_MAXSTAGES", "6"))
+CHAIN_HEAD = os.environ.get("VSE_CHAIN_HEAD", "1") != "0"               # the DB head's two transposed convs as one chain (try_lower_head_tail)
 CHAIN_LDS_2 = 76 * 1024          # two blocks per CU (160 KiB of LDS)
 CHAIN_LDS_1 = 150 * 1024
 CHAIN_TILES = [(8, 32), (16, 16), (8, 16), (4, 32), (4, 16), (2, 32), (4, 8), (2, 16), (2, 8)]
@@ -356,7 +357,7 @@ class ChainMixin:
         4 r + c is output pixel (4 y + r, 4 x + c) of input pixel (y, x); the kernel stores those 4 x 4 blocks of the fp32 map itself
         (CHS_SHUF).  The c1-channel tensor at twice the resolution (24 x 272 x 480 per frame, written and read back: 16 MB of the
         mobile detectors' 200 MB per frame) never exists."""
-        if not (CHAIN and getattr(self, "chain", False)) or self.ragged:
+        if not (CHAIN and CHAIN_HEAD and getattr(self, "chain", False)) or self.ragged:
             return False
         op0 = self.ops[i0]
         if op0["type"] != "conv2d_transpose":
