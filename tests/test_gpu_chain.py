@@ -35,7 +35,9 @@ def test_chained_mobile_detector_matches_the_oracle(ctx, mid, shape):
     got, prog = _run(ctx, desc, w, x, True)
     plain, prog0 = _run(ctx, desc, w, x, False)
     kinds = [int(o["kind"]) for o in prog.ops]
-    assert kinds.count(ir.OP_CHAIN) >= 4 and ir.OP_CHAIN not in [int(o["kind"]) for o in prog0.ops]
+    # (the layer-by-layer program keeps ONE chain record: the DB head's tail, which runs in registers — chain_pw2_kernel)
+    assert kinds.count(ir.OP_CHAIN) >= 4 and [int(o["kind"]) for o in prog0.ops].count(ir.OP_CHAIN) == 1
+    assert int(prog0.ops[-1]["p"][ir.P_CH_PW2]) == 1 and int(prog.ops[-1]["p"][ir.P_CH_PW2]) == 1
     assert int(prog.ops[-1]["kind"]) == ir.OP_CHAIN and int(prog.ops[-1]["out"]["esize"]) == 4       # the head tail stores the map
     assert sum(bool(int(o["flags"]) & ir.F_OGATE) for o in prog.ops if int(o["kind"]) == ir.OP_CONV) == 4
     e1, e0 = np.abs(got - ref).max(), np.abs(plain - ref).max()

@@ -1,3 +1,2 @@
-export VSE_CHAIN_HEAD=0
-python tools/chain_check.py --time 2>&1 | grep -E "chain_check|FAIL|64x544x960" | cut -c1-120
-for hw in "1080 1920" "720 1280"; do python tools/parity_sweep.py 128 $hw 2>&1 | grep -v amdgpu.ids | tail -1; done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > gpurun_out/r4_c49_tests.log; cat gpurun_out/r4_c49_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

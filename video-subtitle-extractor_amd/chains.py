@@ -357,7 +357,8 @@ class ChainMixin:
         4 r + c is output pixel (4 y + r, 4 x + c) of input pixel (y, x); the kernel stores those 4 x 4 blocks of the fp32 map itself
         (CHS_SHUF).  The c1-channel tensor at twice the resolution (24 x 272 x 480 per frame, written and read back: 16 MB of the
         mobile detectors' 200 MB per frame) never exists."""
-        if not (CHAIN and CHAIN_HEAD and getattr(self, "chain", False)) or self.ragged:
+        # (also in the layer-by-layer program of a hi + lo net, chain=False: the register form chain_pw2_kernel replaces two launches)
+        if not (CHAIN and CHAIN_HEAD and (getattr(self, "chain", False) or getattr(self, "hilo", False))) or self.ragged:
             return False
         op0 = self.ops[i0]
         if op0["type"] != "conv2d_transpose":
@@ -511,6 +512,9 @@ class ChainMixin:
         name = "chain:" + "+".join(st["out_name"] for st in stages)
         self.emit(ir.OP_CHAIN, name[:200], ins, outs[0], p={ir.P_CH_TILES_H: tiles_h, ir.P_CH_TILES_W: tiles_w, ir.P_CH_LDS: plan["lds_total"],
                                                              ir.P_CH_NSTAGES: n, ir.P_CH_NBUFS: n + 1,
+                                                             ir.P_CH_PW2: int(bool(map_out and n == 2 and all(st["type"] == "pw" for st in stages)
+                                                                                   and stages[0]["cin"] <= 64 and stages[1]["cout"] <= 32)),
+                                                             ir.P_CH_IMG: int(lds_img.nbytes),
                                                              ir.P_CH_LO_IN: int(getattr(inv.buf, "lo_off", 0) or 0),
                                                              ir.P_CH_LO_OUT0: outs[0].buf.lo_off,
                                                              ir.P_CH_LO_OUT1: outs[1].buf.lo_off if len(outs) > 1 else 0,
