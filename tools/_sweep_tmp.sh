@@ -1,4 +1,2 @@
-bash tools/collect_profiles.sh r04 > gpurun_out/r4_c52_prof.log 2>&1
-tail -2 gpurun_out/r4_c52_prof.log | cut -c1-200
-python -c "
-import json; d=json.load(open('gpurun_out/bench_r04.json')); print(d['value'], d['ms_per_step'], {k:(v.get('value'), v.get('timed_blocks')) for k,v in d['config']['secondary'].items()})"
+python tools/dw_tile_check.py 2>&1 | grep -v amdgpu.ids | cut -c1-150
+python tools/chain_check.py --time 2>&1 | grep -E "chain_check|FAIL|64x544x960" | cut -c1-120

@@ -4,6 +4,7 @@
 // layout allows it, so a wave reads/writes 1 KiB per instruction with consecutive lanes on consecutive
 // channel groups of the same pixel (coalesced NHWC).
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 #define GRID_CAP 16384
@@ -124,38 +125,47 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[o][e] = bias[g * 8 + e];
         const half8 gv = GM ? ld8(gate, n, g * 8) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-        for (int dyp = 0; dyp < (lo_in ? 2 * kh : kh); ++dyp) {
-            // (a pair input: every filter row is walked twice, over the hi and over the lo half of the same pixels)
-            const int dy = dyp < kh ? dyp : dyp - kh;
-            const int coff = dyp < kh ? 0 : lo_in;
-            const int ih = oh * sh - ph + dy;
-            if (ih < 0 || ih >= in.h) continue;
-            const long rowpix = (n * in.h + ih) * in.w;
-            half8 x[WIN];
+        // wave-uniform: every lane's WIN input columns lie inside the image (all waves but those that hold a first / last quad of a row):
+        // the column tests of the loads and of the taps — ~550 of the 1660 vector instructions of a 5 x 5 thread, and the kernel is
+        // VALU-bound — are compiled out of that path.  Same operations on the same values: bit-identical.
+        const bool inside = __builtin_amdgcn_ballot_w64(!(iw0 >= 0 && iw0 + WIN - 1 < in.w)) == 0;
+        auto rows = [&](auto chk) {
+            constexpr bool CHK = decltype(chk)::value;
+            for (int dyp = 0; dyp < (lo_in ? 2 * kh : kh); ++dyp) {
+                // (a pair input: every filter row is walked twice, over the hi and over the lo half of the same pixels)
+                const int dy = dyp < kh ? dyp : dyp - kh;
+                const int coff = dyp < kh ? 0 : lo_in;
+                const int ih = oh * sh - ph + dy;
+                if (ih < 0 || ih >= in.h) continue;
+                const long rowpix = (n * in.h + ih) * in.w;
+                half8 x[WIN];
 #pragma unroll
-            for (int c = 0; c < WIN; ++c) {
-                const int iw = iw0 + c;
-                x[c] = (iw >= 0 && iw < in.w) ? ld8(in, rowpix + iw, g * 8 + coff) : half8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-            // all loads of the row first, arithmetic afterwards: multiplying each vector as it arrives serialises the loads
-            // (the kernel is HBM-bound on the detector's maps: 0.52 ms gated against 0.32 ms with the loads batched)
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (GM != 0) {
+                for (int c = 0; c < WIN; ++c) {
+                    const int iw = iw0 + c;
+                    x[c] = (!CHK || (iw >= 0 && iw < in.w)) ? ld8(in, rowpix + iw, g * 8 + coff) : half8{0, 0, 0, 0, 0, 0, 0, 0};
+                }
+                // all loads of the row first, arithmetic afterwards: multiplying each vector as it arrives serialises the loads
+                // (0.52 ms gated against 0.32 ms with the loads batched on the detector's maps)
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (GM != 0) {
 #pragma unroll
-                for (int c = 0; c < WIN; ++c) x[c] = dw_gate_t<GM>(x[c], gv);
-            }
+                    for (int c = 0; c < WIN; ++c) x[c] = dw_gate_t<GM>(x[c], gv);
+                }
 #pragma unroll
-            for (int dx = 0; dx < KW; ++dx) {
-                const float4v k0 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + g * 8);
-                const float4v k1 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + g * 8 + 4);
+                for (int dx = 0; dx < KW; ++dx) {
+                    const float4v k0 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + g * 8);
+                    const float4v k1 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + g * 8 + 4);
 #pragma unroll
-                for (int o = 0; o < OUTW; ++o) {
-                    const int iw = iw0 + o * SW + dx;
-                    if (iw < 0 || iw >= in.w) continue;           // the reference kernel skips padded taps (no +0 rounding issue, same sums)
-                    vse_fma_h8(acc[o], x[o * SW + dx], k0, k1);
+                    for (int o = 0; o < OUTW; ++o) {
+                        const int iw = iw0 + o * SW + dx;
+                        if (CHK && (iw < 0 || iw >= in.w)) continue;      // the reference kernel skips padded taps (no +0 rounding issue, same sums)
+                        vse_fma_h8(acc[o], x[o * SW + dx], k0, k1);
+                    }
                 }
             }
-        }
+        };
+        if (inside) rows(std::false_type{});
+        else rows(std::true_type{});
         // ONE activation switch for the thread's 32 values (a per-element switch is a chain of scalar branches per element)
 #pragma unroll
         for (int o = 0; o < OUTW; ++o) vse_act_n<8>(acc[o], act, act_a, act_b);
