@@ -39,6 +39,8 @@ def main():
         outs = net.run(x, widths=widths) if widths is not None else net.run(x)
         torch.cuda.synchronize()
         hsh = hashlib.sha1(b"".join(o.cpu().numpy().tobytes() for o in outs)).hexdigest()[:16]
+        if os.environ.get("VSE_DUMP"):
+            np.save(os.path.join("gpurun_out", f"dump_{os.environ['VSE_DUMP']}_{mid}_{n}.npy"), outs[0].float().cpu().numpy())
         t0 = time.perf_counter()
         for _ in range(5):
             net.run(x, widths=widths) if widths is not None else net.run(x)
