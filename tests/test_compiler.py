@@ -400,6 +400,22 @@ def test_mobile_detector_chains_and_gated_laterals(mid):
         if int(o["out"]["esize"]) == 4:
             final_h //= 4               # the head tail stores 4 x 4 map pixels per pixel of its last stage (CHS_SHUF)
         assert int(o["p"][ir.P_CH_TILES_H]) * hdr[ir.CHH_TH] >= final_h and int(o["p"][ir.P_CH_LDS]) == hdr[ir.CHH_LDS_TOTAL]
+    # the DB head's tail (the last op of both programs) is flagged for the register form chain_pw2_kernel, image size in the record;
+    # the layer-by-layer program keeps exactly that one chain record
+    for pr in (prog, plain):
+        tail = pr.ops[-1]
+        hdr = np.frombuffer(bytes(pr.weights.blob[int(tail["w_off"]):int(tail["w_off"]) + 4 * ir.CH_HDR]), np.int32)
+        assert int(tail["kind"]) == ir.OP_CHAIN and int(tail["p"][ir.P_CH_PW2]) == 1 and int(tail["p"][ir.P_CH_IMG]) == hdr[ir.CHH_LDSW_BYTES] <= 64 * 1024
+    assert [int(o["kind"]) for o in plain.ops].count(ir.OP_CHAIN) == 1
+    # depthwise filter tables are fp32 [taps][C] = fp16 hi + fp16 lo summed (round 4): the emulator and the kernels read them as such
+    dw = [o for o in plain.ops if int(o["kind"]) == ir.OP_DWCONV]
+    assert dw
+    for o in dw[:3]:
+        taps, cp = int(o["p"][ir.P_KH]) * int(o["p"][ir.P_KW]), int(o["in0"]["c"])
+        tab = np.frombuffer(bytes(plain.weights.blob[int(o["w_off"]):int(o["w_off"]) + 4 * taps * cp]), np.float32)
+        hi = tab.astype(np.float16).astype(np.float32)
+        lo = (tab - hi).astype(np.float16).astype(np.float32)
+        assert np.isfinite(tab).all() and np.abs(tab).max() > 0 and np.array_equal(hi + lo, tab)      # exactly a hi + lo pair
     # a tensor that feeds a chain is a pair: its producer stores the lo half, the chain reads it at the same offset
     lo_in = [int(o["p"][ir.P_CH_LO_IN]) for o in chains]
     assert any(lo_in) and all(v % 8 == 0 for v in lo_in)
