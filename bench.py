@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="finish batch k before the detector of batch k+1 starts")
     ap.add_argument("--det-priority", type=int, default=0, help="HIP stream priority of the detector streams (-1 = high)")
     ap.add_argument("--rec-priority", type=int, default=-1, help="HIP stream priority of the recogniser side streams (-1 = high: the small recogniser kernels get CUs as they free up beside the detector of the next batch, +0.6 %)")
+    ap.add_argument("--det-stream-mode", default="independent", choices=["own", "shared", "independent"],
+                    help="detector batches in flight: own = one torch stream each (torch's round-robin pool: whether two of them share a "
+                         "hardware queue is left to the runtime), shared = ONE stream for all of them (in order, back to back), independent = "
+                         "streams verified to run concurrently with each other and with the main stream (engine.Context.side_streams)")
     ap.add_argument("--det-depth", type=int, default=2, help="detector batches in flight ahead of the one being recognised (2: two detector launches fill each other's tails, +3.6 % over 1 on one box; 3: +1.6 %)")
     return ap.parse_args()
 
@@ -198,6 +202,10 @@ def main():
 
     ctx = engine.Context(local)
     coll_dev = ctx.tdev if backend == "nccl" else "cpu"
+    # gather vs all_gather for the record exchange: agreed by all ranks here, once, never inside the timed region (parallel.gather_mode)
+    gmode = parallel.gather_mode(coll_dev)
+    if world > 1 and rank == 0:
+        print(f"[bench] record exchange: {gmode} (agreed by all {world} ranks)", file=sys.stderr, flush=True)
 
     def sync():
         if world > 1:
@@ -276,7 +284,12 @@ def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, 
     # whole-video extraction does with consecutive frame batches.  Every batch started inside the timed region is also
     # finished inside it (run_steps drains its last batch), so K steps = K complete det + rec passes.
     depth = max(1, args.det_depth)
-    det_streams = [torch.cuda.Stream(device=ctx.tdev, priority=args.det_priority) for _ in range(depth)]
+    if args.det_stream_mode == "shared":
+        det_streams = [torch.cuda.Stream(device=ctx.tdev, priority=args.det_priority)] * depth
+    elif args.det_stream_mode == "independent":
+        det_streams = ctx.side_streams(depth, priority=args.det_priority)
+    else:
+        det_streams = [torch.cuda.Stream(device=ctx.tdev, priority=args.det_priority) for _ in range(depth)]
     pipe.rec_stream_priority = args.rec_priority
 
     def stage1(k):
@@ -352,13 +365,13 @@ def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, 
 
     return types.SimpleNamespace(pipe=pipe, det=det, rec=rec, det_id=det_id, rec_id=rec_id, lang=lang, frames_np=frames_np, truth=truth,
                                  overlay_np=overlay_np, overlay=overlay, quads=quads, timed=timed, det_maps=det_maps,
-                                 stage2_recognise=stage2_recognise, span=span, depth=depth, args=args)
+                                 stage2_recognise=stage2_recognise, span=span, depth=depth, args=args, coll_dev=coll_dev)
 
 
 def finish(args, ctx, world, rank, W, out, dt, log, host_threads, build_secondary):
     import torch
     import torch.distributed as dist
-    from vse_amd import modelzoo, pipeline, shim
+    from vse_amd import modelzoo, parallel, pipeline, shim
     pipe, det, rec, det_id, rec_id, lang = W.pipe, W.det, W.rec, W.det_id, W.rec_id, W.lang
     frames_np, truth, overlay_np, overlay, quads = W.frames_np, W.truth, W.overlay_np, W.overlay, W.quads
     timed, det_maps, stage2_recognise, span, depth = W.timed, W.det_maps, W.stage2_recognise, W.span, W.depth
@@ -406,7 +419,8 @@ def finish(args, ctx, world, rank, W, out, dt, log, host_threads, build_secondar
                        "rec_span": f"crops of {span} consecutive batch(es) share the recogniser's launch sequences",
                        "frames_per_gpu_step": args.batch, "det_model": det_id, "rec_model": rec_id,
                        "weights": "real" if modelzoo.has_real_weights(det_id) else "seeded random (reference blobs missing)",
-                       "gather": "one variable-length gather of all ranks' records to rank 0 at the end of the timed region",
+                       "gather": "one variable-length gather of all ranks' records to rank 0 at the end of the timed region"
+                                 + (f" ({parallel.gather_mode(None if world == 1 else W.coll_dev)}, agreed by all ranks at start-up)" if world > 1 else ""),
                        "host_threads_per_rank": host_threads if host_threads else "uncapped (1 rank)",
                        "records_gathered": len(out) if out is not None else 0},
         }

@@ -43,22 +43,24 @@ def test_bench_two_ranks_one_json_line(ctx):
     assert one["config"]["boxes_last_step"] > 0
 
 
-@pytest.mark.parametrize("det_id,rec_id", [("V4_ch_det", "V4_ch_rec"), ("V4_ch_det_fast", "V4_ch_rec_fast")])
-def test_bench_configuration_c2_against_the_oracle_in_one_piece(ctx, det_id, rec_id):
-    """The EXACT path bench.py times (BASELINE configs[1]; and configs[0]'s models at the same frame size, the reference's default
-    `fast` mode — bench.py --models fast, config.secondary.fast_mode_1080p) against the CPU oracle, end to end on 4 x 1080p frames:
+@pytest.mark.parametrize("det_id,rec_id,H,W,nf", [("V4_ch_det", "V4_ch_rec", 1080, 1920, 4), ("V4_ch_det_fast", "V4_ch_rec_fast", 1080, 1920, 4),
+                                                  ("V4_ch_det", "V4_ch_rec", 2160, 3840, 2)])
+def test_bench_configuration_c2_against_the_oracle_in_one_piece(ctx, det_id, rec_id, H, W, nf):
+    """The EXACT path bench.py times (BASELINE configs[1]; configs[0]'s models at the same frame size, the reference's default
+    `fast` mode — bench.py --models fast, config.secondary.fast_mode_1080p; and configs[2]'s server pair on 4K frames —
+    config.secondary.4k_batch32) against the CPU oracle, end to end on 4 x 1080p / 2 x 2160p frames:
     V4_ch_det map (engine vs oracle/net_ref) max-overlaid with bench.text_kernel_maps ON BOTH SIDES -> DB post-processing
     -> boxes (identical integers) -> perspective crops -> V4_ch_rec in the benchmarked ragged mode vs the oracle's
-    rec_batches chunks (backend/tools/ocr.py:24-27,88-113; paddleocr TextSystem): confidences within 1e-3 of the oracle's
-    softmax, strings identical wherever the oracle's own top-2 margin is clear."""
-    import difflib
+    rec_batches chunks (backend/tools/ocr.py:24-27,88-113; paddleocr TextSystem): every string reachable from the oracle's
+    per-step distribution through near-ties only (log-margin < 2e-2, tests/parity.py), identical strings carry the oracle's
+    confidence within 1 % relative; the share of identical strings is printed (a random-weight head flips ~0.3-0.5 % of its steps)."""
     import numpy as np
+    from parity import check_text
     import torch
     sys.path.insert(0, ROOT)
     import bench
     from oracle import net_ref, pipeline_ref as P
     from vse_amd import pipeline, shim, synth
-    nf, H, W = 4, 1080, 1920
     from vse_amd import modelzoo
     det = modelzoo.get_model(det_id, seed=0)                          # bench.py's own stand-in detector (seeded, uncalibrated) ...
     det = (det[0], bench.empty_det_head(det[0], dict(det[1])))        # ... with its head pushed below the threshold, as bench.py does
@@ -92,13 +94,8 @@ def test_bench_configuration_c2_against_the_oracle_in_one_piece(ctx, det_id, rec
                 ids, conf = P.ctc_greedy(probs[k])
                 ref_text = P.decode_text(ids, ref_charset)
                 text, score = got_res[f][i]
-                srt = np.sort(probs[k], -1)
-                shaky = int(((srt[:, -1] - srt[:, -2]) < 0.05 * srt[:, -1]).sum())
-                edits = [o for o in difflib.SequenceMatcher(None, text, ref_text).get_opcodes() if o[0] != "equal"]
-                assert len(edits) <= shaky, (text, ref_text, shaky)
-                if not edits:
-                    assert abs(score - conf) < 1e-3, (score, conf)      # mean of the max probabilities of the kept steps
-                    nexact += 1
+                nexact += check_text(rec_id, text, score, probs[k], ref_charset, ref_text, conf)
                 nbox += 1
-    assert nbox >= nf and nexact >= 1
-    print(f"C2 path vs oracle: {nbox} boxes identical, {nexact} / {nbox} strings identical (the rest inside the oracle's top-2 margin)")
+    print(f"{det_id} + {rec_id} @{H}p path vs oracle: {nbox} boxes identical, {nexact} / {nbox} strings identical (the rest reachable "
+          f"through near-ties of the oracle's distribution, tests/parity.py)")
+    assert nbox >= nf and nexact >= 1, (nexact, nbox)

@@ -19,9 +19,10 @@ def _iou(a, b):
 @pytest.mark.parametrize("hw", [(720, 1280), (1080, 1920), (2160, 3840)])      # BASELINE configs C1 / C2 / C3 frame sizes
 def test_ocr_pipeline_vs_oracle(ctx, hw):
     """Boxes: IoU >= 0.99 (in fact identical integers).  Strings: identical after CTC collapse, except that a
-    time step may differ where the ORACLE's own top-2 margin is below 5 % — the recogniser weights are stand-ins
-    (the reference's blobs are missing), so its softmax is nearly flat and fp16 noise can flip such ties."""
+    time step may take another class where the ORACLE's own log-margin over it is below 2e-2 — the recogniser weights are
+    stand-ins (the reference's blobs are missing), so its softmax is nearly flat and fp16 noise can flip such ties."""
     import torch
+    from parity import check_text
     from vse_amd import pipeline, synth
     det = net_ref.get_weights("V3_ch_det_fast")            # the one model with real weights
     rec = net_ref.get_weights("V4_en_rec_fast")            # calibrated stand-in weights
@@ -49,17 +50,14 @@ def test_ocr_pipeline_vs_oracle(ctx, hw):
                 ids, conf = P.ctc_greedy(probs[k])
                 ref_text = P.decode_text(ids, charset)
                 text, score = gr[i]
-                srt = np.sort(probs[k], -1)
-                shaky = int(((srt[:, -1] - srt[:, -2]) < 0.05 * srt[:, -1]).sum())
-                if text == ref_text:
-                    exact += 1
-                else:
-                    import difflib
-                    ops = [o for o in difflib.SequenceMatcher(None, text, ref_text).get_opcodes() if o[0] != "equal"]
-                    assert len(ops) <= shaky, (text, ref_text, shaky)
-                assert abs(score - conf) < 2e-2
+                # the string must be reachable from the oracle's per-step distribution through near-ties only (tests/parity.py: any other
+                # character fails); an identical string carries the oracle's confidence within 1 % relative
+                exact += check_text("V4_en_rec_fast", text, score, probs[k], charset, ref_text, conf)
                 nbox += 1
-    assert nbox >= 2 and exact >= 1
+    print(f"{hw}: {exact} / {nbox} strings identical, the rest reachable through near-ties of the oracle's distribution")
+    # (identical strings on EVERY crop cannot be asked of a random-weight head: a step flips when the oracle's top-2 log-margin is under the
+    # engine's error — ~0.3-0.5 % of the steps — and a 1000-px crop has 125 steps; reachability above is the criterion with teeth)
+    assert nbox >= 2 and exact >= 1, (exact, nbox)
 
 
 def test_blank_and_mixed_frames(ctx):
@@ -269,6 +267,7 @@ def test_text_recognizer_call_site(ctx):
     for i, c in enumerate(crops):
         ref = P.resize_norm_img(c, 640).transpose(1, 2, 0).astype(np.float16)
         assert np.array_equal(pre[i, ..., :3], ref), i
+    from parity import check_text
     rec = net_ref.get_weights("V4_en_rec_fast")
     charset = P.en_charset()
     exact = 0
@@ -277,16 +276,9 @@ def test_text_recognizer_call_site(ctx):
         probs = net_ref.run_graph(rec[0], rec[1], batch)[0].numpy()
         for k, i in enumerate(idx):
             ids, conf = P.ctc_greedy(probs[k])
-            srt = np.sort(probs[k], -1)
-            shaky = int(((srt[:, -1] - srt[:, -2]) < 0.05 * srt[:, -1]).sum())
             text, score = got[i]
-            if text == P.decode_text(ids, charset):
-                exact += 1
-                assert abs(score - conf) < 2e-2          # same kept time steps -> same mean confidence
-            else:
-                import difflib
-                ops = [o for o in difflib.SequenceMatcher(None, text, P.decode_text(ids, charset)).get_opcodes() if o[0] != "equal"]
-                assert len(ops) <= shaky, (text, P.decode_text(ids, charset), shaky)
+            exact += check_text("V4_en_rec_fast", text, score, probs[k], charset, P.decode_text(ids, charset), conf)
+    assert exact >= 1, (exact, len(crops))
     # (the stand-in recogniser's softmax is nearly flat, so an exactly equal string is not guaranteed on a handful of crops:
     # what this call site adds over the net-level parity tests — the crop route above and the grouping — is checked exactly)
     want_groups = [(list(idx), int(w)) for idx, w in P.rec_batches(crops, 3)]

@@ -57,6 +57,73 @@ def test_gather_world2_gloo():
         assert len(boxes) == f % 3 and texts == [(f"t{f}_{k}", np.float32(0.1 * k).item()) for k in range(f % 3)]
 
 
+def _worker_mode(rank, world, port, q, force_rank, force):
+    """One rank only asks for the all_gather form (VSE_GATHER in ITS environment): both ranks must leave gather_mode() with the
+    same answer and the exchange must complete."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("VSE_GATHER", None)
+    if rank == force_rank and force:
+        os.environ["VSE_GATHER"] = force
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mode = parallel.gather_mode()
+    assert parallel.gather_mode() == mode                        # cached: decided once per process group
+    calls = []
+    orig_gather, orig_all = dist.gather, dist.all_gather
+    dist.gather = lambda *a, **k: (calls.append("gather"), orig_gather(*a, **k))[1]
+    dist.all_gather = lambda *a, **k: (calls.append("all_gather"), orig_all(*a, **k))[1]
+    lo, hi = parallel.shard_range(9, rank, world)
+    recs = [(f, np.full((1, 4, 2), f, np.float32), [(f"t{f}", 0.5)]) for f in range(lo, hi)]
+    out = parallel.gather_records(recs)
+    dist.gather, dist.all_gather = orig_gather, orig_all
+    q.put((rank, mode, calls, None if out is None else [r[0] for r in out]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_mode(force_rank, force):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + (7 if force else 0) + 3 * force_rank
+    procs = [ctx.Process(target=_worker_mode, args=(r, 2, port, q, force_rank, force)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))           # a mismatched collective would hang here: the timeout is the test
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_gather_mode_is_agreed_collectively_even_when_one_rank_forces_the_fallback():
+    """gather vs all_gather is chosen once, by all ranks together (all_reduce(MIN) of static votes), never by catching
+    an exception in the middle of the exchange.  Default on gloo: gather (rank 0 alone receives).  The fallback forced on ONE rank
+    only — either one — switches BOTH ranks to all_gather, and the exchange completes (no hang, same records)."""
+    got = _run_mode(0, None)
+    assert [g[1] for g in got] == ["gather", "gather"]
+    assert got[0][2] == ["all_gather", "gather"] and got[1][2] == ["all_gather", "gather"]       # sizes, then the payload
+    assert got[0][3] == list(range(9)) and got[1][3] is None
+    for force_rank in (1, 0):
+        got = _run_mode(force_rank, "all_gather")
+        assert [g[1] for g in got] == ["all_gather", "all_gather"], got
+        assert got[0][2] == ["all_gather", "all_gather"] and got[1][2] == ["all_gather", "all_gather"]
+        assert got[0][3] == list(range(9)) and got[1][3] is None
+
+
+def test_gather_mode_rejects_an_unknown_override(monkeypatch):
+    import pytest
+    import torch.distributed as dist
+    monkeypatch.setenv("VSE_GATHER", "broadcast")
+    assert parallel.gather_mode() == "local"                     # no process group: nothing to decide
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda: 0)
+    monkeypatch.setattr(dist, "get_backend", lambda: "gloo")
+    with pytest.raises(ValueError):
+        parallel.gather_mode()
+
+
 # ---- eight ranks on one node: the HOST side of a step under the per-rank thread cap ---------------------------------------
 def _host_step(pipe, boxes_per_frame, texts, base):
     """What every rank does on the host for one 64-frame batch between the detector's maps and the gather: box ordering,

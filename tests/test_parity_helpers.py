@@ -1,0 +1,58 @@
+"""The string criterion of tests/parity.py (reachable(): is a string producible from the oracle's per-step distribution through
+near-ties only?) on hand-made distributions — CPU, no engine."""
+import numpy as np
+
+from parity import check_rec_probs, reachable
+
+CS = ["blank", "a", "b", "c", " ", " "]
+
+
+def _probs(rows):
+    p = np.asarray(rows, np.float64)
+    return p / p.sum(1, keepdims=True)
+
+
+def test_reachable_follows_ctc_collapse_and_near_ties():
+    clear = _probs([[.9, .02, .02, .02, .02, .02], [.02, .9, .02, .02, .02, .02], [.02, .9, .02, .02, .02, .02], [.9, .02, .02, .02, .02, .02],
+                    [.02, .9, .02, .02, .02, .02], [.02, .02, .02, .9, .02, .02]])
+    assert reachable("aac", clear, CS, 2e-2)                 # a a(repeat) blank a c
+    assert not reachable("ac", clear, CS, 2e-2) and not reachable("aab", clear, CS, 2e-2) and not reachable("aacc", clear, CS, 2e-2)
+    # a near-tie between 'b' and 'c' at the last step (log-margin 1e-2): both strings are reachable, a third one is not
+    tie = clear.copy()
+    tie[5] = _probs([[.02, .02, .45 * np.exp(-1e-2), .45, .02, .02]])[0]
+    assert reachable("aac", tie, CS, 2e-2) and reachable("aab", tie, CS, 2e-2) and not reachable("aaa", tie, CS, 2e-2)
+    assert not reachable("aab", tie, CS, 5e-3)                # the same margin is NOT a tie under a tighter bound
+    # a tie with the blank removes a character; a tie with the previous class merges a repeat
+    tb = clear.copy()
+    tb[4] = _probs([[.45, .45 * np.exp(-5e-3), .02, .02, .02, .02]])[0]
+    assert reachable("aac", tb, CS, 2e-2) and reachable("ac", tb, CS, 2e-2)
+    # two classes with the same character (the two ' ' entries of the en table) collapse by CLASS id, not by character
+    sp = _probs([[.02, .02, .02, .02, .9, .02], [.02, .02, .02, .02, .02, .9]])
+    assert reachable("  ", sp, CS, 2e-2) and not reachable(" ", sp, CS, 2e-2)
+
+
+def test_check_rec_probs_bounds_have_teeth():
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((2, 40, 6625))
+    ref = np.exp(z) / np.exp(z).sum(-1, keepdims=True)
+    ok = np.exp(z + 2e-3 * rng.standard_normal(z.shape))
+    ok /= ok.sum(-1, keepdims=True)
+    st = check_rec_probs("V4_ch_rec", ok, ref)
+    assert st["dlog_max"] < 2e-2
+    for scale in (1.1, 0.9):                                   # every probability moved by 10 %: an absolute 1e-3 bound on a flat softmax
+        bad = ref.copy()                                       # (max-p ~0.004) would pass this; the log bound does not
+        bad[..., :3000] *= scale
+        try:
+            check_rec_probs("V4_ch_rec", bad, ref)
+        except AssertionError:
+            continue
+        raise AssertionError("a 10 % error passed")
+    idx = ref.argmax(-1).copy()
+    srt = np.sort(ref, -1)
+    t = np.unravel_index(np.argmax(srt[..., -1] / srt[..., -2]), idx.shape)      # the clearest step: flip its arg-max
+    idx[t] = (idx[t] + 1) % 6625
+    try:
+        check_rec_probs("V4_ch_rec", ref, ref, idx=idx)
+    except AssertionError:
+        return
+    raise AssertionError("an arg-max flip at a clear step passed")

@@ -226,6 +226,11 @@ class UnsupportedGraph(NotImplementedError):
     """A descriptor uses an attribute value the kernels hard-code differently (would compile and compute wrong values)."""
 
 
+class GatedConvUnsupported(UnsupportedGraph):
+    """A conv rewritten by Compiler._rewrite_se_laterals (F_OGATE) met a layer form its epilogue cannot express: compile_model
+    retries the graph WITHOUT that rewrite (the rewrite itself cannot be undone on a half-lowered graph)."""
+
+
 # Attribute values the lowering hard-codes (every graph under backend/models/ satisfies them, SURVEY App. E).  A descriptor
 # converted from another export (SAME padding, dilated convs, align_corners resize ...) must fail here, loudly, instead of
 # compiling into something that silently computes different values.  A missing attribute means the Paddle default.
@@ -263,7 +268,7 @@ def check_attrs(ops):
 
 class Compiler(ChainMixin):
     def __init__(self, desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True,
-                 store=None, reuse=True):
+                 store=None, reuse=True, se_lateral=None):
         self.desc = desc
         self.W = dict(weights)
         self.ops = list(desc["ops"])
@@ -280,7 +285,7 @@ class Compiler(ChainMixin):
         self.input_norm = None                # (mean3, std3): see fold_input_norm
         self.fuse_preprocess = False          # with input_norm: the stem conv reads the uint8 frames and resizes them itself (F_U8SRC)
         self._merge_parallel_convs()
-        if SE_LATERAL:
+        if SE_LATERAL if se_lateral is None else se_lateral:
             self._rewrite_se_laterals()
         self.N, self.H, self.Wd = batch, height, width
         self.fetch_cols = tuple(fetch_cols)
@@ -1371,10 +1376,15 @@ class Compiler(ChainMixin):
         if a.get("out_gate") is not None:
             # an SE block with shortcut folded into this 1x1 conv (_rewrite_se_laterals): out = conv * (1 + gate[n, c]) (+ residual)
             gv = self.resolve(a["out_gate"])
-            if (gv is None or (gv.h, gv.w) != (1, 1) or gv.c != cout or gv.segs != [(0, cout)] or gv.up or dot is not None
+            # The kernel evaluates (acc + bias) * (1 + gate) + residual.  The rewritten conv's output IS the SE block's output, so every
+            # affine / activation absorb_epilogue folded lies BEHIND the gate in the graph: (conv * (1 + g)) * s + b — which is not
+            # (conv * s + b) * (1 + g).  Only the identity (and the residual add) may ride in this epilogue.
+            affine_id = bool(np.all(ep["scale"] == 1.0) and not np.any(ep["shift"]) and ep["post_a"] == 1.0 and ep["post_b"] == 0.0)
+            if (gv is None or (gv.h, gv.w) != (1, 1) or gv.c != cout or gv.segs != [(0, cout)] or gv.up or dot is not None or not affine_id
                     or flags & (ir.F_SRC2 | ir.F_IMGW | ir.F_PATCH | ir.F_COL | ir.F_STEM) or ep["act"] != ir.ACT_NONE or ep["act2"] != ir.ACT_NONE):
-                raise UnsupportedGraph(f"gated conv {outname}: the gate / layer form is not supported (gate {gv and (gv.h, gv.w, gv.c, gv.segs, gv.up)}, "
-                                       f"flags {flags:#x}, act {ep['act']}/{ep['act2']}, dot {dot is not None})")
+                raise GatedConvUnsupported(f"gated conv {outname}: the gate / layer form is not supported (gate {gv and (gv.h, gv.w, gv.c, gv.segs, gv.up)}, "
+                                           f"flags {flags:#x}, act {ep['act']}/{ep['act2']}, identity affine behind the gate: {affine_id}, "
+                                           f"dot {dot is not None})")
             flags |= ir.F_OGATE
             while len(ins) < 2:
                 ins.append(None)
@@ -2157,13 +2167,21 @@ def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_pro
     twice the MFMA work — for nets whose boxes must track an fp32 reference closely.
     ragged=True (recognisers): `width` is the widest sample of the batch; the plan runs with a per-sample width table
     (Program.width_table) and every sample gets the values a batch of its own width would have produced, bit for bit."""
-    c = Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse)
-    c.ragged = bool(ragged)
-    c.hilo = bool(hilo)
-    c.input_norm = input_norm      # (mean3, std3): the plan takes RAW resized pixels + a ones channel (Compiler.fold_input_norm)
-    c.fuse_preprocess = bool(fuse_preprocess)    # ... and resizes them itself from the uint8 frames (F_U8SRC): the plan input IS the frames
-    c.chain = bool(hilo) if chain is None else bool(chain)      # 1x1 / depthwise chains as OP_CHAIN (chains.py): the hi + lo nets (mobile detectors)
-    c.chain_lo = os.environ.get("VSE_CHAIN_LO", "1") != "0"     # tensors that feed a chain are stored as fp16 hi + lo pairs
-    if c.hilo:
-        c.use_patch = False          # conv_patch_kernel has no two-pass K walk (the implicit-GEMM, stem and column kernels do)
-    return c.compile()
+    def build(se_lateral):
+        c = Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse, se_lateral=se_lateral)
+        c.ragged = bool(ragged)
+        c.hilo = bool(hilo)
+        c.input_norm = input_norm      # (mean3, std3): the plan takes RAW resized pixels + a ones channel (Compiler.fold_input_norm)
+        c.fuse_preprocess = bool(fuse_preprocess)    # ... and resizes them itself from the uint8 frames (F_U8SRC): the plan input IS the frames
+        c.chain = bool(hilo) if chain is None else bool(chain)      # 1x1 / depthwise chains as OP_CHAIN (chains.py): the hi + lo nets (mobile detectors)
+        c.chain_lo = os.environ.get("VSE_CHAIN_LO", "1") != "0"     # tensors that feed a chain are stored as fp16 hi + lo pairs
+        if c.hilo:
+            c.use_patch = False          # conv_patch_kernel has no two-pass K walk (the implicit-GEMM, stem and column kernels do)
+        return c.compile()
+    try:
+        return build(None)
+    except GatedConvUnsupported:
+        # _rewrite_se_laterals turned a 1x1 conv + SE block into a gated conv whose surroundings the epilogue cannot express (an affine or
+        # an activation behind the SE add, a gate shape, a kernel family): the graph compiled before that rewrite existed — compile it
+        # without the rewrite instead of refusing it
+        return build(False)

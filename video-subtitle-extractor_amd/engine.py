@@ -146,6 +146,47 @@ class Context:
     def stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
 
+    # ---- streams ----------------------------------------------------------------------------------------
+    def streams_concurrent(self, a, b, spin_cycles=1_500_000):
+        """Do streams a and b really run side by side?  torch hands streams out of a round-robin pool of 32 per priority and the HIP
+        runtime multiplexes them over a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default; a queue is bound at a stream's
+        FIRST use): two streams on one hardware queue execute in order whatever the program says.  Measured: a short kernel on b is
+        launched behind a long spin on a; concurrent = it finishes while the spin still runs."""
+        t = self.torch
+        x = self.__dict__.setdefault("_probe_buf", t.zeros(64, device=self.tdev))
+        for s in (a, b):                       # bind both streams to their hardware queues first (a first use costs milliseconds)
+            with t.cuda.stream(s):
+                x.add_(1)
+        t.cuda.synchronize(self.tdev)
+        a0, a1, b1 = (t.cuda.Event(enable_timing=True) for _ in range(3))
+        with t.cuda.stream(a):
+            a0.record()
+            t.cuda._sleep(spin_cycles)
+            a1.record()
+        with t.cuda.stream(b):
+            x.add_(1)
+            b1.record()
+        t.cuda.synchronize(self.tdev)
+        return a0.elapsed_time(b1) < 0.5 * a0.elapsed_time(a1)
+
+    def side_streams(self, n, priority=0, tries=24):
+        """n streams of the given priority that run concurrently with each other AND with the current stream (verified by
+        streams_concurrent), cached per (device, priority): every pipeline of the process gets the same ones."""
+        t = self.torch
+        cache = self.__dict__.setdefault("_side_streams", {})
+        have = cache.setdefault(priority, [])
+        main = t.cuda.current_stream(self.tdev)
+        while len(have) < n and tries > 0:
+            tries -= 1
+            s = t.cuda.Stream(device=self.tdev, priority=priority)
+            if any(s.cuda_stream == h.cuda_stream for h in have):
+                continue
+            if self.streams_concurrent(main, s) and all(self.streams_concurrent(h, s) for h in have):
+                have.append(s)
+        if len(have) < n:
+            raise VseError(f"no {n} mutually concurrent HIP streams of priority {priority} on this device (found {len(have)})")
+        return have[:n]
+
     def close(self):
         if self.handle:
             self.lib.vse_destroy(self.handle)

@@ -5,6 +5,7 @@ contiguous ranges, one per rank (one process per GPU), with NO collective on the
 step is the final variable-length gather of per-frame records (boxes, scores, text) to rank 0:
 an all_gather of byte counts (8 B per rank: every rank needs the padded size) followed by a gather of one padded uint8
 tensor to rank 0 (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).  ~100 B/frame: latency-bound, so it is done once per job/chunk.
+Whether the backend's `gather` or the `all_gather` form is used is agreed by all ranks once, at start-up (gather_mode).
 """
 import os
 import struct
@@ -83,15 +84,58 @@ def unpack_records(buf):
     return recs
 
 
+_GATHER_MODE = {}          # (backend, world, rank, id of the default process group) -> "gather" | "all_gather"
+
+
+def gather_mode(device=None):
+    """How the record exchange reaches rank 0 — `dist.gather` (the other ranks receive nothing) or `dist.all_gather` (every rank
+    receives world x the payload and drops it) — decided ONCE per process group, COLLECTIVELY, before any timed region:
+    every rank votes from static knowledge only (the backend's name; VSE_GATHER=gather|all_gather overrides a rank's vote), the
+    votes are combined with all_reduce(MIN) — a collective every backend has — so all ranks leave with the same answer even when
+    only one of them asked for the fallback.  When the answer is "gather" the ranks then run one 8-byte gather as a start-up
+    check; an error there PROPAGATES (with the remedy in its message).  Nothing is ever decided by catching an exception in the
+    middle of the exchange: a rank-local failure there would leave the ranks in different collectives (VERDICT r4 #7)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return "local"
+    backend, world, rank = dist.get_backend(), dist.get_world_size(), dist.get_rank()
+    key = (backend, world, rank, id(dist.group.WORLD))
+    if key in _GATHER_MODE:
+        return _GATHER_MODE[key]
+    dev = device if device is not None else ("cuda" if backend == "nccl" else "cpu")
+    want = os.environ.get("VSE_GATHER", "").strip().lower()
+    if want not in ("", "gather", "all_gather"):
+        raise ValueError(f"VSE_GATHER={want!r}: expected 'gather' or 'all_gather'")
+    vote = 0 if want == "all_gather" else (1 if want == "gather" or backend in ("nccl", "gloo") else 0)
+    v = torch.tensor([vote], dtype=torch.int32, device=dev)
+    dist.all_reduce(v, op=dist.ReduceOp.MIN)
+    mode = "gather" if int(v.item()) == 1 else "all_gather"
+    if mode == "gather":
+        probe = torch.full((8,), rank, dtype=torch.uint8, device=dev)
+        got = [torch.zeros(8, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+        try:
+            dist.gather(probe, got, dst=0)
+        except Exception as exc:
+            raise RuntimeError(f"the start-up probe of dist.gather failed on rank {rank} (backend {backend}): set VSE_GATHER=all_gather on "
+                               f"every rank to use the all_gather form of the record exchange") from exc
+        if rank == 0:
+            assert [int(g[0].item()) for g in got] == list(range(world)), "gather probe returned the wrong ranks' bytes"
+    _GATHER_MODE[key] = mode
+    return mode
+
+
 def gather_records(records, device=None, to_all=False):
     """All ranks call; rank 0 gets the concatenation ordered by frame number, other ranks get None (to_all=True: every
-    rank gets it through an all_gather instead of the gather).  Works without torch.distributed initialised (single process)."""
+    rank gets it through an all_gather instead of the gather).  Works without torch.distributed initialised (single process).
+    gather vs all_gather: gather_mode() (decided once per process group; call it before a timed region — bench.py does)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return sorted(records, key=lambda r: r[0])
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    mode = "all_gather" if to_all else gather_mode(dev)
     payload = pack_records(records)
     size = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
@@ -99,22 +143,14 @@ def gather_records(records, device=None, to_all=False):
     mx = int(max(int(s.item()) for s in sizes))
     buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
     buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    if to_all:
+    if mode == "all_gather":
         bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
         dist.all_gather(bufs, buf)
     else:
         # north_star: "RCCL ... only for the final box/text gather" — a gather to rank 0: the other ranks send their padded
-        # buffer once and receive nothing (an all_gather would deliver world x the payload to ranks that drop it)
+        # buffer once and receive nothing (an all_gather would deliver world x the payload to ranks that drop it).  Errors propagate.
         bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
-        try:
-            dist.gather(buf, bufs, dst=0)
-        except (NotImplementedError, RuntimeError) as exc:
-            # a backend build without gather refuses on every rank alike (no rank is left waiting): the all_gather is the same
-            # exchange with world x the receive volume
-            if "gather" not in str(exc).lower() and not isinstance(exc, NotImplementedError):
-                raise
-            bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
-            dist.all_gather(bufs, buf)
+        dist.gather(buf, bufs, dst=0)
     if rank != 0 and not to_all:
         return None
     out = []

@@ -311,8 +311,9 @@ class OcrPipeline:
         main = t.cuda.current_stream(self.ctx.tdev)
         if nstreams > 1:
             if len(getattr(self, "_streams", [])) < nstreams:
-                self._streams = [t.cuda.Stream(device=self.ctx.tdev, priority=getattr(self, "rec_stream_priority", -1))
-                                 for _ in range(nstreams)]
+                # streams VERIFIED to run beside each other and beside the main stream, shared by every pipeline of the context
+                # (engine.Context.side_streams: torch's pool streams may alias one hardware queue and then execute in order)
+                self._streams = self.ctx.side_streams(nstreams, priority=getattr(self, "rec_stream_priority", -1))
             for st in self._streams[:nstreams]:
                 st.wait_stream(main)
         try:
@@ -386,7 +387,7 @@ class OcrPipeline:
         depth = max(1, int(depth))
         rec_span = max(1, int(rec_span)) if self.rec_mode == "ragged" else 1
         if len(getattr(self, "_det_streams", [])) < depth:
-            self._det_streams = [t.cuda.Stream(device=self.ctx.tdev) for _ in range(depth)]
+            self._det_streams = self.ctx.side_streams(depth)      # verified concurrent with each other and with the main stream
         main = t.cuda.current_stream(self.ctx.tdev)
         queue, ready = [], []
 
@@ -427,7 +428,7 @@ class OcrPipeline:
         t = self.ctx.torch
         depth = max(1, int(depth))
         if len(getattr(self, "_det_streams", [])) < depth:
-            self._det_streams = [t.cuda.Stream(device=self.ctx.tdev) for _ in range(depth)]
+            self._det_streams = self.ctx.side_streams(depth)      # verified concurrent with each other and with the main stream
         main = t.cuda.current_stream(self.ctx.tdev)
         queue = []
 
