@@ -268,7 +268,9 @@ def test_text_recognizer_call_site(ctx):
         ref = P.resize_norm_img(c, 640).transpose(1, 2, 0).astype(np.float16)
         assert np.array_equal(pre[i, ..., :3], ref), i
     from parity import check_text
-    rec = net_ref.get_weights("V4_en_rec_fast")
+    # the oracle runs the weights THE CALL SITE loaded (shim._load_model: the seeded stand-ins of modelzoo, not net_ref's calibrated
+    # ones — until round 5 this test compared the two under a criterion loose enough not to notice)
+    rec = shim._load_model("V4_en_rec_fast")
     charset = P.en_charset()
     exact = 0
     for idx, img_w in P.rec_batches(crops, 3):

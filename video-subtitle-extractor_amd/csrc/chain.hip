@@ -618,20 +618,14 @@ int launch_chain(const vse_op& o, const TView& in0, const TView& out, const TVie
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_INVAL;
     const int lds_bytes = o.p[2];
     if (lds_bytes > 158 * 1024) return VSE_E_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) != hipSuccess)      // (+ 1.6 KiB of static LDS: the descriptor)
-            return VSE_E_HIP;
-        attr_set = true;
-    }
+    static VseDevOnce attr_once;          // (per device, thread-safe: common.h)
+    if (!vse_dev_once(attr_once, [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024) == hipSuccess;      // (+ 1.6 KiB of static LDS: the descriptor)
+        }))
+        return VSE_E_HIP;
     // persistent grid: as many blocks as the chip holds at this LDS size (160 VGPRs: three 4-wave blocks per CU at most), a multiple of 8
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return VSE_E_HIP;
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = vse_cu_count();
+    if (!n_cu) return VSE_E_HIP;
     const int per_cu = std::max(1, std::min(VSE_CHAIN_LB, (160 * 1024) / (lds_bytes + 2048)));
     unsigned grid = (unsigned)std::min<unsigned long long>(blocks, (unsigned long long)n_cu * per_cu);
     if (grid > 8) grid &= ~7u;

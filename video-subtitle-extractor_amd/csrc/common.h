@@ -89,6 +89,37 @@ __device__ __forceinline__ void vse_fma_h8(float (&acc)[8], const half8& x, cons
     acc[7] = vse_fma_mix_hi(u[3], w1[3], acc[7]);
 }
 
+// Per-device launch state (a raised dynamic-LDS limit, the CU count): hipFuncSetAttribute acts on the CURRENT device and a process may
+// hold contexts on several devices and launch from several host threads, so "done once" is kept per device id, under a mutex.
+#include <mutex>
+struct VseDevOnce {
+    std::mutex m;
+    unsigned long long done = 0;          // bit d: device d is set up (<= 64 devices per process)
+};
+template <class F>
+static inline bool vse_dev_once(VseDevOnce& s, F&& setup) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return false;
+    std::lock_guard<std::mutex> g(s.m);
+    if ((s.done >> dev) & 1ull) return true;
+    if (!setup()) return false;
+    s.done |= 1ull << dev;
+    return true;
+}
+static inline int vse_cu_count() {         // compute units of the current device (0 on error)
+    static std::mutex m;
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 0;
+    std::lock_guard<std::mutex> g(m);
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cus[dev] = prop.multiProcessorCount;
+    }
+    return cus[dev];
+}
+
 // XCD-aware block order for STREAMING kernels whose neighbouring outputs share input rows (depthwise / pooling windows, up-sampling
 // copies): the dispatcher places block b on XCD b % 8 and every XCD has a private L2, so with the plain order the blocks of
 // vertically adjacent rows land on different XCDs and every input row is fetched from memory once per XCD that needs it (counters,

@@ -182,12 +182,11 @@ template <int KS, int K, bool LO>
 static int launch_dwpw_t(const ConvParams& p, hipStream_t st) {
     const int ntile = (p.Np + 31) >> 5;
     const size_t lds = (size_t)2 * ntile * 32 * (KS * 16 + 8) * 2 + (size_t)(K * K + 1) * KS * 16 * 4 + (size_t)ntile * 32 * 4;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dwpw_kernel<KS, K, LO>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
-            return VSE_E_HIP;
-        attr = true;
-    }
+    static VseDevOnce attr_once;          // (per device, thread-safe: common.h)
+    if (!vse_dev_once(attr_once, [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dwpw_kernel<KS, K, LO>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+        }))
+        return VSE_E_HIP;
     const unsigned long long blocks = (unsigned long long)((p.M + 255) / 256);
     if (blocks == 0 || p.M >= 0x7fffffffl || lds > 128 * 1024) return VSE_E_INVAL;          // (32-bit pixel arithmetic: conv_pix_coords)
 #ifdef VSE_DEV_BUILD
