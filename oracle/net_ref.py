@@ -74,13 +74,16 @@ def synth_weights(desc, seed=0):
             for w in op["in"]["WeightList"]:
                 role[w] = "lstm"
         elif t in ("elementwise_add", "elementwise_mul"):
-            y = op["in"]["Y"][0]
-            if y in desc["params"] and y not in role:
-                n = int(np.prod(desc["params"][y]["dims"]))
-                if n == 1:
-                    role[y] = "lab_scale" if t == "elementwise_mul" else "lab_bias"
-                else:
-                    role[y] = "bias"
+            # (the parameter is X in the PP-LCNetV3 "learnable affine" multiplies, Y everywhere else: until round 5 only Y was looked
+            # at, the LAB scales fell to the default N(0, 0.05) and every LCNetV3 stand-in multiplied its signal by ~0.05 twice per
+            # unit — after a dozen units the net was a CONSTANT function of its input)
+            for y in (op["in"]["Y"][0], op["in"]["X"][0]):
+                if y in desc["params"] and y not in role:
+                    n = int(np.prod(desc["params"][y]["dims"]))
+                    if n == 1:
+                        role[y] = "lab_scale" if t == "elementwise_mul" else "lab_bias"
+                    else:
+                        role[y] = "bias"
     out = {}
     for name in sorted(desc["params"]):
         dims = desc["params"][name]["dims"]
@@ -120,10 +123,40 @@ def synth_weights(desc, seed=0):
 _CALIB_SHAPES = {"det": (1, 3, 96, 160), "rec": (2, 3, 48, 160), "rec32": (2, 3, 32, 160)}
 
 
+_CALIB_MIN_SAMPLES = 16        # per-channel statistics need this many values per channel (the SE convs see one pixel per image)
+# Where a channel sits relative to its activation after the calibration pass: centred (batch mean removed) and then SHIFTED up by one
+# standard deviation of its input-dependent part.  Measured on the stand-ins (tools/standin_study.py): without the shift every
+# conv -> centre -> ReLU unit amplifies a perturbation by ~1.2 (the chaotic regime of batch-normalised random nets): fp16 WEIGHT rounding
+# alone moved the recognisers' log-probabilities by 0.4-0.8; one sigma up (84 % of the units on the linear side of the ReLU) the same
+# nets still answer different inputs differently (median |delta log p| between two inputs ~1.2) and weight rounding moves them by
+# 6-8e-2 at most, 6-9e-3 in the median; two sigma starts to flatten them again.
+_CALIB_CENTER = float(os.environ.get("VSE_CALIB_CENTER", "1.0"))
+_CALIB_SHIFT = float(os.environ.get("VSE_CALIB_SHIFT", "1.0"))
+
+
+def _calib_scale(y, ch_dim):
+    """Per-OUTPUT-CHANNEL divisor of a conv / linear layer in the calibration pass: the standard deviation of the channel around
+    ITS OWN mean over batch and positions — the part of the activation that depends on the input.  (Round 1-4 divided by the
+    std over all elements, which per-channel offsets dominate: the input-dependent part shrank layer by layer until the deep
+    stand-in nets answered every input alike.)  Channels with (almost) no variation, and layers with fewer than
+    _CALIB_MIN_SAMPLES values per channel, fall back to the layer-wide figure."""
+    n = y.shape[ch_dim]
+    allsd = float(y.std()) if y.numel() > 1 else 1.0
+    allsd = allsd if allsd > 0 else 1.0
+    if y.numel() // n < _CALIB_MIN_SAMPLES:
+        return torch.full((n,), allsd)
+    red = [d for d in range(y.dim()) if d != ch_dim]
+    sd = y.std(red, unbiased=False)
+    floor = 0.1 * float(sd.median()) if float(sd.median()) > 0 else allsd
+    return torch.where(sd > floor, sd, torch.full_like(sd, max(floor, 1e-12)))
+
+
 def calibrate(desc, weights, seed=0):
-    """LSUV-style data-dependent rescale of the synthetic weights: one forward pass on a fixed seeded input,
-    each conv / linear weight divided by the std of its own output so every layer emits O(1) activations and
-    the head is not saturated.  Deterministic given (descriptor, seed); cheap (one tiny forward)."""
+    """Data-dependent rescale of the synthetic weights (LSUV-style, per channel): one forward pass on a fixed seeded input; every conv /
+    linear output channel is divided by the standard deviation of ITS input-dependent part (_calib_scale), batch-norm statistics become
+    the pass's batch statistics (with the seeded spread), per-channel biases behind convs centre their channel — every layer emits O(1)
+    activations that still DEPEND ON THE INPUT (tests/test_oracle_crosschecks.py checks that: two inputs, different outputs), and the
+    head is not saturated.  Deterministic given (descriptor, seed); cheap (one tiny forward)."""
     mid = desc["model"]
     kind = "det" if "_det" in mid else ("rec32" if mid.startswith("V2_") else "rec")
     x = np.random.default_rng(1000 + seed).uniform(-1, 1, _CALIB_SHAPES[kind]).astype(np.float32)
@@ -224,10 +257,10 @@ def run_graph(desc, weights, x, return_all=False, _calibrate=False):
                 y = F.conv2d(I["Input"][0], I["Filter"][0], None, tuple(a["strides"]), _pad2(a["paddings"]),
                              tuple(a.get("dilations", [1, 1])), a.get("groups", 1))
                 if _calibrate:
-                    sd = float(y.std())
-                    if sd > 0:
-                        weights[op["in"]["Filter"][0]] = (weights[op["in"]["Filter"][0]] / sd).astype(np.float32)
-                        y = y / sd
+                    fn = op["in"]["Filter"][0]
+                    sd = _calib_scale(y, 1)
+                    weights[fn] = (weights[fn] / sd.numpy().reshape(-1, 1, 1, 1)).astype(np.float32)
+                    y = y / sd.reshape(1, -1, 1, 1)
                 env[op["out"]["Output"][0]] = y
             elif t == "conv2d_transpose":
                 y = F.conv_transpose2d(I["Input"][0], I["Filter"][0], None, tuple(a["strides"]),
@@ -236,6 +269,15 @@ def run_graph(desc, weights, x, return_all=False, _calibrate=False):
             elif t == "batch_norm":
                 xx = I["X"][0]
                 sh = [1, -1] + [1] * (xx.dim() - 2)
+                if _calibrate and xx.numel() // xx.shape[1] >= _CALIB_MIN_SAMPLES:
+                    # running statistics as a trained net would hold them: the batch statistics of the calibration pass, with the
+                    # seeded spread of the synthetic ones (mean + 0.1 N(0, 1) sigma, variance x U(0.5, 1.5)) so that folding is exercised
+                    red = [d for d in range(xx.dim()) if d != 1]
+                    m, v = xx.mean(red), xx.var(red, unbiased=False).clamp_min(1e-6)
+                    mn, vn = op["in"]["Mean"][0], op["in"]["Variance"][0]
+                    weights[mn] = (_CALIB_CENTER * m + (torch.from_numpy(weights[mn]) - _CALIB_SHIFT) * v.sqrt()).numpy().astype(np.float32)
+                    weights[vn] = (v * torch.from_numpy(weights[vn])).numpy().astype(np.float32)
+                    I["Mean"][0], I["Variance"][0] = torch.from_numpy(weights[mn]), torch.from_numpy(weights[vn])
                 y = (xx - I["Mean"][0].reshape(sh)) / torch.sqrt(I["Variance"][0].reshape(sh) + a["epsilon"])
                 y = y * I["Scale"][0].reshape(sh) + I["Bias"][0].reshape(sh)
                 env[op["out"]["Y"][0]] = y
@@ -268,6 +310,14 @@ def run_graph(desc, weights, x, return_all=False, _calibrate=False):
                 env[op["out"]["Out"][0]] = xx * torch.sigmoid(a.get("beta", 1.0) * xx)
             elif t == "elementwise_add":
                 xx, yy = I["X"][0], I["Y"][0]
+                yn = op["in"]["Y"][0]
+                if (_calibrate and yn in weights and xx.dim() == 4 and yy.dim() == 1 and yy.numel() == xx.shape[1] > 1
+                        and a.get("axis", -1) == 1 and xx.numel() // xx.shape[1] >= _CALIB_MIN_SAMPLES):
+                    # a per-channel bias behind a conv (the re-parameterised nets have no batch norm): centre the channel like the BN it
+                    # stands for would have, keep the seeded bias as the spread around it
+                    weights[yn] = (torch.from_numpy(weights[yn]) - _CALIB_CENTER * xx.mean((0, 2, 3))
+                                   + _CALIB_SHIFT * xx.std((0, 2, 3), unbiased=False)).numpy().astype(np.float32)
+                    yy = torch.from_numpy(weights[yn])
                 env[op["out"]["Out"][0]] = xx + _bcast(xx, yy, a.get("axis", -1))
             elif t == "elementwise_mul":
                 xx, yy = I["X"][0], I["Y"][0]
@@ -299,10 +349,9 @@ def run_graph(desc, weights, x, return_all=False, _calibrate=False):
                 y = torch.matmul(xx, yy)
                 yn = op["in"]["Y"][0]
                 if _calibrate and yn in weights:
-                    sd = float(y.std())
-                    if sd > 0:
-                        weights[yn] = (weights[yn] / sd).astype(np.float32)
-                        y = y / sd
+                    sd = _calib_scale(y, y.dim() - 1)
+                    weights[yn] = (weights[yn] / sd.numpy().reshape(1, -1)).astype(np.float32)
+                    y = y / sd
                 env[op["out"]["Out"][0]] = y
             elif t == "matmul":
                 xx, yy = I["X"][0], I["Y"][0]

@@ -1,28 +1,37 @@
 """Recogniser parity bounds shared by the GPU tests and __graft_entry__.smoke(): what the engine is held to against the
 fp32 oracle, in the units north_star states ("recogniser logits within 1e-3 fp16") — LOG-probabilities, not absolute softmax values.
 
-With stand-in weights the class softmax is nearly flat (6625 classes, median max-p ~0.004), so an absolute bound on p says nothing; the
-log-probability of EVERY class is what carries the logits' error (delta log p_c = delta z_c - delta logsumexp).  Measured on MI355X
-(tools/rec_margin_study.py, round 5): V4 / V2 models max |delta log p| 1.0e-3 .. 9.1e-3 over all classes (median 1e-3), per-step max
-probability within 0.36 % relative; the V3 stand-ins (|logit| up to 14, ill-conditioned: fp16 WEIGHTS alone move them) 3.9e-2 .. 8.6e-2
-over all classes, 3.0e-2 on the oracle's top-5, max probability within 2.1 %; arg-max flips only at oracle top-2 log-margins <= 1e-3
-(V4) / 3e-3 (V3).  The bounds below are 2-2.5 x those figures (the `tie` margins 15-20 x the largest margin a flip was seen at).
+An absolute bound on a 6625-class softmax says nothing (its largest value is a few per cent); the log-probability of EVERY class is what
+carries the logits' error (delta log p_c = delta z_c - delta logsumexp).
 
-Strings: a random-weight head puts ~7 % of the time steps within 2e-2 of a top-2 tie, so "identical strings" cannot hold on every crop; what
-CAN be held exactly is that the engine's string is REACHABLE from the oracle's per-step distribution by choosing, at every step, a class
-whose oracle log-probability is within `tie` of the step's maximum (reachable(): dynamic programme over the CTC collapse).  A wrong
-character anywhere outside a near-tie fails; the share of exactly identical strings is asserted and printed beside it.
+What the stand-in weights allow (round 5).  Until round 5 the seeded stand-ins of oracle/net_ref.py were (nearly) CONSTANT functions of
+their input — the PP-LCNetV3 "learnable affine" scales were drawn as N(0, 0.05) and layer-wide LSUV scaling let per-channel offsets swamp
+the input-dependent part — so every bound measured on them (|delta log p| ~1e-3 .. 9e-3) was a bound on bias propagation.  They are now
+calibrated per channel, centred and shifted one sigma into the ReLU's linear side (net_ref.calibrate, tools/standin_study.py): ALIVE (two
+inputs differ by a median |delta log p| of ~1.2) and not chaotic.  On such nets rounding the WEIGHTS to fp16 alone (fp32 activations, CPU)
+already moves the log-probabilities by 4-8e-2 at most and 5-9e-3 in the median; the engine (fp16 weights AND fp16 activation storage)
+measures on MI355X (tools/rec_margin_study.py): V4 / V3 models max |delta log p| 5.1e-2 .. 1.05e-1 over all classes, median 6.9e-3 ..
+1.2e-2, 2.6e-2 .. 7.3e-2 on the oracle's top-5, per-step max probability within 2.5 .. 5.5 %; arg-max flips at oracle top-2 log-margins
+up to 4e-2; the BiLSTM CRNN (V2) 1.4e-3 / 1.6e-4 / 6e-4 / 0.06 %.  north_star's 1e-3 is out of reach of ANY fp16-weight evaluation of
+these random nets (trained weights are far better conditioned: the real-weight detector's map moves by ~1e-3); the bounds below are ~2.5 x
+the measured figures, the MEDIAN bound being the one a precision regression trips first.
+
+Strings: ~5-10 % of a random head's time steps lie within `tie` of a top-2 tie, so "identical strings" cannot hold on every crop; what CAN
+be held exactly is that the engine's string is REACHABLE from the oracle's per-step distribution by choosing, at every step, a class whose
+oracle log-probability is within `tie` of the step's maximum (reachable(): dynamic programme over the CTC collapse).  A wrong character
+anywhere outside a near-tie fails; the share of exactly identical strings is printed beside it.
 """
 import numpy as np
 
-# dlog: |delta log p| over all classes with oracle p > 1e-12; dlog_top: over the oracle's top-5 classes of a step; maxp_rel: relative
-# error of a step's largest probability (what the CTC confidence averages); tie: oracle log-margin under which a step's arg-max may flip
-TOL = {"default": dict(dlog=2e-2, dlog_top=1.5e-2, maxp_rel=1e-2, tie=2e-2),
-       "V3": dict(dlog=2e-1, dlog_top=8e-2, maxp_rel=5e-2, tie=5e-2)}
+# dlog: |delta log p| over all classes with oracle p > 1e-12 (dlog_median: its median); dlog_top: over the oracle's top-5 classes of a
+# step; maxp_rel: relative error of a step's largest probability (what the CTC confidence averages); tie: oracle log-margin under which
+# a step's arg-max may flip
+TOL = {"default": dict(dlog=2.5e-1, dlog_median=3e-2, dlog_top=1.5e-1, maxp_rel=1.2e-1, tie=1e-1),
+       "V2": dict(dlog=5e-3, dlog_median=6e-4, dlog_top=3e-3, maxp_rel=3e-3, tie=5e-3)}
 
 
 def tol_for(mid):
-    return TOL["V3" if mid.startswith("V3_") else "default"]
+    return TOL["V2" if mid.startswith("V2_") else "default"]
 
 
 def check_rec_probs(mid, probs, ref, idx=None, maxp=None):
@@ -42,9 +51,10 @@ def check_rec_probs(mid, probs, ref, idx=None, maxp=None):
     stats = {"dlog_max": float(dl[live].max()), "dlog_median": float(np.median(dl[live])), "dlog_top_max": float(dl_top.max()),
              "maxp_rel_max": float(rel.max()), "tie_steps": float((gap < tol["tie"]).mean())}
     assert stats["dlog_max"] <= tol["dlog"], (mid, stats)
+    assert stats["dlog_median"] <= tol["dlog_median"], (mid, stats)
     assert stats["dlog_top_max"] <= tol["dlog_top"], (mid, stats)
     assert stats["maxp_rel_max"] <= tol["maxp_rel"], (mid, stats)
-    assert stats["tie_steps"] < 0.5, (mid, stats)                      # the arg-max check below must cover most steps
+    assert stats["tie_steps"] < 0.6, (mid, stats)                      # the arg-max check below must cover the steps
     if idx is not None:
         clear = gap >= tol["tie"]
         assert np.array_equal(np.asarray(idx)[clear], ref.argmax(-1)[clear]), (mid, "arg-max differs outside a near-tie")

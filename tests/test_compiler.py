@@ -26,12 +26,10 @@ def test_program_matches_oracle(mid, shape):
             assert r.max() - r.min() > 0.2, "synthetic det head must not be saturated"
         assert np.abs(got - r).max() < 5e-3
     else:
-        got = out[0][:, 0]
-        assert np.abs(got - ref).max() < 1e-3          # north_star tolerance on recogniser outputs (fp16 weights)
-        idx = out[-1].view(np.int32)[:, 0, :, 0]
-        srt = np.sort(ref, -1)
-        clear = (srt[..., -1] - srt[..., -2]) > 0.05 * srt[..., -1]      # only where the oracle's top-1 is clear
-        assert np.array_equal(idx[clear], ref.argmax(-1)[clear])
+        # fp16 WEIGHTS, fp32 activations (the emulator's default) against the fp32 interpreter: log-probabilities of every class, max
+        # probability, arg-max outside near-ties — the bounds of tests/parity.py (the engine adds fp16 activation storage on top)
+        from parity import check_rec_probs
+        check_rec_probs(mid, out[0][:, 0], ref, idx=out[-1].view(np.int32)[:, 0, :, 0])
     assert len(prog.ops) < 0.5 * len(desc["ops"])        # fusion actually happened
     assert all(int(o["kind"]) in range(ir.OP_CONV, ir.OP_WSCALE + 1) for o in prog.ops)
 
@@ -306,6 +304,7 @@ def test_ragged_plan_gives_every_sample_its_own_width(mid, h, widths):
     """compile_model(ragged=True): samples of different widths share one batch tensor, and each receives what the oracle
     computes for a batch of exactly its width (paddleocr pads a chunk of <= 6 crops of ONE frame to the chunk's widest crop,
     backend/tools/ocr.py:99 + backend/config.py:58; the padded width, not the neighbours, is what a crop's logits depend on)."""
+    from parity import check_rec_probs
     desc, w = net_ref.get_weights(mid)
     rng = np.random.default_rng(3)
     wmax = max(widths) + 9                                  # the tensor may be wider than every sample
@@ -322,10 +321,7 @@ def test_ragged_plan_gives_every_sample_its_own_width(mid, h, widths):
         ref = net_ref.run_graph(desc, w, x[n:n + 1, :, :, :wn])[0].numpy()[0]        # [T_n, classes]
         tn = int(tab[prog.out_level][n])
         assert ref.shape[0] == tn
-        assert np.abs(probs[n, :tn] - ref).max() < 1e-3
-        srt = np.sort(ref, -1)
-        clear = (srt[..., -1] - srt[..., -2]) > 0.05 * srt[..., -1]
-        assert np.array_equal(idx[n, :tn][clear], ref.argmax(-1)[clear])
+        check_rec_probs(mid, probs[n, :tn], ref, idx=idx[n, :tn])
     # the same kernel family per layer whatever the batch and its widest sample (a layer sums its products in one order)
     def families(p):       # op kinds and every flag (kernel family, gate folding, weight tiling ...), layer by layer
         return [(int(o["kind"]), int(o["flags"])) for o in p.ops]

@@ -41,8 +41,11 @@ def test_chained_mobile_detector_matches_the_oracle(ctx, mid, shape):
     assert int(prog.ops[-1]["kind"]) == ir.OP_CHAIN and int(prog.ops[-1]["out"]["esize"]) == 4       # the head tail stores the map
     assert sum(bool(int(o["flags"]) & ir.F_OGATE) for o in prog.ops if int(o["kind"]) == ir.OP_CONV) == 4
     e1, e0 = np.abs(got - ref).max(), np.abs(plain - ref).max()
-    assert np.isfinite(got).all() and e1 < max(5e-3, 2.0 * e0), (e1, e0)
-    assert np.abs(got - plain).max() < 5e-3
+    # (real weights: 5e-3; the LIVE stand-in of V4_ch_det_fast — round 5: its map now depends on its input — moves by up to 1.2e-2 between
+    # the two programs' rounding points)
+    tol = 5e-3 if mid == "V3_ch_det_fast" else 2.5e-2
+    assert np.isfinite(got).all() and e1 < max(tol, 2.0 * e0), (e1, e0)
+    assert np.abs(got - plain).max() < tol
 
 
 def test_chained_detector_on_text_frames_tracks_the_oracle_closer(ctx):

@@ -124,3 +124,32 @@ def test_convex_hull_against_scipy():
         sp = ConvexHull(pts.astype(np.float64))
         theirs = set(map(tuple, pts[sp.vertices]))
         assert ours == theirs          # strict hull: collinear boundary points dropped by both
+
+
+@pytest.mark.parametrize("mid", ["V4_ch_rec", "V4_ch_rec_fast", "V4_en_rec_fast", "V3_ch_rec_fast", "V4_ch_det", "V4_ch_det_fast", "V2_ch_det"])
+def test_standin_weights_are_alive_and_well_conditioned(mid):
+    """The seeded stand-in weights (net_ref.synth_weights + calibrate) must make nets that (a) ANSWER DIFFERENT INPUTS DIFFERENTLY — until
+    round 5 the PP-LCNetV3 stand-ins were constant functions of their input (their "learnable affine" scales were drawn as N(0, 0.05))
+    and the deep HGNet ones nearly so (layer-wide LSUV scaling lets per-channel offsets swamp the input-dependent part), which made every
+    parity test on them a test of bias propagation — and (b) are not chaotic: rounding the weights to fp16 alone must move the outputs
+    by far less than two inputs differ.  Consistency checks of test infrastructure, not pins."""
+    desc, w = net_ref.get_weights(mid)
+    det = "_det" in mid
+    shape = (2, 3, 64, 96) if det else (2, 3, 48, 160)
+    rng = np.random.default_rng(0)
+    xa = rng.uniform(-1, 1, shape).astype(np.float16).astype(np.float32)
+    xb = rng.uniform(-1, 1, shape).astype(np.float16).astype(np.float32)
+    w16 = {k: (v.astype(np.float16).astype(np.float32) if v.ndim >= 2 else v) for k, v in w.items()}
+    pa = net_ref.run_graph(desc, w, xa)[0].numpy().astype(np.float64)
+    pb = net_ref.run_graph(desc, w, xb)[0].numpy().astype(np.float64)
+    p16 = net_ref.run_graph(desc, w16, xa)[0].numpy().astype(np.float64)
+    if det:
+        assert pa.max() - pa.min() > 0.5 and 0.05 < float((pa > 0.3).mean()) < 0.95          # a map that crosses the DB threshold
+        between, rounding = float(np.abs(pa - pb).mean()), float(np.abs(pa - p16).max())
+        assert between > 0.02 and rounding < 5e-3 and rounding < 0.1 * between, (mid, between, rounding)
+    else:
+        lg = lambda p: np.log(np.maximum(p, 1e-300))
+        between = float(np.median(np.abs(lg(pa) - lg(pb))))
+        rounding = np.abs(lg(pa) - lg(p16))
+        assert len(set(pa.argmax(-1).ravel().tolist())) >= 6, "the arg-max must move along the sequence"
+        assert between > 0.3 and float(rounding.max()) < 0.2 and float(np.median(rounding)) < 0.05 * between, (mid, between, float(rounding.max()))

@@ -61,7 +61,22 @@ def main():
     ap.add_argument("--blocks", type=int, default=3)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--no-profile-pass", action="store_true", help="skip the headline's roofline pass + vendor GEMM in front of each iteration")
+    ap.add_argument("--gc", action="store_true", help="leave Python's cyclic collector ON inside the timed blocks (bench.py turns it off) and log its passes")
     pa = ap.parse_args()
+    if pa.gc:
+        os.environ["VSE_BENCH_GC"] = "1"
+    import gc
+    gc_log = []
+    gc_t0 = {}
+
+    def gc_cb(phase, info):
+        if phase == "start":
+            gc_t0[info["generation"]] = time.perf_counter()
+        else:
+            t0 = gc_t0.pop(info["generation"], None)
+            if t0 is not None:
+                gc_log.append((t0, info["generation"], round(1e3 * (time.perf_counter() - t0), 2), info.get("collected", 0)))
+    gc.callbacks.append(gc_cb)
     sys.argv = ["bench.py"]
     import bench
     args = bench.parse()
@@ -132,11 +147,13 @@ def main():
             gaps = [round(1e3 * (s - tstart), 2) for s in stamps if s >= tstart]
             rec["blocks"].append({"fps": round(32 * pa.steps / dtb, 1), "ms": round(1e3 * dtb, 2), "warmup": pa.warm if b == 0 else 0,
                                   "alloc_delta": {k: m1[k] - m0[k] for k in m0}, "rec_call_return_ms": gaps,
+                                  "gc_passes": [(round(1e3 * (g[0] - tstart), 1), g[1], g[2], g[3]) for g in gc_log if tstart <= g[0] <= t1],
                                   "gpu": smp.window(tstart, t1)})
         del W2, _o2
         torch.cuda.empty_cache()
         fps = [b["fps"] for b in rec["blocks"]]
-        log(f"iter {it}: blocks {fps}  alloc {[b['alloc_delta']['device_alloc'] for b in rec['blocks']]}")
+        log(f"iter {it}: blocks {fps}  alloc {[b['alloc_delta']['device_alloc'] for b in rec['blocks']]}  gc passes (ms into block, generation, ms, "
+            f"collected) {[b['gc_passes'] for b in rec['blocks']]}")
         result["iters"].append(rec)
     smp.stop = True
     allf = [b["fps"] for r in result["iters"] for b in r["blocks"]]

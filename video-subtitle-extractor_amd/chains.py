@@ -22,23 +22,24 @@ import struct
 import numpy as np
 
 from . import ir
+from .ir import dev_switch as _dev_switch
 
-CHAIN = os.environ.get("VSE_CHAIN", "1") != "0"
-CHAIN_MAX_STAGES = int(os.environ.get("VSE_CHAIN_MAXSTAGES", "6"))
-CHAIN_HEAD = os.environ.get("VSE_CHAIN_HEAD", "1") != "0"               # the DB head's two transposed convs as one chain (try_lower_head_tail)
+CHAIN = _dev_switch("VSE_CHAIN", "1") != "0"
+CHAIN_MAX_STAGES = int(_dev_switch("VSE_CHAIN_MAXSTAGES", "6"))
+CHAIN_HEAD = _dev_switch("VSE_CHAIN_HEAD", "1") != "0"               # the DB head's two transposed convs as one chain (try_lower_head_tail)
 CHAIN_LDS_2 = 76 * 1024          # two blocks per CU (160 KiB of LDS)
 CHAIN_LDS_1 = 150 * 1024
 CHAIN_TILES = [(8, 32), (16, 16), (8, 16), (4, 32), (4, 16), (2, 32), (4, 8), (2, 16), (2, 8)]
-if os.environ.get("VSE_CHAIN_TILE"):                  # experiments: force the tile, e.g. "4,16"
+if _dev_switch("VSE_CHAIN_TILE"):                  # experiments: force the tile, e.g. "4,16"
     CHAIN_TILES = [tuple(int(v) for v in os.environ["VSE_CHAIN_TILE"].split(","))]
-CHAIN_TILE_CYC = float(os.environ.get("VSE_CHAIN_TILECYC", "2400"))    # fixed cycles of a tile (input store, prefetch issue, turn-over)
-CHAIN_STAGE_CYC = float(os.environ.get("VSE_CHAIN_STAGECYC", "600"))   # fixed cycles of a stage (descriptor lanes, barrier)
-CHAIN_BLOCKS_CU = int(os.environ.get("VSE_CHAIN_BLOCKS", "3"))         # blocks per CU the kernel's registers allow (VSE_CHAIN_LB in chain.hip)
-CHAIN_ONE_BLOCK = float(os.environ.get("VSE_CHAIN_ONEBLOCK", "2.4"))   # cost factor of a plan that leaves one block per CU
-CHAIN_TWO_BLOCKS = float(os.environ.get("VSE_CHAIN_TWOBLOCKS", "1.4"))  # ... two
+CHAIN_TILE_CYC = float(_dev_switch("VSE_CHAIN_TILECYC", "2400"))    # fixed cycles of a tile (input store, prefetch issue, turn-over)
+CHAIN_STAGE_CYC = float(_dev_switch("VSE_CHAIN_STAGECYC", "600"))   # fixed cycles of a stage (descriptor lanes, barrier)
+CHAIN_BLOCKS_CU = int(_dev_switch("VSE_CHAIN_BLOCKS", "3"))         # blocks per CU the kernel's registers allow (VSE_CHAIN_LB in chain.hip)
+CHAIN_ONE_BLOCK = float(_dev_switch("VSE_CHAIN_ONEBLOCK", "2.4"))   # cost factor of a plan that leaves one block per CU
+CHAIN_TWO_BLOCKS = float(_dev_switch("VSE_CHAIN_TWOBLOCKS", "1.4"))  # ... two
 # segmentation: a chain's estimated time is weighted against the layer-by-layer ops it replaces; < 1 prefers chains (they round a
 # tensor to fp16 once per chain instead of once per layer: the detector's box parity) even where they are not faster
-CHAIN_TIME_WEIGHT = float(os.environ.get("VSE_CHAIN_WEIGHT", "0.5"))
+CHAIN_TIME_WEIGHT = float(_dev_switch("VSE_CHAIN_WEIGHT", "0.5"))
 CHAIN_OP_TBS = 2.5e6            # bytes per microsecond an un-fused streaming op reaches on this chip (measured: 2-3 TB/s), + 6 us per launch
 
 

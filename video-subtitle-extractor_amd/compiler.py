@@ -29,6 +29,7 @@ import os
 import numpy as np
 
 from . import ir
+from .ir import dev_switch as _dev_switch
 from .chains import ChainMixin
 
 
@@ -169,47 +170,48 @@ _ACTS = {"relu": ir.ACT_RELU, "hard_swish": ir.ACT_HSWISH, "swish": ir.ACT_SWISH
 
 
 # shortest K (taps x channels) worth a conv_patch_kernel launch; VSE_PATCH_MINK overrides it for kernel experiments
-PATCH_MIN_K = int(os.environ.get("VSE_PATCH_MINK", "500"))
+PATCH_MIN_K = int(_dev_switch("VSE_PATCH_MINK", "500"))
 # most couts sent to the patch kernel: with more than 64 couts the 256-pixel implicit-GEMM tiles (conv_gemm.hip,
 # activation tile fetched once for 128-256 couts) measure 15-50 % faster than the patch kernel on MI355X
 PATCH_MAX_COUT = 64
 # smallest useful fraction of a tile grid (8/16 x 32 output pixels) for the patch kernel; below it the map is too ragged
-PATCH_MIN_TILE_EFF = float(os.environ.get("VSE_PATCH_MINEFF", "0.5"))
+PATCH_MIN_TILE_EFF = float(_dev_switch("VSE_PATCH_MINEFF", "0.5"))
 # LIGHT patch variant policy, mirrors VSE_PATCH_LIGHT in csrc/conv_patch.hip: 0 never, 1 layers with 65-128 couts, 2 all eligible
-PATCH_LIGHT = int(os.environ.get("VSE_PATCH_LIGHT", "2"))
+PATCH_LIGHT = int(_dev_switch("VSE_PATCH_LIGHT", "2"))
 # evaluate the PP-OCRv4 server detector's last 3x3 conv on the low-res grid (conv_head.hip); VSE_HEAD_UP2=0 keeps it on
 # the patch kernel (experiments / A-B)
-STEM = os.environ.get("VSE_STEM", "1") != "0"         # conv_stem_kernel for 3x3 convs over <= 4 real channels
-GATE_DW = os.environ.get("VSE_GATE_DW", "1") != "0"   # SE gate folded into a depthwise consumer
-GATE_FOLD = os.environ.get("VSE_GATE_FOLD", "1") != "0"   # SE gate whose consumers are a depthwise conv and 1x1 convs: folded into them
-WK32 = os.environ.get("VSE_WK32", "1") != "0"      # 32-deep weight tiles for conv_gemm_kernel (contiguous wave DMAs)
-HEAD_UP2 = os.environ.get("VSE_HEAD_UP2", "1") != "0"
-COL = os.environ.get("VSE_COL", "1") != "0"           # conv_col_kernel (one filter column per step) for 9x9 / 7x7 / 5x5 layers
+STEM = _dev_switch("VSE_STEM", "1") != "0"         # conv_stem_kernel for 3x3 convs over <= 4 real channels
+GATE_DW = _dev_switch("VSE_GATE_DW", "1") != "0"   # SE gate folded into a depthwise consumer
+GATE_FOLD = _dev_switch("VSE_GATE_FOLD", "1") != "0"   # SE gate whose consumers are a depthwise conv and 1x1 convs: folded into them
+WK32 = _dev_switch("VSE_WK32", "1") != "0"      # 32-deep weight tiles for conv_gemm_kernel (contiguous wave DMAs)
+HEAD_UP2 = _dev_switch("VSE_HEAD_UP2", "1") != "0"
+COL = _dev_switch("VSE_COL", "1") != "0"           # conv_col_kernel (one filter column per step) for 9x9 / 7x7 / 5x5 layers
 # below this tile efficiency the 8-row tiles of conv_patch_kernel win (measured: 17x30 map 0.163 vs 0.203 ms, 34x60 0.50 vs 0.43)
-COL_MIN_TILE_EFF = float(os.environ.get("VSE_COL_MINEFF", "0.75"))
+COL_MIN_TILE_EFF = float(_dev_switch("VSE_COL_MINEFF", "0.75"))
 # conv_c3_kernel (3x3, two blocks per CU): VSE_COL3=0 off; cout / tile-efficiency limits from per-layer A/B runs
-COL3 = os.environ.get("VSE_COL3", "1") != "0"
-COL3_MAX_COUT = int(os.environ.get("VSE_COL3_MAXCOUT", "192"))     # per-layer A/B (tools/bench_conv.py --cfgs d,p,c): 224-cout layers tie or lose
-PW = os.environ.get("VSE_PW", "1") != "0"             # conv_pw_kernel for 1x1 convs (and 2x2 s2 transposed convs) over <= 64 input channels
-PW_MAX_COUT = int(os.environ.get("VSE_PW_MAXCOUT", "64"))
-COL3_MIN_K = int(os.environ.get("VSE_COL3_MINK", "250"))   # 3x3 32->32 @136x240 (K = 288): 0.180 ms on the implicit GEMM, 0.115 ms here
+COL3 = _dev_switch("VSE_COL3", "1") != "0"
+COL3_MAX_COUT = int(_dev_switch("VSE_COL3_MAXCOUT", "192"))     # per-layer A/B (tools/bench_conv.py --cfgs d,p,c): 224-cout layers tie or lose
+PW = _dev_switch("VSE_PW", "1") != "0"             # conv_pw_kernel for 1x1 convs (and 2x2 s2 transposed convs) over <= 64 input channels
+PW_MAX_COUT = int(_dev_switch("VSE_PW_MAXCOUT", "64"))
+COL3_MIN_K = int(_dev_switch("VSE_COL3_MINK", "250"))   # 3x3 32->32 @136x240 (K = 288): 0.180 ms on the implicit GEMM, 0.115 ms here
 COL3_WIDE_MIN_CIN = 128    # layers with more than 64 couts (two+ cout tiles refetch the patch) only from 128 input channels on
-COL3_MIN_TILE_EFF = float(os.environ.get("VSE_COL3_MINEFF", "0.8"))
+COL3_MIN_TILE_EFF = float(_dev_switch("VSE_COL3_MINEFF", "0.8"))
 # nominal sample width for the kernel selection of ragged (recogniser) plans: subtitle lines are several hundred pixels wide at
 # 48 px height; every plan of a model selects as if its maps were this wide (the choice only steers efficiency, never results
 # ACROSS plans of one process; a different value is a different set of summation orders)
-RAGGED_SEL_W = int(os.environ.get("VSE_RAGGED_SELW", "768"))
-ONECH = os.environ.get("VSE_ONECH", "1") != "0"             # DB head: last transposed conv stores the fp32 map directly
-GATE_CONCAT = os.environ.get("VSE_GATE_CONCAT", "1") != "0"   # SE output that only feeds a concat: multiplied by the copy into the slot
-PAIR_MAX_PIX = int(os.environ.get("VSE_PAIR_MAXPIX", str(1 << 40)))     # experiments: tensors with more pixels per image stay plain fp16
-PAIR_MIN_PIX = int(os.environ.get("VSE_PAIR_MINPIX", "0"))                # ... and tensors with fewer
-DWPW = os.environ.get("VSE_DWPW", "1") != "0"                 # depthwise conv fused in front of its 1x1 consumer (hi + lo nets: conv_dwpw.hip)
+RAGGED_SEL_W = int(_dev_switch("VSE_RAGGED_SELW", "768"))
+ONECH = _dev_switch("VSE_ONECH", "1") != "0"             # DB head: last transposed conv stores the fp32 map directly
+GATE_CONCAT = _dev_switch("VSE_GATE_CONCAT", "1") != "0"   # SE output that only feeds a concat: multiplied by the copy into the slot
+PAIR_MAX_PIX = int(_dev_switch("VSE_PAIR_MAXPIX", str(1 << 40)))     # experiments: tensors with more pixels per image stay plain fp16
+PAIR_MIN_PIX = int(_dev_switch("VSE_PAIR_MINPIX", "0"))                # ... and tensors with fewer
+DWPW = _dev_switch("VSE_DWPW", "1") != "0"                 # depthwise conv fused in front of its 1x1 consumer (hi + lo nets: conv_dwpw.hip)
 # filter sizes sent there: 3x3 wins against depthwise + 1x1 launches (V4 16 -> 32 @272x480: 0.33 vs 0.44 ms), 5x5 loses (V3 64 -> 24
 # @68x120: 0.21 vs 0.14 ms: 25 taps of fp32 VALU work per 8 channels and lane, no window sharing between neighbouring pixels)
-DWPW_K = tuple(int(v) for v in os.environ.get("VSE_DWPW_K", "3").split(","))
-SE_LATERAL = os.environ.get("VSE_SE_LATERAL", "1") != "0"   # 1x1 conv + SE block with shortcut -> one gated conv (F_OGATE)
-LSTM_MFMA = os.environ.get("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
-LSTM_WAVES = int(os.environ.get("VSE_LSTM_WAVES", "16"))    # 8: lstm_mfma_kernel, 16: lstm_mfma16_kernel (twice the loads in flight)
+# (5 x 5 filters lose fused — 25 taps per lane — and their kernel instantiations exist in development builds only)
+DWPW_K = tuple(int(v) for v in _dev_switch("VSE_DWPW_K", "3").split(",")) if os.environ.get("VSE_DEV_BUILD", "0") == "1" else (3,)
+SE_LATERAL = _dev_switch("VSE_SE_LATERAL", "1") != "0"   # 1x1 conv + SE block with shortcut -> one gated conv (F_OGATE)
+LSTM_MFMA = _dev_switch("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
+LSTM_WAVES = int(_dev_switch("VSE_LSTM_WAVES", "16"))    # 8: lstm_mfma_kernel, 16: lstm_mfma16_kernel (twice the loads in flight)
 
 
 def c3_tile_eff(oh, ow):
@@ -1025,7 +1027,7 @@ class Compiler(ChainMixin):
     def gemm_eligible(kh, kw, ph, pw, cinp, inshift, flags):
         """Mirror of conv_gemm_mode() (csrc/conv_gemm.hip): the layer runs on conv_gemm_kernel.  The launcher refuses an
         F_WK32 op it cannot send there, so a drift between the two rules fails loudly instead of computing garbage."""
-        if os.environ.get("VSE_CONV_GEMM", "1")[:1] == "0":
+        if _dev_switch("VSE_CONV_GEMM", "1")[:1] == "0":
             return False
         if inshift or (flags & (ir.F_PATCH | ir.F_DOT1 | ir.F_SRC2 | ir.F_UP2HEAD)):
             return False
@@ -2174,7 +2176,7 @@ def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_pro
         c.input_norm = input_norm      # (mean3, std3): the plan takes RAW resized pixels + a ones channel (Compiler.fold_input_norm)
         c.fuse_preprocess = bool(fuse_preprocess)    # ... and resizes them itself from the uint8 frames (F_U8SRC): the plan input IS the frames
         c.chain = bool(hilo) if chain is None else bool(chain)      # 1x1 / depthwise chains as OP_CHAIN (chains.py): the hi + lo nets (mobile detectors)
-        c.chain_lo = os.environ.get("VSE_CHAIN_LO", "1") != "0"     # tensors that feed a chain are stored as fp16 hi + lo pairs
+        c.chain_lo = _dev_switch("VSE_CHAIN_LO", "1") != "0"     # tensors that feed a chain are stored as fp16 hi + lo pairs
         if c.hilo:
             c.use_patch = False          # conv_patch_kernel has no two-pass K walk (the implicit-GEMM, stem and column kernels do)
         return c.compile()

@@ -582,7 +582,7 @@ int launch_chain(const vse_op& o, const TView& in0, const TView& out, const TVie
     if (nstages < 1 || nstages > CH_MAX_STAGES || nbufs < 1 || nbufs > CH_MAX_BUFS) return VSE_E_INVAL;
     // p[5] = 1 (compiler.py try_lower_head_tail): a 1x1 -> 1x1 chain with the pixel-shuffle map store — the register form
     // (chain_pw2_kernel; VSE_HEAD_PW2=0 keeps the generic kernel for A/B runs)
-    static const bool pw2_on = !(getenv("VSE_HEAD_PW2") && atoi(getenv("VSE_HEAD_PW2")) == 0);
+    static const bool pw2_on = !(vse_dev_getenv("VSE_HEAD_PW2") && atoi(vse_dev_getenv("VSE_HEAD_PW2")) == 0);
     // (an image above 64 KiB — the ResNet detector's 64 -> 4 x 64 -> 16 tail — stays on the generic kernel)
     if (o.p[5] == 1 && pw2_on && nstages == 2 && o.p[6] > 0 && o.p[6] <= 64 * 1024 && in0.c <= 64) {
         Pw2Args b;

@@ -89,6 +89,18 @@ __device__ __forceinline__ void vse_fma_h8(float (&acc)[8], const half8& x, cons
     acc[7] = vse_fma_mix_hi(u[3], w1[3], acc[7]);
 }
 
+// An EXPERIMENT switch (kernel selection for A/B runs, ablations): read from the environment only in a development build
+// (-DVSE_DEV_BUILD); the product library has none of them.  The product's own switches are listed in INTEGRATION.md.
+#include <stdlib.h>
+static inline const char* vse_dev_getenv(const char* name) {
+#ifdef VSE_DEV_BUILD
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // Per-device launch state (a raised dynamic-LDS limit, the CU count): hipFuncSetAttribute acts on the CURRENT device and a process may
 // hold contexts on several devices and launch from several host threads, so "done once" is kept per device id, under a mutex.
 #include <mutex>

@@ -173,8 +173,15 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 4 : KS <= 4 ? 3 : 2)) void conv_dwp
     }
 }
 
+// 5 x 5 filters stay on two launches (25 taps per lane: 0.21 against 0.09 + 0.04 ms, and the unrolled form spills): the 5 x 5 instantiations
+// exist in development builds only (VSE_DEV_BUILD, compiler.py VSE_DWPW_K=3,5)
+#ifdef VSE_DEV_BUILD
+#define DWPW_K5 1
+#else
+#define DWPW_K5 0
+#endif
 bool conv_dwpw_ok(int k, int s, int cinp, int Np, int flags) {
-    return (k == 3 || k == 5) && (s == 1 || s == 2) && (cinp & 7) == 0 && cinp <= 96 && Np <= 192 && (flags & F_HILO)
+    return (k == 3 || (DWPW_K5 && k == 5)) && (s == 1 || s == 2) && (cinp & 7) == 0 && cinp <= 96 && Np <= 192 && (flags & F_HILO)
            && !(flags & (F_SRC2 | F_DOT1 | F_PATCH | F_COL | F_PIXSHUF | F_IMGW | F_STEM));
 }
 
@@ -204,8 +211,12 @@ static int launch_dwpw_t(const ConvParams& p, hipStream_t st) {
 int launch_conv_dwpw(const ConvParams& p, hipStream_t st) {
     if (!conv_dwpw_ok(p.kh, p.sh, p.cinp, p.Np, p.flags) || p.kh != p.kw || p.sh != p.sw || p.ph != p.pw || !p.dotw) return VSE_E_UNSUPPORTED;
     const int ks = (p.cinp + 15) / 16;
+#if DWPW_K5
 #define DWPW(KS_) (p.in_lo_off ? (p.kh == 3 ? launch_dwpw_t<KS_, 3, true>(p, st) : launch_dwpw_t<KS_, 5, true>(p, st)) \
                                : (p.kh == 3 ? launch_dwpw_t<KS_, 3, false>(p, st) : launch_dwpw_t<KS_, 5, false>(p, st)))
+#else
+#define DWPW(KS_) (p.in_lo_off ? launch_dwpw_t<KS_, 3, true>(p, st) : launch_dwpw_t<KS_, 3, false>(p, st))
+#endif
     switch (ks) {
         case 1: return DWPW(1);
         case 2: return DWPW(2);

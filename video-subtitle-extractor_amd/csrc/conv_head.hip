@@ -549,12 +549,7 @@ int launch_conv_head_up2(const ConvParams& pin, int n_img, hipStream_t st) {
         const unsigned long long tiles = (unsigned long long)n_img * p.tiles_h * p.tiles_w;
         if (tiles == 0 || tiles > 0x7fffffffull) return VSE_E_INVAL;
         p.ntiles = (unsigned)tiles;
-        static const int cus = [] {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-            return prop.multiProcessorCount;
-        }();
+        const int cus = vse_cu_count() ? vse_cu_count() : 256;          // (per device: common.h)
         unsigned long long want = 2 * ((tiles + 7) / 8) * 8;                 // two blocks (row parities) per tile slot, whole XCD rounds
         if (want > (unsigned long long)cus) want = (unsigned long long)cus;
         const unsigned grid = (unsigned)(want < 16 ? 16 : want / 16 * 16);

@@ -323,7 +323,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     if (a.flags & F_COL) return (p.kh == 3 && p.kw == 3) ? launch_conv_c3(p, a.in.n, st) : launch_conv_col(p, a.in.n, st);
     if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
     if (a.Kp % 64) return VSE_E_INVAL;
-    static const bool use_gemm = [] { const char* e = getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
+    static const bool use_gemm = [] { const char* e = vse_dev_getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
     if (use_gemm) {
         const int rc = launch_conv_gemm(p, a.Kp, st);
         if (rc != VSE_E_UNSUPPORTED) return rc;

@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, MODE == 2 ? 4 : 2) void conv_patch_kernel(cons
 //   (3x3, 1xk) and no 1-channel projection is fused (that needs all couts of a pixel in one wave);
 //   else 64 couts per tile, 16-row tiles when they fit the 960-pixel patch (mode 1 above 640 pixels), else 8-row tiles.
 static int patch_light_policy() {       // VSE_PATCH_LIGHT: 0 never, 1 only layers with more than 64 couts, 2 every eligible layer
-    static const int v = [] { const char* e = getenv("VSE_PATCH_LIGHT"); return e && e[0] ? atoi(e) : 2; }();
+    static const int v = [] { const char* e = vse_dev_getenv("VSE_PATCH_LIGHT"); return e && e[0] ? atoi(e) : 2; }();
     return v;
 }
 void conv_patch_plan(int kh, int kw, int OH, int Np, int flags, int* th, int* bn, int* mode) {

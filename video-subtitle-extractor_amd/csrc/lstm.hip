@@ -157,7 +157,7 @@ __global__ __launch_bounds__(1024, 4) void lstm_mfma16_kernel(TView gates_f, TVi
 #pragma unroll
     for (int i = 0; i < 8; ++i) c[i] = 0.f;
 #ifndef LSTM16_WQ
-#define LSTM16_WQ 4       // 8 spills ~25 dwords per lane at the 128-VGPR budget of 4 waves per SIMD and is 12 % slower (tools/ablate_lstm.sh)
+#define LSTM16_WQ 2       // fragments in flight: 4 spills 15 VGPRs at the 128-register budget of 4 waves per SIMD and is 10 % SLOWER (2.46 vs 2.22 ms per layer, tools/ab_lstm_wq.sh, round 5); 8 spills ~25 and is 12 % slower still
 #endif
     constexpr int WQ = LSTM16_WQ, SPC = WQ / 2, NCH = 16 / SPC;      // fragments in flight = SPC k-slices x two tiles; chunks per step
     half8 wq[WQ];

@@ -803,12 +803,11 @@ static int launch_dw_tile(const TView& in0, const TView& out, const TView& gate,
     const int colstride = CGB * 16 + (CGB == 4 ? 16 : CGB == 8 ? 32 : 0);
     const size_t lds = (size_t)(p[P_LO_RES] ? 2 : 1) * IR * IC * colstride;
     if (lds > 150 * 1024) return VSE_E_UNSUPPORTED;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_tile_kernel<KW, SW, GM>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-            return VSE_E_HIP;
-        attr = true;
-    }
+    static VseDevOnce attr_once;          // (per device, thread-safe: common.h)
+    if (!vse_dev_once(attr_once, [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_tile_kernel<KW, SW, GM>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+        }))
+        return VSE_E_HIP;
     const int cg = in0.c >> 3, cgblocks = (cg + CGB - 1) / CGB, tiles_w = (out.w + 31) / 32, tiles_h = (out.h + TR - 1) / TR;
     const unsigned long long blocks = (unsigned long long)out.n * tiles_h * tiles_w * cgblocks;
     if (blocks == 0 || blocks > 0x7fffffffull) return VSE_E_UNSUPPORTED;
@@ -881,7 +880,7 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             if ((in0.c & 7) || out.c != in0.c) return VSE_E_INVAL;
             const long items = (long)out.n * out.h * out.w * (in0.c >> 3);
             // (is_max = 2: the fp32 form of the max, for A/B runs: VSE_POOL_PK=0)
-            static const int pk_off = getenv("VSE_POOL_PK") && atoi(getenv("VSE_POOL_PK")) == 0;
+            static const int pk_off = vse_dev_getenv("VSE_POOL_PK") && atoi(vse_dev_getenv("VSE_POOL_PK")) == 0;
             hipLaunchKernelGGL(pool_kernel, dim3(grid_for(items, 256)), dim3(256), 0, st, in0, out, p[P_KH], p[P_KW],
                                p[P_SH], p[P_SW], p[P_PH], p[P_PW], p[P_POOL_MAX] ? (pk_off ? 2 : 1) : 0, p[P_POOL_EXCL], wl_in, wl_out);
             break;

@@ -165,6 +165,26 @@ int vse_plan_create(vse_ctx* c, int weights_id, const vse_op* ops, int n_ops, si
             delete p;
             return VSE_E_INVAL;
         }
+        if (o.kind == OP_CHAIN) {
+            // the chain kernels read their descriptor from the weight blob: check, once, that the record and the blob describe the
+            // same chain (header: magic, stages, buffers, LDS image bytes / offset / total; compiler.py emit_chain) and that the
+            // descriptor + LDS image lie inside the blob — a stale or foreign blob must fail here, not inside a kernel
+            int hdr[16];
+            const size_t words = 16 + (size_t)std::max(o.p[4], 0) * 16 + (size_t)std::max(o.p[3], 0) * 28;
+            if ((size_t)o.w_off + words * 4 > wbytes || (o.w_off & 3) ||
+                hipMemcpy(hdr, reinterpret_cast<const char*>(c->weights[weights_id]) + o.w_off, sizeof hdr, hipMemcpyDeviceToHost) != hipSuccess) {
+                set_err("op %d: chain descriptor out of the weight blob", i);
+                delete p;
+                return VSE_E_INVAL;
+            }
+            if (hdr[0] != 0x43484e31 || hdr[1] != o.p[3] || hdr[2] != o.p[4] || hdr[5] != o.p[2] || hdr[3] < 0 || hdr[4] < 0 ||
+                (size_t)o.w_off + (size_t)hdr[4] + (size_t)hdr[3] > wbytes) {
+                set_err("op %d: chain descriptor does not match its record (magic %#x, stages %d / %d, buffers %d / %d, LDS %d / %d)", i, hdr[0],
+                        hdr[1], o.p[3], hdr[2], o.p[4], hdr[5], o.p[2]);
+                delete p;
+                return VSE_E_INVAL;
+            }
+        }
     }
     *out = p;
     return VSE_OK;
@@ -401,7 +421,7 @@ int vse_plan_op_variant(vse_plan* p, int i) {
         return 100000 * mode + 1000 * th + bn;
     }
     // conv_gemm_kernel configuration c, MASK m -> 200000 + 10*c + m; conv_mfma_kernel<.., UPS> -> 10000*UPS + BN
-    static const bool use_gemm = [] { const char* e = getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
+    static const bool use_gemm = [] { const char* e = vse_dev_getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
     const int mode = use_gemm ? conv_gemm_mode(o.p[P_KH], o.p[P_KW], o.p[P_SH], o.p[P_SW], o.p[P_PH], o.p[P_PW], o.p[P_CINP],
                                                o.p[P_KTOT], o.p[P_INSHIFT], o.flags) : 0;
     if (mode) {

@@ -146,3 +146,11 @@ P_CH_TILES_H, P_CH_TILES_W, P_CH_LDS, P_CH_NSTAGES, P_CH_NBUFS = 0, 1, 2, 3, 4
 P_CH_PW2, P_CH_IMG = 5, 6     # P_CH_PW2 = 1: a 1x1 -> 1x1 chain with the pixel-shuffle map store (the DB head's tail): the launcher may run the
                                # REGISTER form chain_pw2_kernel on the same blob; P_CH_IMG = bytes of the blob's LDS image
 P_CH_LO_IN, P_CH_LO_OUT0, P_CH_LO_OUT1, P_CH_LO_OUT2 = 10, 11, 12, 13     # channel offset of the lo half of a hi + lo tensor (0 = plain fp16)
+
+
+def dev_switch(name, default=None):
+    """An EXPERIMENT switch of the compiler (kernel-family routing, thresholds, ablations): read from the environment only in a development
+    build (VSE_DEV_BUILD=1, the build that also carries the experimental kernels); the product always takes the default.  The product's
+    own switches are listed in INTEGRATION.md."""
+    import os
+    return os.environ.get(name, default) if os.environ.get("VSE_DEV_BUILD", "0") == "1" else default
