@@ -351,22 +351,12 @@ def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, 
         return parallel.gather_records(local, device=coll_dev)
 
     def timed(warmup, steps):
-        import gc
         out = run_steps(warmup)
         sync()
-        # the interpreter's cyclic collector stays out of the timed region (collected right before it): a generation-2 pass over the
-        # process's objects is a 30-60 ms host stall — 5-10 % of a 0.65 s region — that lands in about one block in twenty-five
-        # (tools/half_speed_probe.py, round 5: one recogniser call returning 40 ms late, GPU clocks and allocator untouched)
-        gc.collect()
-        if os.environ.get("VSE_BENCH_GC", "0") != "1":          # (VSE_BENCH_GC=1: leave the collector on — tools/half_speed_probe.py --gc)
-            gc.disable()
-        try:
-            t0 = time.perf_counter()
-            out = run_steps(steps)
-            sync()
-            dt = time.perf_counter() - t0
-        finally:
-            gc.enable()
+        t0 = time.perf_counter()
+        out = run_steps(steps)
+        sync()
+        dt = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

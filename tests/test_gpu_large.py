@@ -27,7 +27,10 @@ def test_server_detector_at_the_reference_input_size(ctx):
     assert ref.max() - ref.min() > 0.2                      # the stand-in head is not saturated
     # (522 k pixels of a stand-in head that sits near 0.5: single-pixel maxima of 0.018-0.025 measured, fp16 activation storage)
     assert d.max() < 4e-2 and d.mean() < 1e-3, (d.max(), d.mean())
-    assert ((got > 0.3) != (ref > 0.3)).mean() < 1e-3
+    # (a live stand-in map crosses the 0.3 threshold all over the frame: the pixels that land on the other side are the ones whose
+    # oracle value lies within the map error of it — measured 1.0e-3 of them)
+    assert ((got > 0.3) != (ref > 0.3)).mean() < 3e-3
+    assert not (((got > 0.3) != (ref > 0.3)) & (np.abs(ref - 0.3) > d.max())).any()
 
 
 def test_4k_frame_with_limit_side_3840(ctx):
@@ -60,4 +63,7 @@ def test_4k_frame_with_limit_side_3840(ctx):
     d = np.abs(got - ref)
     # (8.4 M pixels of a stand-in head that sits near 0.5 everywhere: the largest single deviation measured is 0.031)
     assert np.isfinite(got).all() and d.max() < 6e-2 and d.mean() < 2e-3, (d.max(), d.mean())      # (live stand-in, round 5: mean 1.0e-3)
-    assert ((got > 0.3) != (ref > 0.3)).mean() < 1e-3
+    # (a live stand-in map crosses the 0.3 threshold all over the frame: the pixels that land on the other side are the ones whose
+    # oracle value lies within the map error of it — measured 1.0e-3 of them)
+    assert ((got > 0.3) != (ref > 0.3)).mean() < 3e-3
+    assert not (((got > 0.3) != (ref > 0.3)) & (np.abs(ref - 0.3) > d.max())).any()
