@@ -60,19 +60,37 @@ def main():
         return d if os.path.isdir(d) else os.path.join(go, f"pmc_{name}")
     f = load(os.path.join(pmc("fetch"), "bench_counter_collection.csv"))
     w = load(os.path.join(pmc("write"), "bench_counter_collection.csv"))
+    # counter units per kernel family from the newest calibration run (tools/ubench/counter_calib.hip, tools/counter_calibration.py):
+    # known bytes / counter for that family's access shape; the guide's 2.0 / 1.0 for everything that was not calibrated on its own
+    import glob
+    calib, calib_src = {}, None
+    for cpath in sorted(glob.glob(os.path.join(out, "r*_counter_calibration.json")), reverse=True):
+        cj = json.load(open(cpath))
+        calib, calib_src = cj.get("families", {}), "profiles/" + os.path.basename(cpath)
+        dflt = cj.get("default", {})
+        break
+    else:
+        dflt = {}
+
+    def unit(kname):
+        fam = calib.get(kname.split("<")[0], {})
+        return (fam.get("fetch_factor") or dflt.get("fetch_factor") or 2.0, fam.get("write_factor") or dflt.get("write_factor") or 1.0)
     kernels = {}
     for k in f:
         nf, nw = len(f[k]), len(w.get(k, []))
         fk = sum(f[k]) / nf
         wk = sum(w[k]) / nw if nw else 0.0
+        uf, uw = unit(k)
         kernels[k] = {"launches_fetch_pass": nf, "launches_write_pass": nw, "fetch_size_kib_avg": round(fk, 1),
-                      "write_size_kib_avg": round(wk, 1),
-                      "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024)}
+                      "write_size_kib_avg": round(wk, 1), "fetch_unit": uf, "write_unit": uw,
+                      "hbm_bytes_per_launch": int(uf * fk * 1024 + uw * wk * 1024)}
     if kernels:
         with open(os.path.join(out, f"{tag}_traffic.json"), "w") as fh:
             json.dump({"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                                  "`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline`; "
-                                 "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction)",
+                                 "bytes = fetch_unit*FETCH_SIZE*1024 + write_unit*WRITE_SIZE*1024; the units per kernel family come from "
+                                 + (calib_src or "the guide (2.0 / 1.0)") + " (known byte counts in each family's access shape: 2.0 / 1.0 for "
+                                 "every shape measured, the 16-byte gathers at pixel stride included)",
                        "kernels": dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches_fetch_pass"]))},
                       fh, indent=1)
     sq = os.path.join(pmc("sq"), "bench_counter_collection.csv")

@@ -91,21 +91,56 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
 }
 
 // The three label passes walk a [n, h, w] map of which ~1-2 % of the pixels are text: a thread owns FOUR consecutive pixels of one row
-// (one 16-byte load), blockIdx = (column group, row, frame) so no pixel index is ever divided (the first form — one pixel per thread,
-// three 64-bit divisions by runtime extents each — spent 337 us on a 134 MB label map, 17 x its bytes at HBM rate), and a vector that
-// holds no text pixel is done after that one load.  Rows whose width is not a multiple of 4 (or unaligned maps) take the scalar tail.
+// (one 16-byte load), a block one row segment of 1024 pixels, blockIdx = (segment, row, frame) — no pixel index is ever divided (the first
+// form, one pixel per thread with three 64-bit divisions by runtime extents each, spent 337 us on a 134 MB label map) — and a vector that
+// holds no text pixel is done after that one load.
+// Labels start as RUN STARTS: db_init_kernel gives every text pixel the index of the first pixel of its horizontal run inside the block's
+// segment (a block-wide max-scan of "last background column"), so a run is one tree of depth 1 from the start and db_merge_kernel has
+// only the vertical / diagonal contacts (and the seam between two segments of a row) left to union.  With pixel-index labels every pixel
+// was hooked to its left neighbour concurrently: chains as long as the run, walked by every later find (258 us of the pass).
 __global__ __launch_bounds__(256) void db_init_kernel(const float* __restrict__ prob, int* __restrict__ Lall, int h, int w, float thresh) {
-    const int y = blockIdx.y, x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x0 >= w) return;
+    __shared__ int wave_last[4];
+    const int y = blockIdx.y, xg = blockIdx.x * 1024, x0 = xg + threadIdx.x * 4;
     const long row = ((long)blockIdx.z * h + y) * w;
-    const int p0 = y * w + x0;
-    if (x0 + 3 < w && ((reinterpret_cast<uintptr_t>(prob + row + x0) | reinterpret_cast<uintptr_t>(Lall + row + x0)) & 15) == 0) {
-        const float4v v = *reinterpret_cast<const float4v*>(prob + row + x0);
-        int4 l;
-        l.x = v[0] > thresh ? p0 : -1; l.y = v[1] > thresh ? p0 + 1 : -1; l.z = v[2] > thresh ? p0 + 2 : -1; l.w = v[3] > thresh ? p0 + 3 : -1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};                       // columns behind the row count as background
+    const bool vec = x0 + 3 < w && ((reinterpret_cast<uintptr_t>(prob + row + x0) | reinterpret_cast<uintptr_t>(Lall + row + x0)) & 15) == 0;
+    if (vec) {
+        const float4v q = *reinterpret_cast<const float4v*>(prob + row + x0);
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+    } else {
+        for (int k = 0; k < 4; ++k) if (x0 + k < w) v[k] = prob[row + x0 + k];
+    }
+    bool fg[4];
+    int last = -1;                                           // last background column of this vector (-1: none)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { fg[k] = v[k] > thresh; if (!fg[k]) last = x0 + k; }
+    // inclusive max-scan over the block's threads (columns ascend with the thread index)
+    int scan = last;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(scan, d, 64);
+        if (lane >= d) scan = max(scan, o);
+    }
+    if (lane == 63) wave_last[wave] = scan;
+    __syncthreads();
+    int before = __shfl_up(scan, 1, 64);                     // last background column left of this vector ...
+    if (lane == 0) before = -1;
+    for (int q = 0; q < wave; ++q) before = max(before, wave_last[q]);
+    if (x0 >= w) return;
+    const int p0 = y * w;
+    int lab[4];
+    int start = max(before + 1, xg);                         // ... so a run that reaches this vector starts here (at the segment's first column at the earliest)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!fg[k]) { lab[k] = -1; start = x0 + k + 1; }
+        else lab[k] = p0 + start;
+    }
+    if (vec) {
+        int4 l; l.x = lab[0]; l.y = lab[1]; l.z = lab[2]; l.w = lab[3];
         *reinterpret_cast<int4*>(Lall + row + x0) = l;
     } else {
-        for (int k = 0; k < 4 && x0 + k < w; ++k) Lall[row + x0 + k] = prob[row + x0 + k] > thresh ? p0 + k : -1;
+        for (int k = 0; k < 4 && x0 + k < w; ++k) Lall[row + x0 + k] = lab[k];
     }
 }
 __global__ __launch_bounds__(256) void db_merge_kernel(int* __restrict__ Lall, int h, int w) {
@@ -125,7 +160,8 @@ __global__ __launch_bounds__(256) void db_merge_kernel(int* __restrict__ Lall, i
     for (int k = 0; k < 4; ++k) {
         if (lab[k] < 0) continue;
         const int x = x0 + k, p = p0 + k;
-        if (k > 0 ? lab[k - 1] >= 0 : (x > 0 && L[p - 1] >= 0)) uf_union(L, p, p - 1);
+        // (a run is already one tree: only the seam between two 1024-pixel segments of a row needs the horizontal union)
+        if ((x & 1023) == 0 && x > 0 && L[p - 1] >= 0) uf_union(L, p, p - 1);
         if (y > 0) {
             if (L[p - w] >= 0) uf_union(L, p, p - w);
             if (x > 0 && L[p - w - 1] >= 0) uf_union(L, p, p - w - 1);
