@@ -1323,7 +1323,7 @@ class Compiler(ChainMixin):
             w_off = self.add_weights(("convh", wname, tuple(inv.segs), ep["out_name"]),
                                      lambda: self.head_up2_weights(self.pack_conv_weights(w, ep["scale"], inv)[0], inv.span))
         elif (PW and (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and inv.parts is None and inv_main.up == 0 and dot is None
-              and inv.span % 8 == 0 and inv.span <= 64 and coutp <= (128 if self.hilo else PW_MAX_COUT) and flags in (0, ir.F_RES)):
+              and inv.span % 8 == 0 and inv.span <= (96 if self.hilo else 64) and coutp <= (128 if self.hilo else PW_MAX_COUT) and flags in (0, ir.F_RES)):
             # (hi + lo nets: the alternative is the generic kernel with K padded to 64 and walked twice — any cout count it can hold
             # is faster here)
             flags |= ir.F_PW | (ir.F_HILO if self.hilo else 0)

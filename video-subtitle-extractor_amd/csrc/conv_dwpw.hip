@@ -61,11 +61,15 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 4 : KS <= 4 ? 3 : 2)) void conv_dwp
 
     __syncthreads();
     const int wr = conv_wrow(fx);
-    const long m0 = (long)xcd_block(blockIdx.x, gridDim.x) * 256 + wave * 64;       // (XCD-contiguous block order: common.h)
+#ifndef VSE_DWPW_TPW
+#define VSE_DWPW_TPW 2          // 32-pixel tiles per wave (A/B: tools/ab.sh conv_dwpw VSE_DWPW_TPW; a block = 4 waves x TPW tiles)
+#endif
+    constexpr int TPW = VSE_DWPW_TPW;
+    const long m0 = (long)xcd_block(blockIdx.x, gridDim.x) * (128 * TPW) + wave * (32 * TPW);       // (XCD-contiguous block order: common.h)
     // one 32-pixel MFMA tile at a time (a rolled loop: the two tiles of a wave share no registers — unrolled, hipcc kept both tiles' loads,
     // fragments and accumulators live and spilled hundreds of bytes per lane)
 #pragma unroll 1
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TPW; ++i) {
         const long mraw = m0 + i * 32 + fx;
         const long m = mraw < p.M ? mraw : 0;
         int ow, oh;
@@ -194,7 +198,7 @@ static int launch_dwpw_t(const ConvParams& p, hipStream_t st) {
             return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dwpw_kernel<KS, K, LO>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
         }))
         return VSE_E_HIP;
-    const unsigned long long blocks = (unsigned long long)((p.M + 255) / 256);
+    const unsigned long long blocks = (unsigned long long)((p.M + 128 * VSE_DWPW_TPW - 1) / (128 * VSE_DWPW_TPW));
     if (blocks == 0 || p.M >= 0x7fffffffl || lds > 128 * 1024) return VSE_E_INVAL;          // (32-bit pixel arithmetic: conv_pix_coords)
 #ifdef VSE_DEV_BUILD
     static int abl_set = -1;

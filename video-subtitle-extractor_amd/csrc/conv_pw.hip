@@ -1,4 +1,4 @@
-// Pointwise (1x1, stride 1) convolution over FEW INPUT CHANNELS (cin <= 64; any cout up to 256): F_PW.
+// Pointwise (1x1, stride 1) convolution over FEW INPUT CHANNELS (cin <= 64, <= 96 with hi + lo weights; any cout up to 256): F_PW.
 //
 // The implicit-GEMM kernels stage a 256-pixel tile and its weights through an LDS ring; with K = 16..64 that is a prologue, one or
 // two K steps and an epilogue per block — the detector's IntraCL 1x1 layers (32 <-> 64 channels @136x240) take 0.10-0.20 ms against
@@ -19,7 +19,7 @@
 #define PW_MAXN_HILO 128
 
 template <int KS, bool HILO = false>       // 16-channel K slices
-__global__ __launch_bounds__(256, (KS <= 2 ? 4 : 3)) void conv_pw_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (KS <= 2 ? 4 : KS <= 4 ? 3 : 2)) void conv_pw_kernel(const ConvParams p) {
     constexpr int ROWH = KS * 16 + 8;                    // halfs per staged weight row (16 bytes of padding)
     constexpr int ROWS = HILO ? PW_MAXN_HILO : PW_MAXN, NT = HILO ? 2 : 1;
     __shared__ __attribute__((aligned(16))) half_t swt[NT * ROWS * ROWH];
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 4 : 3)) void conv_pw_kernel(const C
 }
 
 bool conv_pw_ok(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int Np, int inshift, int flags) {
-    return kh == 1 && kw == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && inshift == 0 && (cinp & 7) == 0 && cinp <= 64
+    return kh == 1 && kw == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && inshift == 0 && (cinp & 7) == 0
+           && cinp <= ((flags & F_HILO) ? 96 : 64)      // (hi + lo nets: a 48-channel PAIR tensor is 96 input channels — round 5)
            && Np <= ((flags & F_HILO) ? PW_MAXN_HILO : PW_MAXN) && !(flags & (F_SRC2 | F_DOT1 | F_PATCH | F_COL));
 }
 
@@ -110,6 +111,8 @@ int launch_conv_pw(const ConvParams& p, hipStream_t st) {
             case 2: hipLaunchKernelGGL((conv_pw_kernel<2, true>), grid, block, 0, st, p); break;
             case 3: hipLaunchKernelGGL((conv_pw_kernel<3, true>), grid, block, 0, st, p); break;
             case 4: hipLaunchKernelGGL((conv_pw_kernel<4, true>), grid, block, 0, st, p); break;
+            case 5: hipLaunchKernelGGL((conv_pw_kernel<5, true>), grid, block, 0, st, p); break;
+            case 6: hipLaunchKernelGGL((conv_pw_kernel<6, true>), grid, block, 0, st, p); break;
             default: return VSE_E_UNSUPPORTED;
         }
         return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
