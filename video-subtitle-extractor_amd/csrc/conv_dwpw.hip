@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 4 : KS <= 4 ? 3 : 2)) void conv_dwp
     __syncthreads();
     const int wr = conv_wrow(fx);
 #ifndef VSE_DWPW_TPW
-#define VSE_DWPW_TPW 2          // 32-pixel tiles per wave (A/B: tools/ab.sh conv_dwpw VSE_DWPW_TPW; a block = 4 waves x TPW tiles)
+#define VSE_DWPW_TPW 1          // 32-pixel tiles per wave; a block = 4 waves x TPW tiles.  1 beats 2 by 2.8 % on the box-exact mobile detector (6.40 -> 6.22 ms; layer by layer +-0: tools/ab_dwpw_tpw.sh, round 5) and 4 loses 3 %: a wave that stores and exits frees its slot for one that loads — stores share the in-order vmcnt queue with the next tile's loads
 #endif
     constexpr int TPW = VSE_DWPW_TPW;
     const long m0 = (long)xcd_block(blockIdx.x, gridDim.x) * (128 * TPW) + wave * (32 * TPW);       // (XCD-contiguous block order: common.h)
