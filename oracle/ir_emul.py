@@ -315,6 +315,13 @@ class Emulator:
                 wmat = wmat + self.wread(int(r["w_off"]) + 2 * Np * Kp, Np * Kp, np.float16).astype(np.float32).reshape(Np, Kp)
             assert not wmat[:, cinp:].any()
             wmat = wmat[:, :cinp]
+        elif int(r["flags"]) & ir.F_COL and int(r["flags"]) & ir.F_HLSUM:
+            # 64-row stages [hi 32 | lo 32]: w = hi + lo (the kernel adds the two accumulator tiles)
+            assert cinp % 16 == 0 and Kp == kh * kw * cinp and Np <= 32 and (kh, kw) == (3, 3) and not int(r["flags"]) & ir.F_HILO
+            wt = self.wread(int(r["w_off"]), Kp * 64 + 3 * kh * 64 * 16, np.float16).astype(np.float32)
+            assert not wt[Kp * 64:].any()
+            w64 = np.ascontiguousarray(wt[:Kp * 64].reshape(cinp // 16, kw, kh, 64, 16).transpose(3, 2, 1, 0, 4)).reshape(64, Kp)
+            wmat = (w64[:32] + w64[32:])[:Np]
         elif int(r["flags"]) & ir.F_COL:
             assert cinp % 16 == 0 and Kp == kh * kw * cinp
             npass = 2 if int(r["flags"]) & ir.F_HILO else 1          # w = hi + lo (the lo stream follows the hi stream)

@@ -237,12 +237,16 @@ def test_recognizer_side_streams_keep_results(ctx, mode):
     assert torch.cuda.current_stream(ctx.tdev) == torch.cuda.default_stream(ctx.tdev)
 
 
-def test_text_recognizer_call_site(ctx):
+def test_text_recognizer_call_site(ctx, tmp_path):
     """paddleocr TextRecognizer(args)(img_list): ready-made crops of different sizes, grouped like the reference (sorted
     by w/h, chunks of rec_batch_num, padded to the chunk's widest) — checked against the oracle recogniser."""
     from types import SimpleNamespace
     from vse_amd import shim, synth
-    shim.config.allow_standin_weights = True
+    # the call site loads its weights by model id: hand it the oracle's CALIBRATED stand-ins as an .npz under config.weights_dir (the
+    # seeded stand-ins the shim would otherwise fall back to — modelzoo.random_weights, "values do not matter" — answer every input alike)
+    np.savez(tmp_path / "V4_en_rec_fast.npz", **net_ref.get_weights("V4_en_rec_fast")[1])
+    old_dir, shim.config.weights_dir = getattr(shim.config, "weights_dir", None), str(tmp_path)
+    shim.config.allow_standin_weights = False
     frames, truth = synth.make_frames(3, 720, 1280, seed=21, p_two_lines=1.0, return_truth=True)
     crops = []
     for f, tr in enumerate(truth):
@@ -268,9 +272,10 @@ def test_text_recognizer_call_site(ctx):
         ref = P.resize_norm_img(c, 640).transpose(1, 2, 0).astype(np.float16)
         assert np.array_equal(pre[i, ..., :3], ref), i
     from parity import check_text
-    # the oracle runs the weights THE CALL SITE loaded (shim._load_model: the seeded stand-ins of modelzoo, not net_ref's calibrated
-    # ones — until round 5 this test compared the two under a criterion loose enough not to notice)
+    # the oracle runs the weights THE CALL SITE loaded (until round 5 this test compared the shim's uncalibrated stand-ins with the
+    # oracle's calibrated ones under a criterion loose enough not to notice)
     rec = shim._load_model("V4_en_rec_fast")
+    assert all(np.array_equal(rec[1][k], v) for k, v in net_ref.get_weights("V4_en_rec_fast")[1].items())
     charset = P.en_charset()
     exact = 0
     for idx, img_w in P.rec_batches(crops, 3):
@@ -292,6 +297,8 @@ def test_text_recognizer_call_site(ctx):
     tr.pipe.rec_mode = "reference"
     assert tr(crops)[0] == got
     assert tr([])[0] == []
+    shim.config.weights_dir = old_dir
+    shim.config.allow_standin_weights = True
 
 
 def test_extractor_on_a_clip_engine_vs_oracle(ctx):

@@ -53,6 +53,34 @@ def _synthetic_maps(seed, n=3, h=160, w=256):
     return maps
 
 
+@pytest.mark.parametrize("w", [1024, 1027, 2500, 3840])
+def test_db_labels_across_row_segments(ctx, w):
+    """The label passes give a block one 1024-pixel SEGMENT of a row and start every text pixel on its run's first pixel inside that
+    segment (round 5); runs that cross a segment seam (x = 1024, 2048, ...), end on one, start on one, touch the map's last column or a
+    width that is not a multiple of 4 must still come out as ONE component each: boxes identical to the oracle's."""
+    import torch
+    h = 48
+    rng = np.random.default_rng(w)
+    maps = np.zeros((3, h, w), np.float32)
+    for f in range(3):
+        bars = [(4, 900, min(w, 1200)), (12, 1020, min(w, 1024)), (20, min(w - 40, 1024), w), (28, 8, w - 3), (36, 2040 % (w - 60), 2040 % (w - 60) + 40)]
+        for y0, xa, xb in bars:
+            if xb - xa < 6:
+                continue
+            maps[f, y0 + f:y0 + f + 5, xa:xb] = rng.uniform(0.7, 0.95)
+        maps[f, 2:46:9, 1023 % w] = 0.9                      # single pixels on a seam column
+        maps[f] += rng.uniform(0, 0.2, (h, w)).astype(np.float32) * (maps[f] == 0)
+    got = ctx.db_postprocess(torch.from_numpy(maps).cuda(), 2 * h, 2 * w)
+    total = 0
+    for f in range(3):
+        rb, rs = P.db_postprocess(maps[f], 2 * h, 2 * w)
+        gb, gs = got[f]
+        assert gb.shape == rb.shape and np.array_equal(gb, rb), (w, f, gb, rb)
+        assert np.abs(gs - rs).max() < 1e-6 if len(rs) else True
+        total += len(rb)
+    assert total >= 9
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_db_postprocess_matches_oracle(ctx, seed):
     import torch

@@ -209,6 +209,7 @@ DWPW = _dev_switch("VSE_DWPW", "1") != "0"                 # depthwise conv fuse
 # @68x120: 0.21 vs 0.14 ms: 25 taps of fp32 VALU work per 8 channels and lane, no window sharing between neighbouring pixels)
 # (5 x 5 filters lose fused — 25 taps per lane — and their kernel instantiations exist in development builds only)
 DWPW_K = tuple(int(v) for v in _dev_switch("VSE_DWPW_K", "3").split(",")) if os.environ.get("VSE_DEV_BUILD", "0") == "1" else (3,)
+HLSUM = _dev_switch("VSE_HLSUM", "1") != "0"              # 3x3 convs with <= 32 couts of a hi + lo net: hi | lo weight rows in one pass (F_HLSUM)
 SE_LATERAL = _dev_switch("VSE_SE_LATERAL", "1") != "0"   # 1x1 conv + SE block with shortcut -> one gated conv (F_OGATE)
 LSTM_MFMA = _dev_switch("VSE_LSTM_MFMA", "1") != "0"     # batch-shared MFMA recurrence (csrc/lstm.hip) for 256-unit LSTMs
 LSTM_WAVES = int(_dev_switch("VSE_LSTM_WAVES", "16"))    # 8: lstm_mfma_kernel, 16: lstm_mfma16_kernel (twice the loads in flight)
@@ -1330,6 +1331,19 @@ class Compiler(ChainMixin):
             Kp = rup(inv.span, 16)          # weight rows are whole 16-channel K slices (zero columns behind the channels)
             w_off = self.add_weights(("convpw", wname, tuple(inv.segs), ep["out_name"], self.hilo),
                                      lambda: self.pw_weights(self.pack_conv_weights(w, ep["scale"], inv)[0][:, :rup(inv.span, 16)], self.hilo))
+        elif col and self.hilo and HLSUM and (kh, kw) == (3, 3) and coutp <= 32:
+            # the 32-cout tile of conv_c3_kernel walks K twice for a hi + lo net with half its MFMA tile empty: ONE pass over a 64-row
+            # stage [hi 32 | lo 32] instead, the two accumulator tiles added in the epilogue (F_HLSUM)
+            Kp = kh * kw * inv.span
+            flags |= ir.F_HLSUM
+
+            def pack_hl():
+                mat = np.zeros((32, Kp), np.float64)
+                m0 = self.pack_conv_weights(w, ep["scale"], inv)[0]
+                mat[:m0.shape[0]] = m0[:, :Kp]
+                hi = mat.astype(np.float16).astype(np.float64)
+                return self.col_weights(np.concatenate([hi, mat - hi]), kh, kw, inv.span, False)
+            w_off = self.add_weights(("convc_hl", wname, tuple(inv.segs), ep["out_name"]), pack_hl)
         elif col:
             Kp = kh * kw * inv.span
             if self.hilo:

@@ -100,13 +100,14 @@ __device__ __forceinline__ void conv_c3_body(const ConvParams& p) {
     const half_t* const in_img = p.in + img * (long)p.Hs * p.Ws * p.in_ld;
     const half_t* wptr;
     bool wok;
-    const int winc = 3 * p.Np * 16;                        // elements per stage (wave-uniform; masked per lane at issue)
+    const int wnp = p.wnp;                                 // weight rows per tap (= Np; F_HLSUM: hi 32 | lo 32)
+    const int winc = 3 * wnp * 16;                         // elements per stage (wave-uniform; masked per lane at issue)
     {
         const int row = 32 * wave + (lane >> 1);
         const int kh_ = (lane & 1) ^ ((row >> 3) & 1);
         const int dy = row / BN, r = row - dy * BN;
-        wok = (row < WROWS) && (n0 + r < p.Np);
-        wptr = wok ? p.w + ((long)dy * p.Np + n0 + r) * 16 + kh_ * 8 : p.zero;
+        wok = (row < WROWS) && (n0 + r < wnp);
+        wptr = wok ? p.w + ((long)dy * wnp + n0 + r) * 16 + kh_ * 8 : p.zero;
     }
     auto issue_patch = [&](int cc) {
         half_t* base = patch0 + (cc & 1) * PATCH_HALFS;
@@ -292,6 +293,17 @@ __device__ __forceinline__ void conv_c3_body(const ConvParams& p) {
         const int oy = oy0 + 2 * rw + i, ox = ox0 + 32 * cw + fx;
         if (oy >= p.OH || ox >= p.OW) continue;
         const long m = (img * p.OH + oy) * p.OW + ox;
+        if constexpr (TN == 2) {
+            if (p.flags & F_HLSUM) {                     // tile 0 = W_hi x, tile 1 = W_lo x of the same 32 couts
+                float bias[16];
+                conv_epilogue_consts(sbias, 0, lane, bias);
+                float16v sum;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum[e] = acc[i][0][e] + acc[i][1][e];
+                conv_epilogue_tile(p, sum, bias, m, img, oy, ox, n0, lane);
+                continue;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float bias[16];
@@ -354,8 +366,11 @@ int launch_conv_c3(const ConvParams& pin, int n_img, hipStream_t st) {
     if (force == 8 || force == 4 || force == 2) rw = force;
 #endif
     const int cw = 8 / rw;
-    const int bn = p.Np <= 32 ? 32 : C3BN;
-    p.ntn = (unsigned)((p.Np + bn - 1) / bn);
+    const bool hlsum = (p.flags & F_HLSUM) != 0;
+    if (hlsum && (p.Np > 32 || (p.flags & F_HILO))) return VSE_E_INVAL;
+    const int bn = (p.Np <= 32 && !hlsum) ? 32 : C3BN;
+    p.wnp = hlsum ? 64 : p.Np;
+    p.ntn = hlsum ? 1u : (unsigned)((p.Np + bn - 1) / bn);
     p.tiles_h = (p.OH + 2 * rw - 1) / (2 * rw);
     p.tiles_w = (p.OW + 32 * cw - 1) / (32 * cw);
     const unsigned long long blocks = (unsigned long long)n_img * p.tiles_h * p.tiles_w * p.ntn;

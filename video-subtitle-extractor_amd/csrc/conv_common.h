@@ -39,6 +39,7 @@ struct ConvParams {
     int lo_off;             // != 0: fp16 hi + lo pair output: fp16(v - fp16(v)) goes lo_off channels behind the hi value
     const half_t* ogate;    // F_OGATE: per-(image, cout) gate [n][ogate_ld] fp16; the value is multiplied by (1 + gate) ahead of the residual
     int ogate_ld;
+    int wnp;                // conv_c3_kernel: weight rows per tap of a ring stage (= Np; F_HLSUM: 64 = hi 32 | lo 32 while Np stays 32)
     const uint8_t* u8src;   // F_U8SRC (stem): uint8 BGR frames [n][u8_h][u8_w][3], row pitch / frame stride in bytes
     int u8_h, u8_w;
     long u8_pitch, u8_fstride;

@@ -411,7 +411,7 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if ((o.flags & F_COL) && o.p[P_KH] == 3 && o.p[P_KW] == 3) {   // conv_c3_kernel<RW, 8 / RW>
         int rw;
         conv_c3_plan(o.out.h, o.out.w, &rw);
-        return 700000 + rw + (o.p[P_COUT] <= 32 ? 50000 : 0);      // + 50000: the 32-cout form conv_c3n32_kernel
+        return 700000 + rw + ((o.p[P_COUT] <= 32 && !(o.flags & F_HLSUM)) ? 50000 : 0);      // + 50000: the 32-cout form conv_c3n32_kernel (F_HLSUM: the 64-row form, hi | lo)
     }
     if (o.flags & F_COL) return 600000 + 100 * o.p[P_KH] + conv_col_bn(o.p[P_COUT]);   // conv_col_kernel<KH, BN>
     if (o.flags & F_PATCH) {   // conv_patch_kernel<TH, BN, BIGP> -> 100000*BIGP + 1000*TH + BN

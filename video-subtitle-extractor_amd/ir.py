@@ -88,6 +88,9 @@ F_DWPRE = 262144    # OP_CONV | F_PW | F_HILO: a depthwise k x k conv (+ bias + 
                     # post_a, post_b, table [k*k + 1][Kp] (last row = bias)], p[P_LO_IN] = pair offset of the INPUT
 F_ONECH = 32768     # OP_CONV with F_PIXSHUF | F_OUT_F32 and ONE real cout: the output is the 1-channel fp32 map itself (ld = 1); every
                     # lane's 8-channel run is one pixel-shuffle quad whose first channel is stored
+F_HLSUM = 524288    # OP_CONV | F_COL, 3x3, <= 32 couts of a hi + lo net (the mobile detectors' 96 -> 24 neck convs): ONE pass over K with the lo
+                    # weights as 32 more weight rows of a 64-row stage ([3 dy][hi 32 | lo 32][16]); conv_c3_kernel adds its two 32-cout
+                    # accumulator tiles in the epilogue (instead of walking the patch chunks twice over a half-empty 32-cout tile)
 F_COL = 2048        # column-per-step LDS-patch kernel (conv_col.hip): weights packed [cinp/16][kw][kh][Np][16] + 3 zero stages
 F_UP2HEAD = 64      # F_SRC2 | F_DOT1 3x3 conv over [1-channel full-res map, x2-upsampled 64-channel map] evaluated on the LOW-RES
                     # grid: weights packed [chunk][parity][2x2 tap][Np][32] + [Np][32] for the 1-channel source (conv_head.hip)
