@@ -390,6 +390,11 @@ def test_mobile_detector_chains_and_gated_laterals(mid):
     gated = [o for o in prog.ops if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_OGATE]
     assert len(gated) == 4 and sum(bool(int(o["flags"]) & ir.F_RES) for o in gated) == 3      # four laterals, three top-down adds
     assert ir.OP_SCALE not in [int(o["kind"]) for o in prog.ops if int(o["out"]["c"]) == 96]        # no 96-channel SE multiply is left
+    # the neck's 3x3 96 -> 24 convs take their hi and lo weights in ONE pass (64-row stages [hi 32 | lo 32], F_HLSUM) in both programs
+    # (at the reference's detector input size: on this test's small maps they fall to the implicit GEMM)
+    for pr in (compiler.compile_model(desc, w, 1, 544, 960, hilo=True), compiler.compile_model(desc, w, 1, 544, 960, hilo=True, chain=False)):
+        hl = [o for o in pr.ops if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_HLSUM]
+        assert len(hl) == 4 and all(int(o["p"][ir.P_KH]) == 3 and int(o["p"][ir.P_COUT]) <= 32 and not int(o["flags"]) & ir.F_HILO for o in hl)
     for o in chains:
         hdr = np.frombuffer(bytes(prog.weights.blob[int(o["w_off"]):int(o["w_off"]) + 4 * ir.CH_HDR]), np.int32)
         assert hdr[ir.CHH_MAGIC] == ir.CH_MAGIC and 2 <= hdr[ir.CHH_NSTAGES] <= 8 and hdr[ir.CHH_LDS_TOTAL] <= 160 * 1024
