@@ -384,6 +384,7 @@ static void launch_cfg(const ConvParams& p, int mode, dim3 grid, hipStream_t st)
 int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st) {
     const int mode = conv_gemm_mode(p.kh, p.kw, p.sh, p.sw, p.ph, p.pw, p.cinp, Kp, p.inshift, p.flags);
     if (!mode) return VSE_E_UNSUPPORTED;
+    p.nkh = Kp / ((p.flags & F_WK32) ? 32 : 64);                         // (K tiles of one weight pass, as conv_smallm.hip walks them)
     if (conv_smallm_ok(p, mode)) return launch_conv_smallm(p, st);       // a handful of pixels (SE gates): conv_smallm.hip
     // 32-bit offsets: the rows of one block span at most BM output pixels (+ one image seam), the tap walk kh rows
     const double span = ((double)512 * p.sw + (512.0 / p.OW + 3) * p.sh * p.Ws + (double)p.kh * p.Ws + p.kw) * p.in_ld * 2;

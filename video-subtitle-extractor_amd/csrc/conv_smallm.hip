@@ -15,9 +15,8 @@
 
 #define SM_UNROLL 8
 
-template <int KT>
-__global__ __launch_bounds__(64) void conv_smallm_kernel(const ConvParams p) {
-    __shared__ float sbias[32];
+template <int KT, bool HILO>       // HILO (round 5, the mobile detectors' SE convs): the lo weight tiles follow the hi tiles; K is walked twice
+__device__ __forceinline__ void conv_smallm_body(const ConvParams& p, float* sbias) {
     const int lane = threadIdx.x;
     const int fx = lane & 31, fj = lane >> 5;
     const int n0 = blockIdx.x * 32;                          // first cout of this wave
@@ -37,17 +36,22 @@ __global__ __launch_bounds__(64) void conv_smallm_kernel(const ConvParams p) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const half8 zero8 = half8{0, 0, 0, 0, 0, 0, 0, 0};
     const int nslice = p.cinp >> 4;
-    for (int s0 = 0; s0 < nslice; s0 += SM_UNROLL) {
-        half8 wf[SM_UNROLL], xf[SM_UNROLL];
+    // (hi pass, then lo pass over the same activations into the same accumulator: conv_gemm_kernel's two-pass K walk, identical bits)
+#pragma unroll 1
+    for (int pass = 0; pass < (HILO ? 2 : 1); ++pass) {
+        const half_t* wp = wl + (long)pass * p.nkh * wstep;
+        for (int s0 = 0; s0 < nslice; s0 += SM_UNROLL) {
+            half8 wf[SM_UNROLL], xf[SM_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SM_UNROLL; ++u) {
-            const int k = (s0 + u) << 4;
-            const bool live = s0 + u < nslice;
-            wf[u] = (live && wok) ? *reinterpret_cast<const half8*>(wl + (long)(k / KT) * wstep + (k % KT)) : zero8;
-            xf[u] = (live && xok) ? *reinterpret_cast<const half8*>(xl + k) : zero8;
+            for (int u = 0; u < SM_UNROLL; ++u) {
+                const int k = (s0 + u) << 4;
+                const bool live = s0 + u < nslice;
+                wf[u] = (live && wok) ? *reinterpret_cast<const half8*>(wp + (long)(k / KT) * wstep + (k % KT)) : zero8;
+                xf[u] = (live && xok) ? *reinterpret_cast<const half8*>(xl + k) : zero8;
+            }
+#pragma unroll
+            for (int u = 0; u < SM_UNROLL; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[u], xf[u], acc, 0, 0, 0);
         }
-#pragma unroll
-        for (int u = 0; u < SM_UNROLL; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[u], xf[u], acc, 0, 0, 0);
     }
     __syncthreads();
     if (xok) {
@@ -60,10 +64,21 @@ __global__ __launch_bounds__(64) void conv_smallm_kernel(const ConvParams p) {
     }
 }
 
+template <int KT>
+__global__ __launch_bounds__(64) void conv_smallm_kernel(const ConvParams p) {
+    __shared__ float sbias[32];
+    conv_smallm_body<KT, false>(p, sbias);
+}
+template <int KT>
+__global__ __launch_bounds__(64) void conv_smallm_hl_kernel(const ConvParams p) {
+    __shared__ float sbias[32];
+    conv_smallm_body<KT, true>(p, sbias);
+}
+
 // Layers this kernel serves: conv_gemm_kernel's unmasked 1x1 mode (mode 2) at stride 1 with at most 256 pixels, one weight stream.
 bool conv_smallm_shape_ok(int mode, long M, int sh, int sw, int same_hw, int flags, int cinp) {
     static const bool on = [] { const char* e = vse_dev_getenv("VSE_SMALLM"); return !(e && e[0] == '0'); }();
-    return on && mode == 2 && M <= 256 && sh == 1 && sw == 1 && same_hw && !(flags & (F_HILO | F_IMGW | F_PIXSHUF | F_DOT1 | F_SRC2)) && (cinp & 15) == 0;
+    return on && mode == 2 && M <= 256 && sh == 1 && sw == 1 && same_hw && !(flags & (F_IMGW | F_PIXSHUF | F_DOT1 | F_SRC2)) && (cinp & 15) == 0;
 }
 bool conv_smallm_ok(const ConvParams& p, int mode) {
     return conv_smallm_shape_ok(mode, p.M, p.sh, p.sw, p.H == p.OH && p.W == p.OW && p.Hs == p.H && p.Ws == p.W, p.flags, p.cinp);
@@ -71,7 +86,10 @@ bool conv_smallm_ok(const ConvParams& p, int mode) {
 
 int launch_conv_smallm(const ConvParams& p, hipStream_t st) {
     const dim3 grid((unsigned)((p.Np + 31) / 32), (unsigned)((p.M + 31) / 32)), block(64);
-    if (p.flags & F_WK32) hipLaunchKernelGGL((conv_smallm_kernel<32>), grid, block, 0, st, p);
+    if (p.flags & F_HILO) {
+        if (p.flags & F_WK32) hipLaunchKernelGGL((conv_smallm_hl_kernel<32>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv_smallm_hl_kernel<64>), grid, block, 0, st, p);
+    } else if (p.flags & F_WK32) hipLaunchKernelGGL((conv_smallm_kernel<32>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((conv_smallm_kernel<64>), grid, block, 0, st, p);
     return hipGetLastError() == hipSuccess ? VSE_OK : VSE_E_HIP;
 }

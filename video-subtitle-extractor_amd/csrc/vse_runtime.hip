@@ -428,7 +428,7 @@ int vse_plan_op_variant(vse_plan* p, int i) {
         long m = (long)o.out.n * o.out.h * o.out.w;
         if (o.flags & F_PIXSHUF) m /= 4;
         if (conv_smallm_shape_ok(mode, m, o.p[P_SH], o.p[P_SW], o.in0.h == o.out.h && o.in0.w == o.out.w, o.flags, o.p[P_CINP]))
-            return 900000 + ((o.flags & F_WK32) ? 32 : 64);            // conv_smallm_kernel<KT>
+            return 900000 + ((o.flags & F_WK32) ? 32 : 64) + ((o.flags & F_HILO) ? 1000 : 0);   // conv_smallm_kernel<KT> (+ 1000: conv_smallm_hl_kernel)
         return 200000 + 10 * conv_gemm_config(o.p[P_COUT], o.p[P_CINP], m) + (mode == 1 ? 1 : 0);
     }
     return (o.p[P_INSHIFT] ? 10000 : 0) + conv_tile_bn(o.p[P_COUT]);
@@ -447,7 +447,8 @@ const char* vse_plan_op_kernel_name(vse_plan* p, int i) {
         return buf;
     }
     const int code = vse_plan_op_variant(p, i);
-    if (code >= 900000) snprintf(buf, sizeof buf, "conv_smallm_kernel<%d>", code - 900000);
+    if (code >= 901000) snprintf(buf, sizeof buf, "conv_smallm_hl_kernel<%d>", code - 901000);
+    else if (code >= 900000) snprintf(buf, sizeof buf, "conv_smallm_kernel<%d>", code - 900000);
     else if (code >= 850000) snprintf(buf, sizeof buf, "conv_dwpw_kernel<%d, %d, %s>", (code - 850000) / 10, code % 10, o.p[P_LO_IN] ? "true" : "false");
     else if (code >= 800000) snprintf(buf, sizeof buf, "conv_pw_kernel<%d>", code - 800000);
     else if (code >= 750000) snprintf(buf, sizeof buf, "conv_c3n32_kernel<%d, %d>", code - 750000, 8 / (code - 750000));
