@@ -258,7 +258,14 @@ class Emulator:
         p, f = r["p"], r["f"]
         kh, kw, sh, sw, ph, pw = (int(p[i]) for i in range(6))
         Np, Kp, cinp = int(p[ir.P_COUT]), int(p[ir.P_KTOT]), int(p[ir.P_CINP])
-        x = self._up(self.read(r["in0"]), int(p[ir.P_INSHIFT]))
+        v0 = r["in0"]
+        if int(r["flags"]) & ir.F_UP2HEAD and int(v0["ld"]) == 1:
+            # the dense 1-channel map of an F_TAIL2 conv (nominal span 8, ld = 1): the head reads channel 0 at pixel stride 1
+            v0 = v0.copy()
+            v0["c"] = 1
+            x = F.pad(self.read(v0), (0, 7))
+        else:
+            x = self._up(self.read(v0), int(p[ir.P_INSHIFT]))
         if int(r["flags"]) & ir.F_SRC2:
             x = torch.cat([x, self._up(self.read(r["in2"]), int(p[ir.P_IN2SHIFT]))], dim=3)
         assert x.shape[3] == cinp
@@ -270,7 +277,7 @@ class Emulator:
             wx = wt[:2 * 4 * 4 * 64 * 32].reshape(2, 4, 4, 64, 32)
             wu = torch.from_numpy(wt[2 * 4 * 4 * 64 * 32:].reshape(64, 32)[:Np, :9].reshape(Np, 1, 3, 3).copy())
             xl = self.read(r["in2"]).permute(0, 3, 1, 2)                      # [n,64,Hl,Wl]
-            u = self.read(r["in0"])[..., 0:1].permute(0, 3, 1, 2)            # [n,1,2Hl,2Wl]
+            u = x[..., 0:1].permute(0, 3, 1, 2)                              # [n,1,2Hl,2Wl]
             n, _, Hl, Wl = xl.shape
             y = F.conv2d(u, wu, None, 1, 1)                                   # [n,Np,2Hl,2Wl]
             xp = F.pad(xl, (1, 1, 1, 1))
@@ -390,6 +397,36 @@ class Emulator:
             return
         oc = int(r["out"]["c"])
         self.write_pair(r["out"], int(p[ir.P_LO_OUT]), y[..., :oc] if y.shape[3] >= oc else F.pad(y, (0, oc - y.shape[3])))
+        if flags & ir.F_TAIL2:
+            # the second 2x2 s2 transposed conv (-> ONE channel) on the fp16 values just stored (csrc/conv_pw.hip, conv_pw_tail_kernel):
+            # decoded from stage B's MFMA fragments [Np / 16][2][16][8] — a block-diagonal [16][Np] matrix, row 4 r + c, column
+            # (2 dy + dx) * cp + co, non-zero where (r >> 1, c >> 1) = (dy, dx), value w2[co][r & 1][c & 1] in every block
+            assert flags & ir.F_PW and flags & ir.F_PIXSHUF and not flags & (ir.F_HILO | ir.F_RES | ir.F_DOT1) and Np % 32 == 0
+            cp, nks2 = Np // 4, Np // 16
+            fr = self.wread(int(r["aux_off"]), nks2 * 2 * 16 * 8, np.float16).astype(np.float32).reshape(nks2, 2, 16, 8)
+            fx = np.arange(16)
+            rows = (fx & ~12) | ((fx & 4) << 1) | ((fx & 8) >> 1)
+            wb = np.zeros((16, Np), np.float32)
+            for s_ in range(nks2):
+                for fj in range(2):
+                    wb[rows, s_ * 16 + fj * 8:s_ * 16 + fj * 8 + 8] = fr[s_, fj]
+            w2 = np.zeros((cp, 1, 2, 2), np.float32)
+            for r_ in range(4):
+                for c_ in range(4):
+                    q = ((r_ >> 1) * 2 + (c_ >> 1)) * cp
+                    blk = wb[4 * r_ + c_].copy()
+                    if q == 0:
+                        w2[:, 0, r_ & 1, c_ & 1] = blk[:cp]
+                    assert np.array_equal(blk[q:q + cp], w2[:, 0, r_ & 1, c_ & 1]), "stage B is not the same 2x2 filter in every sub-pixel block"
+                    blk[q:q + cp] = 0
+                    assert not blk.any(), "stage B is not block-diagonal"
+            yf = y.half().float() if self.round else y
+            z = F.conv_transpose2d(yf.permute(0, 3, 1, 2), torch.from_numpy(w2), stride=2).permute(0, 2, 3, 1) + float(f[ir.FS_PRE_B])
+            z = _act(z, int(p[ir.P_DOTACT]))
+            v2 = r["out2"].copy()
+            assert int(v2["ld"]) == 1 and int(v2["esize"]) == 2
+            v2["c"] = 1
+            self.write(v2, z)
 
     def _op2(self, r):   # DWCONV
         p, f = r["p"], r["f"]

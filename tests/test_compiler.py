@@ -471,3 +471,30 @@ def test_gated_lateral_falls_back_when_something_rides_behind_the_se_add(tail):
         assert len(gated) == 0, (tail, len(gated))    # (a `scale` op is lowered on its own: the gated conv in front of it stays valid)
     got = np.transpose(ir_emul.Emulator(prog).run(ir_emul.to_nhwc8(x))[0][..., :24], (0, 3, 1, 2))
     assert np.abs(got - ref).max() < 5e-3 * max(1.0, np.abs(ref).max()), (tail, np.abs(got - ref).max())
+
+
+def test_head_tail_fusion_and_its_fallback(monkeypatch):
+    """F_TAIL2: the server detector's second head deconv (64 -> 1, the base map) rides in the first one's launch and its map is stored
+    densely (ld 1) for the F_UP2HEAD conv.  The emulator decodes stage B from the MFMA fragments the kernel reads; with fp16 rounding
+    of every stored tensor the fused and the separate programs give the same map.  A graph whose dense map would reach any other
+    reader (here: the head kernel switched off) compiles with the two launches instead (Tail2Unsupported -> retry)."""
+    desc, w = net_ref.get_weights("V4_ch_det")
+    x = np.random.default_rng(3).uniform(-1, 1, (1, 3, 64, 96)).astype(np.float16).astype(np.float32)
+    outs = {}
+    for t2 in (None, False):
+        prog = compiler.compile_model(desc, w, 1, 64, 96, tail2=t2)
+        tails = [o for o in prog.ops if int(o["flags"]) & ir.F_TAIL2]
+        assert len(tails) == (1 if t2 is None else 0)
+        if tails:
+            o = tails[0]
+            assert int(o["flags"]) & ir.F_PW and int(o["flags"]) & ir.F_PIXSHUF and int(o["out2"]["ld"]) == 1 and int(o["out2"]["esize"]) == 2
+            assert (int(o["out2"]["h"]), int(o["out2"]["w"])) == (64, 96)
+            head = [q for q in prog.ops if int(q["flags"]) & ir.F_UP2HEAD]
+            assert len(head) == 1 and int(head[0]["in0"]["ld"]) == 1 and int(head[0]["in0"]["off"]) == int(o["out2"]["off"])
+        outs[t2] = ir_emul.Emulator(prog, round_f16=True).run(ir_emul.to_nhwc8(x))[0]
+    assert np.abs(outs[None] - outs[False]).max() < 2e-6 and outs[None].std() > 0
+    monkeypatch.setattr(compiler, "HEAD_UP2", False)
+    prog = compiler.compile_model(desc, w, 1, 64, 96)
+    assert not any(int(o["flags"]) & (ir.F_TAIL2 | ir.F_UP2HEAD) for o in prog.ops)
+    ref = net_ref.run_graph(desc, w, x)[0].numpy()[:, 0]
+    assert np.abs(ir_emul.Emulator(prog).run(ir_emul.to_nhwc8(x))[0][..., 0] - ref).max() < 5e-3

@@ -362,6 +362,29 @@ def test_wide_3x3_route_gives_identical_bits():
     assert out["0"] == out["1"]
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 160), (1, 160, 224), (3, 96, 224), (2, 544, 960)])
+def test_head_tail_fusion_gives_identical_bits(ctx, shape):
+    """F_TAIL2 (conv_pw_tail_kernel): the server detector's second head deconv (64 -> 1, the base map) inside the launch of the first,
+    the map stored densely (ld 1) and read by conv_head_up2r_kernel at pixel stride 1 — every output bit equals the two separate
+    conv_pw launches (tail2=False), odd tile edges and the full detector input size included."""
+    import torch
+    from vse_amd import engine, ir
+    desc, w = net_ref.get_weights("V4_ch_det")
+    n, h, wd = shape
+    x = np.random.default_rng(7).uniform(-1, 1, (n, 3, h, wd)).astype(np.float32)
+    xt = torch.from_numpy(ir_emul.to_nhwc8(x).astype(np.float16)).cuda()
+    outs = {}
+    for t2 in (None, False):
+        net = engine.Net(ctx, desc, w, tail2=t2)
+        fused = [int(r["flags"]) & ir.F_TAIL2 for r in net.program(n, h, wd).ops]
+        assert any(fused) == (t2 is None)
+        outs[t2] = [o.cpu().numpy() for o in net.run(xt)]
+    assert len(outs[None]) == len(outs[False])
+    for a, b in zip(outs[None], outs[False]):
+        assert a.tobytes() == b.tobytes()
+    assert outs[None][0].std() > 0
+
+
 def test_detector_head_forms_are_identical_and_race_free():
     """The server detector's last conv has two kernels — the streaming one and the persistent resident-weight one (the default):
     same bits on five shapes, and the same bits every time beside unrelated work on another stream (tools/race_screen_det.py)."""

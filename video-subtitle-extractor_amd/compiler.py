@@ -70,6 +70,7 @@ class View:
     up: int = 0                    # virtual nearest-upsample shift (logical h,w already upsampled)
     tag: str = "nchw"              # logical layout of the Paddle tensor this view stands for
     parts: Optional[list] = None   # virtual 2-way concat: [View, View] gathered by the consumer conv (no copy)
+    dense1: bool = False           # ONE channel stored densely (buffer ld = 1) behind a nominal 8-channel span: only F_UP2HEAD reads it (F_TAIL2)
     gate: Optional[tuple] = None   # (gate View, flags): the tensor is  this * gate  (F_RES: this * (1 + gate)), not yet multiplied — an SE
                                    # output whose only reader is a concat: the copy into the slot applies it (lower_concat)
 
@@ -193,6 +194,7 @@ COL3 = _dev_switch("VSE_COL3", "1") != "0"
 COL3_MAX_COUT = int(_dev_switch("VSE_COL3_MAXCOUT", "192"))     # per-layer A/B (tools/bench_conv.py --cfgs d,p,c): 224-cout layers tie or lose
 PW = _dev_switch("VSE_PW", "1") != "0"             # conv_pw_kernel for 1x1 convs (and 2x2 s2 transposed convs) over <= 64 input channels
 PW_MAX_COUT = int(_dev_switch("VSE_PW_MAXCOUT", "64"))
+TAIL2 = _dev_switch("VSE_TAIL2", "1") != "0"       # the server detector's second head deconv inside the first one's launch (F_TAIL2)
 COL3_MIN_K = int(_dev_switch("VSE_COL3_MINK", "250"))   # 3x3 32->32 @136x240 (K = 288): 0.180 ms on the implicit GEMM, 0.115 ms here
 COL3_WIDE_MIN_CIN = 128    # layers with more than 64 couts (two+ cout tiles refetch the patch) only from 128 input channels on
 COL3_MIN_TILE_EFF = float(_dev_switch("VSE_COL3_MINEFF", "0.8"))
@@ -234,6 +236,11 @@ class GatedConvUnsupported(UnsupportedGraph):
     retries the graph WITHOUT that rewrite (the rewrite itself cannot be undone on a half-lowered graph)."""
 
 
+class Tail2Unsupported(UnsupportedGraph):
+    """The dense 1-channel map an F_TAIL2 conv writes (ld = 1) reached a consumer other than the F_UP2HEAD conv that reads it at pixel
+    stride: compile_model retries the graph with the two transposed convs as separate launches."""
+
+
 # Attribute values the lowering hard-codes (every graph under backend/models/ satisfies them, SURVEY App. E).  A descriptor
 # converted from another export (SAME padding, dilated convs, align_corners resize ...) must fail here, loudly, instead of
 # compiling into something that silently computes different values.  A missing attribute means the Paddle default.
@@ -271,8 +278,9 @@ def check_attrs(ops):
 
 class Compiler(ChainMixin):
     def __init__(self, desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True,
-                 store=None, reuse=True, se_lateral=None):
+                 store=None, reuse=True, se_lateral=None, tail2=None):
         self.desc = desc
+        self.tail2 = tail2                    # False: never fuse the head's second transposed conv into the first (F_TAIL2)
         self.W = dict(weights)
         self.ops = list(desc["ops"])
         check_attrs(self.ops)
@@ -734,6 +742,9 @@ class Compiler(ChainMixin):
             lin, lout = self._ragged_levels(kind, name, ins, out, out2, flags, rec["p"])
             rec["p"][ir.P_WLIN] = 0 if lin is None else lin + 1
             rec["p"][ir.P_WLOUT] = 0 if lout is None else lout + 1
+        for v in ins:
+            if v is not None and v.dense1 and not (kind == ir.OP_CONV and flags & ir.F_UP2HEAD and v is ins[0]):
+                raise Tail2Unsupported(f"{name} reads the dense 1-channel map of an F_TAIL2 conv")
         for v in list(ins) + [out, out2]:
             if v is not None and v.buf is not None:
                 v.buf.first = min(v.buf.first, idx)
@@ -1144,6 +1155,35 @@ class Compiler(ChainMixin):
         ublock[:, :9] = wu.reshape(64, 9)
         return np.concatenate([out.reshape(-1), ublock.reshape(-1)]).astype(np.float16)
 
+    def _tail2_candidate(self, name, c1):
+        """`name` = the output (behind its BN / activation) of a 2x2 s2 transposed conv with c1 couts.  If ONE of its readers is a second
+        2x2 s2 transposed conv c1 -> 1 whose own output (behind its activation) is read only as the FIRST part of a virtual concat — the
+        PP-OCRv4 server detector's base map in front of the local refinement conv — claim that conv and its epilogue and return
+        {ep, w, wname}; else None with nothing changed."""
+        cons = [k for k in self._live_consumers(name) if self.ops[k]["type"] == "conv2d_transpose" and self.ops[k]["in"]["Input"][0] == name
+                and k not in self.done]
+        if len(cons) != 1 or name in self.fetched_names:
+            return None
+        k = cons[0]
+        op1 = self.ops[k]
+        a1 = op1["attrs"]
+        wn = op1["in"]["Filter"][0]
+        w2 = self.W[wn]
+        if tuple(w2.shape) != (c1, 1, 2, 2) or list(a1["strides"]) != [2, 2] or any(a1["paddings"]) or a1.get("groups", 1) != 1:
+            return None
+        snapshot = set(self.done)
+        ep2 = self.absorb_epilogue(op1["out"]["Output"][0], k, 1, allow_res=False)
+        fc = self._live_consumers(ep2["out_name"])
+        ok = (ep2["post_a"] == 1.0 and ep2["post_b"] == 0.0 and ep2["act2"] == ir.ACT_NONE and ep2["act"] in (ir.ACT_NONE, ir.ACT_SIGMOID, ir.ACT_RELU)
+              and ep2["out_name"] not in self.fetched_names and ep2["out_name"] not in self.placement and len(fc) == 1
+              and self.ops[fc[0]]["type"] == "concat" and self.ops[fc[0]]["out"]["Out"][0] in self.virtual_concats
+              and self.ops[fc[0]]["in"]["X"][0] == ep2["out_name"] and len(self.ops[fc[0]]["in"]["X"]) == 2)
+        if not ok:
+            self.done = snapshot
+            return None
+        self.done.add(k)
+        return dict(ep=ep2, w=w2, wname=wn)
+
     def lower_conv(self, i):
         op = self.ops[i]
         a = op["attrs"]
@@ -1194,7 +1234,38 @@ class Compiler(ChainMixin):
                 tflags |= ir.F_OUT_F32 | ir.F_ONECH
             else:
                 out = self.alloc_out(ep["out_name"], inv.n, oh, ow, cout)
-            if PW and inv.span % 8 == 0 and inv.span <= 64 and 4 * coutp <= (128 if self.hilo else 256) and inv.up == 0:
+            pw_ok = PW and inv.span % 8 == 0 and inv.span <= 64 and 4 * coutp <= (128 if self.hilo else 256) and inv.up == 0
+            tail = None
+            if (pw_ok and TAIL2 and self.tail2 is not False and not self.hilo and not self.ragged and inv.span in (32, 64) and cout > 1
+                    and (4 * coutp) % 32 == 0 and not (tflags & ir.F_ONECH) and ep["post_a"] == 1.0 and ep["post_b"] == 0.0
+                    and ep["act2"] == ir.ACT_NONE and out.buf.lo_off == 0):
+                tail = self._tail2_candidate(ep["out_name"], cout)
+            out2, aux_off, tp, tf = None, 0, {}, {}
+            if tail is not None:
+                # the head's SECOND transposed conv (c1 -> 1, 2x2 s2, + activation) in this launch (F_TAIL2, conv_pw_tail_kernel): stage B
+                # = a block-diagonal 1x1 conv over this op's 4 coutp channels (dy, dx, co) -> 16 outputs 4 r + c = pixel (4 y + r, 4 x + c)
+                # of the map, r = 2 dy + ey, c = 2 dx + ex; its fp16 weights are the separate launch's (w2 * scale2 rounded once)
+                ep2, w2 = tail["ep"], tail["w"].astype(np.float64) * float(tail["ep"]["scale"][0])
+                wb = np.zeros((16, 4 * coutp), np.float64)
+                for r in range(4):
+                    for c in range(4):
+                        q = ((r >> 1) * 2 + (c >> 1)) * coutp
+                        wb[4 * r + c, q:q + cout] = w2[:, 0, r & 1, c & 1]
+                fx = np.arange(16)
+                rows = (fx & ~12) | ((fx & 4) << 1) | ((fx & 8) >> 1)           # conv_wrow: the cout row MFMA row fx carries
+                nks2 = 4 * coutp // 16
+                frag = np.zeros((nks2, 2, 16, 8), np.float16)
+                for s_ in range(nks2):
+                    for fj in range(2):
+                        frag[s_, fj] = wb[rows][:, s_ * 16 + fj * 8:s_ * 16 + fj * 8 + 8].astype(np.float16)
+                aux_off = self.add_weights(("convTtail", wname, tail["wname"], ep2["out_name"]), frag.reshape(-1))
+                ub = self.new_buf(inv.n, 2 * oh, 2 * ow, 1, esize=2)
+                out2 = View(ub, 0, inv.n, 2 * oh, 2 * ow, [(0, 1)], 8, dense1=True)
+                tflags |= ir.F_TAIL2
+                tp = {ir.P_DOTACT: ep2["act"]}
+                tf = {ir.FS_PRE_B: float(np.float32(ep2["shift"][0]))}
+                assert ep2["act"] in (ir.ACT_NONE, ir.ACT_SIGMOID, ir.ACT_RELU), ep2      # (activations without parameters: the kernel passes none)
+            if pw_ok:
                 # few input channels: conv_pw_kernel streams the pixels straight from global memory (pixel-shuffle store as ever);
                 # hi + lo weights: two tables, the K slices walked twice over the same activation fragments
                 tflags |= ir.F_PW
@@ -1207,11 +1278,14 @@ class Compiler(ChainMixin):
             self.emit(ir.OP_CONV, ep["out_name"], [inv], out, flags=tflags,
                       p={ir.P_KH: 1, ir.P_KW: 1, ir.P_SH: 1, ir.P_SW: 1, ir.P_PH: 0, ir.P_PW: 0,
                          ir.P_ACT: ep["act"], ir.P_ACT2: 0, ir.P_COUT: 4 * coutp, ir.P_KTOT: Kp,
-                         ir.P_INSHIFT: 0, ir.P_RESSHIFT: 0, ir.P_CINP: inv.span},
+                         ir.P_INSHIFT: 0, ir.P_RESSHIFT: 0, ir.P_CINP: inv.span, **tp},
                       f={ir.FS_ACT_A: ep["act_a"], ir.FS_ACT_B: ep["act_b"], ir.FS_POST_A: ep["post_a"],
-                         ir.FS_POST_B: ep["post_b"]}, w_off=w_off, b_off=b_off)
+                         ir.FS_POST_B: ep["post_b"], **tf}, w_off=w_off, b_off=b_off, aux_off=aux_off, out2=out2)
             self.add_gmacs(inv.n * inv.h * inv.w * cin * cout * 4 / 1e9)
             self.env[ep["out_name"]] = out
+            if tail is not None:
+                self.add_gmacs(inv.n * oh * ow * cout * 4 / 1e9)
+                self.env[tail["ep"]["out_name"]] = out2
             return
         cout, cin, kh, kw = w.shape
         assert cin == inv.c, (cin, inv.c, outname)
@@ -2177,14 +2251,14 @@ class Compiler(ChainMixin):
 
 
 def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True, hilo=False,
-                  ragged=False, input_norm=None, fuse_preprocess=False, chain=None):
+                  ragged=False, input_norm=None, fuse_preprocess=False, chain=None, tail2=None):
     """reuse=False gives every buffer its own workspace range (debugging: all intermediates stay readable).
     hilo=True stores every conv / depthwise / transposed-conv weight as an fp16 hi + lo pair (F_HILO): ~22-bit weights for
     twice the MFMA work — for nets whose boxes must track an fp32 reference closely.
     ragged=True (recognisers): `width` is the widest sample of the batch; the plan runs with a per-sample width table
     (Program.width_table) and every sample gets the values a batch of its own width would have produced, bit for bit."""
-    def build(se_lateral):
-        c = Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse, se_lateral=se_lateral)
+    def build(se_lateral, tail2=tail2):
+        c = Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse, se_lateral=se_lateral, tail2=tail2)
         c.ragged = bool(ragged)
         c.hilo = bool(hilo)
         c.input_norm = input_norm      # (mean3, std3): the plan takes RAW resized pixels + a ones channel (Compiler.fold_input_norm)
@@ -2195,9 +2269,14 @@ def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_pro
             c.use_patch = False          # conv_patch_kernel has no two-pass K walk (the implicit-GEMM, stem and column kernels do)
         return c.compile()
     try:
-        return build(None)
+        try:
+            return build(None)
+        except Tail2Unsupported:
+            # the dense map of an F_TAIL2 conv met a reader that cannot take it: the two transposed convs as separate launches
+            tail2 = False
+            return build(None, False)
     except GatedConvUnsupported:
         # _rewrite_se_laterals turned a 1x1 conv + SE block into a gated conv whose surroundings the epilogue cannot express (an affine or
         # an activation behind the SE add, a gate shape, a kernel family): the graph compiled before that rewrite existed — compile it
         # without the rewrite instead of refusing it
-        return build(False)
+        return build(False, tail2)

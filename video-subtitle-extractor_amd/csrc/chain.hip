@@ -485,7 +485,8 @@ __global__ __launch_bounds__(256, 3) void chain_pw2_kernel(const Pw2Args a) {
     {
         const int nb16 = D[3] >> 4;
         const int4* __restrict__ wsrc = reinterpret_cast<const int4*>(a.blob + D[4]);
-        for (int i = tid; i < nb16; i += 256) reinterpret_cast<int4*>(lds)[i] = wsrc[i];
+        // (all of a thread's loads in flight before its first LDS write: stage_batched, common.h)
+        stage_batched<8>(nb16, tid, [&](int i) { return wsrc[i]; }, [&](int i, int4 x) { reinterpret_cast<int4*>(lds)[i] = x; });
     }
     const int nksA = SA[S_NKS], nctA = SA[S_NCT], coutA = SA[S_COUT], actA = SA[S_ACT], hasloA = SA[S_HASLO];
     const float actA_a = __int_as_float(SA[S_ACT_A]), actA_b = __int_as_float(SA[S_ACT_B]);

@@ -13,7 +13,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_SWISH = 3, ACT_SIGMOID = 4, ACT_HSIGMOID = 5 };
 enum { OP_CONV = 1, OP_DWCONV, OP_POOL, OP_GAP, OP_SCALE, OP_BINARY, OP_RESIZE, OP_UNARY, OP_LAYERNORM, OP_ATTN,
        OP_SOFTMAX, OP_LSTM, OP_WSCALE, OP_CHAIN };   // OP_CHAIN: 1x1 / depthwise conv chain with LDS-resident intermediates (chain.hip)
-enum { F_LSTM_MFMA = 16384, F_ONECH = 32768, F_U8SRC = 65536, F_OGATE = 131072, F_DWPRE = 262144, F_HLSUM = 524288 };   // F_HLSUM: hi | lo weight rows in one 64-row stage, accumulator tiles added (see ir.py)   // F_DWPRE: depthwise conv fused in front of a 1x1 conv (conv_dwpw.hip)   // F_OGATE: in2 = per-image output gate (see ir.py)   // F_U8SRC: the stem conv resizes the uint8 BGR frames itself (see ir.py)   // F_ONECH: pixel-shuffle conv to one channel stores the fp32 map itself (see ir.py)
+enum { F_LSTM_MFMA = 16384, F_ONECH = 32768, F_U8SRC = 65536, F_OGATE = 131072, F_DWPRE = 262144, F_HLSUM = 524288, F_TAIL2 = 1048576 };   // F_HLSUM: hi | lo weight rows in one 64-row stage, accumulator tiles added (see ir.py)   // F_DWPRE: depthwise conv fused in front of a 1x1 conv (conv_dwpw.hip)   // F_OGATE: in2 = per-image output gate (see ir.py)   // F_U8SRC: the stem conv resizes the uint8 BGR frames itself (see ir.py)   // F_ONECH: pixel-shuffle conv to one channel stores the fp32 map itself (see ir.py)
 enum { F_LSTM_MFMA_ = 0 };   // OP_LSTM: W_hh^T in MFMA fragment order, H = 256 (lstm.hip); p[P_REVERSE] = 2: both directions, in1 = reverse gates
 enum { F_RES = 1, F_PIXSHUF = 2, F_OUT_F32 = 4, F_PATCH = 8, F_DOT1 = 16, F_SRC2 = 32, F_UP2HEAD = 64, F_WK32 = 128, F_GATE = 256, F_STEM = 512, F_HILO = 1024, F_COL = 2048, F_PW = 4096, F_IMGW = 8192 };
 // p[] slots (keep in sync with ir.py)
@@ -130,6 +130,26 @@ static inline int vse_cu_count() {         // compute units of the current devic
         cus[dev] = prop.multiProcessorCount;
     }
     return cus[dev];
+}
+
+// Staging a table global -> LDS / registers with ALL of a thread's loads in flight before the first use (round 5).  The obvious
+//     for (v = tid; v < n; v += 256) { if (ok(v)) x = src[v]; dst[v] = x; }
+// compiles to load -> s_waitcnt vmcnt(0) -> ds_write per iteration — and a load under a condition to a branch around it besides: one
+// memory round trip per 256 vectors, 3 .. 10 dependent round trips (3 - 8 us) in front of the first MFMA of a block that then computes
+// for 2 us (conv_pw / conv_dwpw / conv_stem / chain_pw2 before this helper).  ld(v) must be UNCONDITIONAL (clamp the address, select the
+// value in st); CH loads per thread and round.
+template <int CH, int NT = 256, typename LD, typename ST>
+__device__ __forceinline__ void stage_batched(int n, int tid, LD&& ld, ST&& st) {
+    for (int b = 0; b < n; b += CH * NT) {
+        decltype(ld(0)) t[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) t[k] = ld(min(b + k * NT + tid, n - 1));
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int v = b + k * NT + tid;
+            if (v < n) st(v, t[k]);
+        }
+    }
 }
 
 // XCD-aware block order for STREAMING kernels whose neighbouring outputs share input rows (depthwise / pooling windows, up-sampling

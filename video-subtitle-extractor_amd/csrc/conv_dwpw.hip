@@ -42,19 +42,25 @@ __global__ __launch_bounds__(256, (KS <= 2 ? 4 : KS <= 4 ? 3 : 2)) void conv_dwp
     float* sbias = sdw + (K2 + 1) * CP;                                          // [ntile * 32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fx = lane & 31, fj = lane >> 5;
-    for (int v = tid; v < ntile * 32 * KS * 2; v += 256) {
-        const int r = v / (KS * 2), c = v - r * (KS * 2);
-        half8 x = half8{0, 0, 0, 0, 0, 0, 0, 0}, y = x;
-        if (r < p.Np) {
-            x = *reinterpret_cast<const half8*>(p.w + (long)r * CP + c * 8);
-            y = *reinterpret_cast<const half8*>(p.w + (long)(p.Np + r) * CP + c * 8);
-        }
-        *reinterpret_cast<half8*>(swt + r * ROWH + c * 8) = x;
-        *reinterpret_cast<half8*>(swt + (ntile * 32 + r) * ROWH + c * 8) = y;
-    }
     const float* aux = p.dotw;
-    for (int v = tid; v < (K2 + 1) * CP; v += 256) sdw[v] = aux[8 + v];
-    for (int c = tid; c < ntile * 32; c += 256) sbias[c] = c < p.Np ? p.bias[c] : 0.f;
+    {
+        // every table with all of a thread's loads in flight before its first LDS write (stage_batched, common.h: the 1x1 tables of a
+        // 96 -> 96 unit used to cost five dependent memory round trips per 128-pixel block, the depthwise table four more)
+        const int nvec = ntile * 32 * KS * 2, rmax = p.Np - 1;
+#pragma unroll
+        for (int tab = 0; tab < 2; ++tab) {                  // hi, lo
+            const half_t* wt = p.w + (long)tab * p.Np * CP;
+            half_t* dt = swt + tab * ntile * 32 * ROWH;
+            stage_batched<4>(nvec, tid,
+                [&](int v) { const int r = v / (KS * 2), c = v - r * (KS * 2); return *reinterpret_cast<const half8*>(wt + (long)min(r, rmax) * CP + c * 8); },
+                [&](int v, half8 x) { const int r = v / (KS * 2), c = v - r * (KS * 2);
+                                      *reinterpret_cast<half8*>(dt + r * ROWH + c * 8) = r <= rmax ? x : half8{0, 0, 0, 0, 0, 0, 0, 0}; });
+        }
+        // (the depthwise table [K2 + 1][CP] fp32 starts 32 bytes into the aux blob: 16-byte vectors, CP % 16 == 0)
+        stage_batched<4>((K2 + 1) * CP / 4, tid, [&](int v) { return *reinterpret_cast<const float4v*>(aux + 8 + 4 * v); },
+                         [&](int v, float4v x) { *reinterpret_cast<float4v*>(sdw + 4 * v) = x; });
+        stage_batched<1>(ntile * 32, tid, [&](int c) { return p.bias[min(c, rmax)]; }, [&](int c, float b) { sbias[c] = c <= rmax ? b : 0.f; });
+    }
     const int S = p.sh, PAD = p.ph, dact = __float_as_int(aux[3]);
     const float dact_a = aux[4], dact_b = aux[5], dpost_a = aux[6], dpost_b = aux[7];
     const int lo_in = p.in_lo_off;

@@ -270,7 +270,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     } else if (a.in.c != a.cinp) {
         return VSE_E_INVAL;
     }
-    if (a.in.esize != 2 || (a.in.ld & 7) || (a.cinp & 7)) return VSE_E_INVAL;
+    // (F_UP2HEAD reads ONE channel of in0 at pixel stride ld: the dense map of an F_TAIL2 producer has ld = 1)
+    if (a.in.esize != 2 || ((a.in.ld & 7) && !((a.flags & F_UP2HEAD) && a.in.ld == 1)) || (a.cinp & 7)) return VSE_E_INVAL;
     if ((a.flags & F_RES) && (a.res.esize != 2 || (a.res.ld & 3))) return VSE_E_INVAL;
     if ((!(a.flags & (F_DOT1 | F_ONECH)) && (a.out.ld & 3)) || (a.Np & 7)) return VSE_E_INVAL;
     if ((a.flags & F_ONECH) && (!(a.flags & F_PIXSHUF) || !(a.flags & F_OUT_F32) || a.Np != 32 || a.out.ld != 1 || a.out.esize != 4 || (a.flags & F_RES)))

@@ -44,18 +44,6 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fx = lane & 31, fj = lane >> 5;
 
-    // ---- weight tables [Np][80] (hi, then lo) -> LDS, rows >= Np zero ---------------------------------------------------------
-    {
-        const int nvec = p.Np * 10;                                             // 16-byte vectors per table
-        for (int v = tid; v < (HILO ? 2 : 1) * 640; v += 256) {
-            const int tab = v / 640, u = v - tab * 640;
-            half8 x = half8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (u < nvec) x = *reinterpret_cast<const half8*>(p.w + (long)tab * p.Np * 80 + u * 8);
-            *reinterpret_cast<half8*>(swt + tab * WTAB + u * 8) = x;
-        }
-    }
-    if (tid < 64) sbias[tid] = tid < p.Np ? p.bias[tid] : 0.f;
-
     // (one tile per block: a block that walks 8 consecutive tiles was measured 15 % slower — its tiles run back to back
     // and nothing overlaps inside it, while 4 resident blocks per CU overlap each other's load / compute / store phases)
     unsigned t = xcd_block(blockIdx.x, gridDim.x);          // (XCD-contiguous tile order: vertical neighbours share their halo rows in one L2)
@@ -65,53 +53,104 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
     const int oy0 = ty * ST_ROWS, ox0 = tx * ST_COLS;
     const int iy0 = oy0 * SH - p.ph, ix0 = ox0 * SW - p.pw;
 
+    // Round 5: EVERY global load of the prologue — weight tables and input patch — is issued unconditionally (clamped address, value
+    // selected afterwards) and before the first use, so the block pays ONE memory round trip.  The loads used to sit under their
+    // range checks inside the staging loops: hipcc branches around such a load and waits vmcnt(0) behind it, i.e. 3 + 5 dependent
+    // round trips per block (the kernel ran at 2.2 TB/s of its bytes with its waves waiting 68 % of the time).
+    constexpr int NIT = (NPIX + 255) / 256;                 // patch pixels per thread
+    constexpr int NWV = (HILO ? 2 : 1) * 640;               // 16-byte vectors of the weight tables [Np][80] (hi, then lo)
+    constexpr int NWIT = (NWV + 255) / 256;
+    // resize coefficients of the patch's rows and columns (clamped to the image): one lin_coef per row / column and block instead
+    // of two per patch pixel (double-precision division)
+    __shared__ LinCoef scoef[U8 ? PH_ + PW_ : 1];
+    if constexpr (U8) {
+        if (tid < PH_ + PW_) {
+            const bool row = tid < PH_;
+            const int d = row ? iy0 + tid : ix0 + (tid - PH_);
+            const int dst = row ? p.H : p.W;
+            scoef[tid] = lin_coef(min(max(d, 0), dst - 1), dst, row ? p.u8_h : p.u8_w);
+        }
+        __syncthreads();
+    }
+    half8 wv[NWIT];
+    {
+        const int nvec = p.Np * 10;                                             // 16-byte vectors per table
+#pragma unroll
+        for (int k = 0; k < NWIT; ++k) {
+            const int v = min(tid + 256 * k, NWV - 1);
+            const int tab = v / 640, u = v - tab * 640;
+            wv[k] = *reinterpret_cast<const half8*>(p.w + (long)tab * p.Np * 80 + min(u, nvec - 1) * 8);
+        }
+    }
+    float bv = 0.f;
+    if (tid < 64) bv = p.bias[min(tid, p.Np - 1)];
+
     // ---- input patch: channels 0..3 of every pixel, zeros outside the image ---------------------------------------------------
     if constexpr (U8) {
         const uint8_t* fb = p.u8src + img * p.u8_fstride;
-        const bool same = p.u8_w == p.W && p.u8_h == p.H;
-        for (int q = tid; q < NPIX; q += 256) {
+        const int rowb = p.u8_w * 3;                       // bytes of a source row (launch_conv_stem: >= 8)
+        unsigned long long q0[NIT], q1[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int q = min(tid + 256 * k, NPIX - 1);
             const int py = q / PW_, px = q - py * PW_;
+            const LinCoef cy = scoef[py], cx = scoef[PH_ + px];
+            // both source pixels of a row = 6 consecutive bytes: ONE (unaligned) 8-byte load per row; in the last columns the load starts
+            // earlier and the bytes are shifted down (the second pixel is then the first one again: x1 = s0)
+            const int b0 = min(cx.s0 * 3, rowb - 8);
+            __builtin_memcpy(&q0[k], fb + (long)cy.s0 * p.u8_pitch + b0, 8);
+            __builtin_memcpy(&q1[k], fb + (long)min(cy.s0 + 1, p.u8_h - 1) * p.u8_pitch + b0, 8);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int q = tid + 256 * k;
+            const int qc = min(q, NPIX - 1);
+            const int py = qc / PW_, px = qc - py * PW_;
             const int iy = iy0 + py, ix = ix0 + px;
+            const LinCoef cy = scoef[py], cx = scoef[PH_ + px];
+            const int sh0 = (cx.s0 * 3 - min(cx.s0 * 3, rowb - 8)) * 8;
+            const int sh1 = sh0 + (cx.s0 + 1 < p.u8_w ? 24 : 0);
             half4 v = half4{0, 0, 0, 0};
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                const LinCoef cx = lin_coef(ix, p.W, p.u8_w), cy = lin_coef(iy, p.H, p.u8_h);
-                const int x1 = min(cx.s0 + 1, p.u8_w - 1), y1 = min(cy.s0 + 1, p.u8_h - 1);
-                const uint8_t* r0 = fb + (long)cy.s0 * p.u8_pitch;
-                const uint8_t* r1 = fb + (long)y1 * p.u8_pitch;
-                if (VSE_STEM_WIDE && !same && cx.s0 + 3 < p.u8_w) {
-                    // both source pixels of a row = 6 consecutive bytes: ONE (unaligned) 8-byte load per row instead of six byte
-                    // loads — the kernel was bound by the number of its vector-memory instructions, not by their bytes
-                    unsigned long long q0, q1;
-                    __builtin_memcpy(&q0, r0 + cx.s0 * 3, 8);
-                    __builtin_memcpy(&q1, r1 + cx.s0 * 3, 8);
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int u = cv_bilinear_u8((int)((q0 >> (8 * c)) & 255), (int)((q0 >> (8 * c + 24)) & 255), (int)((q1 >> (8 * c)) & 255),
-                                                     (int)((q1 >> (8 * c + 24)) & 255), cx, cy);
-                        v[c] = (half_t)(float)u;
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int u = same ? (int)r0[cx.s0 * 3 + c]
-                                           : cv_bilinear_u8(r0[cx.s0 * 3 + c], r0[x1 * 3 + c], r1[cx.s0 * 3 + c], r1[x1 * 3 + c], cx, cy);
-                        v[c] = (half_t)(float)u;
-                    }
-                }
-                v[3] = (half_t)1.f;
+            for (int c = 0; c < 3; ++c) {
+                const int u = cv_bilinear_u8((int)((q0[k] >> (sh0 + 8 * c)) & 255), (int)((q0[k] >> (sh1 + 8 * c)) & 255),
+                                             (int)((q1[k] >> (sh0 + 8 * c)) & 255), (int)((q1[k] >> (sh1 + 8 * c)) & 255), cx, cy);
+                v[c] = (half_t)(float)u;
             }
-            *reinterpret_cast<half4*>(patch + q * 4) = v;
+            v[3] = (half_t)1.f;
+            if (!(iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)) v = half4{0, 0, 0, 0};
+            if (q < NPIX) *reinterpret_cast<half4*>(patch + q * 4) = v;
         }
     } else {
         const half_t* base = p.in + img * (long)p.Hs * p.Ws * p.in_ld;
-        for (int q = tid; q < NPIX; q += 256) {
+        half4 pv[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int q = min(tid + 256 * k, NPIX - 1);
+            const int py = q / PW_, px = q - py * PW_;
+            const int iy = min(max(iy0 + py, 0), p.H - 1), ix = min(max(ix0 + px, 0), p.W - 1);
+            pv[k] = *reinterpret_cast<const half4*>(base + ((long)iy * p.Ws + ix) * p.in_ld);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int q = tid + 256 * k;
             const int py = q / PW_, px = q - py * PW_;
             const int iy = iy0 + py, ix = ix0 + px;
-            half4 v = half4{0, 0, 0, 0};
-            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = *reinterpret_cast<const half4*>(base + ((long)iy * p.Ws + ix) * p.in_ld);
-            *reinterpret_cast<half4*>(patch + q * 4) = v;
+            const half4 v = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? pv[k] : half4{0, 0, 0, 0};
+            if (q < NPIX) *reinterpret_cast<half4*>(patch + q * 4) = v;
         }
     }
+    // ---- weight tables -> LDS, rows >= Np zero -----------------------------------------------------------------------------------
+    {
+        const int nvec = p.Np * 10;
+#pragma unroll
+        for (int k = 0; k < NWIT; ++k) {
+            const int v = tid + 256 * k;
+            const int tab = v / 640, u = v - tab * 640;
+            if (v < NWV) *reinterpret_cast<half8*>(swt + tab * WTAB + u * 8) = u < nvec ? wv[k] : half8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    if (tid < 64) sbias[tid] = tid < p.Np ? bv : 0.f;
     __syncthreads();
 
     // ---- weights: lane (f = lane & 31, fj) supplies cout conv_wrow(f) of each 32-cout tile, k = 16 ks + 8 fj .. +7 ----------
@@ -189,7 +228,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const ConvParams p) {
 
 int launch_conv_stem(const ConvParams& pin, int n_img, hipStream_t st) {
     ConvParams p = pin;
-    if (p.kh != 3 || p.kw != 3 || p.ph != 1 || p.pw != 1 || p.cinp != 8 || p.inshift != 0 || p.Np > 64) return VSE_E_INVAL;
+    if (p.kh != 3 || p.kw != 3 || p.ph != 1 || p.pw != 1 || p.cinp != 8 || p.inshift != 0 || p.Np > 64 || p.Np < 1) return VSE_E_INVAL;
     if (p.flags & (F_PIXSHUF | F_DOT1 | F_SRC2 | F_PATCH | F_UP2HEAD)) return VSE_E_INVAL;
     if (!((p.sh == 1 && p.sw == 1) || (p.sh == 2 && p.sw == 2))) return VSE_E_INVAL;
     p.tiles_h = (p.OH + ST_ROWS - 1) / ST_ROWS;
@@ -199,7 +238,7 @@ int launch_conv_stem(const ConvParams& pin, int n_img, hipStream_t st) {
     const dim3 grid((unsigned)blocks), block(256);
     const bool hilo = p.flags & F_HILO;
     if (p.flags & F_U8SRC) {
-        if (!p.u8src || p.u8_h <= 0 || p.u8_w <= 0) return VSE_E_INVAL;
+        if (!p.u8src || p.u8_h <= 0 || p.u8_w < 3) return VSE_E_INVAL;          // (8-byte row loads: >= 9 bytes per source row)
         if (p.sh == 2 && hilo) hipLaunchKernelGGL((conv_stem_kernel<2, 2, true, true>), grid, block, 0, st, p);
         else if (p.sh == 2) hipLaunchKernelGGL((conv_stem_kernel<2, 2, false, true>), grid, block, 0, st, p);
         else if (hilo) hipLaunchKernelGGL((conv_stem_kernel<1, 1, true, true>), grid, block, 0, st, p);

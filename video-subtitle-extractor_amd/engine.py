@@ -298,7 +298,7 @@ class Net:
     """One model (descriptor + fp32 weights) with plans compiled per static input shape."""
 
     def __init__(self, ctx: Context, desc, weights, fetch_cols=(0,), want_probs=True, hilo=False, ragged=False, input_norm=None,
-                 fuse_preprocess=False, chain=None):
+                 fuse_preprocess=False, chain=None, tail2=None):
         """hilo=True: conv weights as fp16 hi + lo pairs (compiler.compile_model): ~22-bit weights, twice the MFMA work.
         ragged=True (recognisers): every plan takes a per-sample width vector (run(x, widths=...)); a sample's outputs do
         not depend on the batch it rides in (compiler.compile_model(ragged=True))."""
@@ -313,6 +313,7 @@ class Net:
         self.fetch_cols = fetch_cols
         self.want_probs = want_probs
         self.hilo = bool(hilo)
+        self.tail2 = tail2                    # False: the server detector's two head deconvs as separate launches (compiler F_TAIL2; tests)
         self.chain = chain                    # None: 1x1 / depthwise chains (OP_CHAIN) for hi + lo nets; False / True forces it
         self.store = compiler.WeightStore()
         self.plans = {}
@@ -327,7 +328,7 @@ class Net:
             try:
                 prog = compiler.compile_model(self.desc, self.weights, n, h, w, self.fetch_cols, self.want_probs,
                                               self.store, hilo=self.hilo, ragged=self.ragged, input_norm=self.input_norm,
-                                              fuse_preprocess=self.fuse_preprocess, chain=self.chain)
+                                              fuse_preprocess=self.fuse_preprocess, chain=self.chain, tail2=self.tail2)
             except compiler.UnsupportedGraph:
                 if not self.fuse_preprocess or self.plans:
                     raise
