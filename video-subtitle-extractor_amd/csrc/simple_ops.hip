@@ -724,6 +724,76 @@ __global__ __launch_bounds__(256) void softmax_kernel(TView in, TView idxp, TVie
     }
 }
 
+// The same row softmax with the row held in REGISTERS (round 5): NV 16-byte vectors per thread, all loaded before the first use —
+// ONE memory round trip per row where softmax_kernel's three scalar passes over 6625 classes make 3 x 26 dependent ones (77 us per
+// 56-crop recogniser sequence, launch-to-launch).  Same arg-max rule (largest value, smallest index among equals); the sum is taken in
+// this kernel's own (fixed) order.  Rows must be 16-byte aligned (the launcher checks); classes behind ncls count as -inf.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void softmax_reg_kernel(TView in, TView idxp, TView probs, int ncls, int want_probs) {
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T vec_t __attribute__((ext_vector_type(VW)));
+    __shared__ float smax[4];
+    __shared__ int sidx[4];
+    __shared__ float ssum[4];
+    const long row = blockIdx.x;
+    const T* x = reinterpret_cast<const T*>(in.ptr) + row * in.ld;
+    const int nvec = (ncls + VW - 1) / VW;
+    vec_t xv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) xv[k] = *reinterpret_cast<const vec_t*>(x + (long)min(k * 256 + (int)threadIdx.x, nvec - 1) * VW);
+    float v[NV][VW];
+    float mx = -1e30f;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            const int c = (k * 256 + (int)threadIdx.x) * VW + e;
+            v[k][e] = c < ncls ? (float)xv[k][e] : -1e30f;
+            if (v[k][e] > mx) { mx = v[k][e]; mi = c; }          // (c ascends inside a thread: the first of equal values is kept)
+        }
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float om = __shfl_xor(mx, o);
+        const int oi = __shfl_xor(mi, o);
+        if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smax[wave] = mx; sidx[wave] = mi; }
+    __syncthreads();
+    mx = smax[0]; mi = sidx[0];
+    for (int q = 1; q < 4; ++q)
+        if (smax[q] > mx || (smax[q] == mx && sidx[q] < mi)) { mx = smax[q]; mi = sidx[q]; }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+            const int c = (k * 256 + (int)threadIdx.x) * VW + e;
+            v[k][e] = c < ncls ? expf(v[k][e] - mx) : 0.f;
+            s += v[k][e];
+        }
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) ssum[wave] = s;
+    __syncthreads();
+    s = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+    const float inv = 1.f / s;
+    if (threadIdx.x == 0) {
+        int* ip = reinterpret_cast<int*>(idxp.ptr) + row * idxp.ld;
+        ip[0] = mi;
+        reinterpret_cast<float*>(ip)[1] = inv;   // max prob = exp(0)/sum
+    }
+    if (want_probs) {
+        float* pr = reinterpret_cast<float*>(probs.ptr) + row * probs.ld;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+                const int c = (k * 256 + (int)threadIdx.x) * VW + e;
+                if (c < ncls) pr[c] = v[k][e] * inv;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ LSTM
 // One block per batch row; gates fp32 [B,1,T,4H] hold x.W_ih^T + b_ih + b_hh for every step (one MFMA GEMM up
 // front); this kernel adds h.W_hh^T and runs the cell.  W_hh^T is fp16 [H][4H] read through L2 every step.
@@ -961,6 +1031,21 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
         }
         case OP_SOFTMAX: {
             const long rows = (long)in0.n * in0.h * in0.w;
+            const int wp = out2.ptr != nullptr ? 1 : 0;
+            // the row in registers (one memory round trip) when rows are 16-byte aligned and fit 8 vectors per thread
+            const int vw = 16 / in0.esize, nvt = ((p[0] + vw - 1) / vw + 255) / 256;
+            if ((reinterpret_cast<uintptr_t>(in0.ptr) & 15) == 0 && ((long)in0.ld * in0.esize) % 16 == 0 && nvt <= 8 && p[0] > 0
+                && (long)((p[0] + vw - 1) / vw) * vw <= in0.ld) {
+                const dim3 g((unsigned)rows), b(256);
+#define VSE_SM_LAUNCH(T, NV) hipLaunchKernelGGL((softmax_reg_kernel<T, NV>), g, b, 0, st, in0, out, out2, p[0], wp)
+                if (in0.esize == 4) {
+                    if (nvt <= 1) VSE_SM_LAUNCH(float, 1); else if (nvt <= 2) VSE_SM_LAUNCH(float, 2); else if (nvt <= 4) VSE_SM_LAUNCH(float, 4); else VSE_SM_LAUNCH(float, 8);
+                } else {
+                    if (nvt <= 1) VSE_SM_LAUNCH(half_t, 1); else if (nvt <= 2) VSE_SM_LAUNCH(half_t, 2); else if (nvt <= 4) VSE_SM_LAUNCH(half_t, 4); else VSE_SM_LAUNCH(half_t, 8);
+                }
+#undef VSE_SM_LAUNCH
+                break;
+            }
             if (in0.esize == 4)
                 hipLaunchKernelGGL(softmax_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, in0, out, out2, p[0],
                                    out2.ptr != nullptr ? 1 : 0);
