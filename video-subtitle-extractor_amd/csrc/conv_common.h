@@ -40,6 +40,8 @@ struct ConvParams {
     const half_t* ogate;    // F_OGATE: per-(image, cout) gate [n][ogate_ld] fp16; the value is multiplied by (1 + gate) ahead of the residual
     int ogate_ld;
     int wnp;                // conv_c3_kernel: weight rows per tap of a ring stage (= Np; F_HLSUM: 64 = hi 32 | lo 32 while Np stays 32)
+    float* gap_part;        // F_GAPSUM (conv_gemm_kernel): fp32 partial sums [n][gap_slots][Np] of the stored values, one slot per 128 output pixels of an image
+    int gap_slots;
     const uint8_t* u8src;   // F_U8SRC (stem): uint8 BGR frames [n][u8_h][u8_w][3], row pitch / frame stride in bytes
     int u8_h, u8_w;
     long u8_pitch, u8_fstride;
@@ -165,8 +167,12 @@ __device__ __forceinline__ void conv_epilogue_consts(const float* tab, int c, in
 // Epilogue of one 32(cout) x 32(pixel) accumulator tile: lane l owns pixel (l & 31) — passed in as (m, n, oh, ow).
 //   + bias (BN folded) -> activation -> scalar affine -> (+ residual, optionally nearest-upsampled) -> activation2
 //   -> fp16 / fp32 store; F_PIXSHUF scatters a 2x2-stride-2 transposed conv.
-__device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const float16v& acc, const float (&bias)[16], long m,
-                                                   long n, int oh, int ow, int cbase, int lane) {
+// GAP (conv_gemm_kernel; active when gq != nullptr, F_GAPSUM): called by EVERY lane of the wave (`valid` = the lane's pixel exists); the 16 values AS STORED
+// (rounded to fp16; 0 for a pixel or couts that do not exist) are then summed over the tile's 32 pixels (xor butterfly inside the lane
+// half) and lane 0 of each half adds the sums to the wave's own LDS row `gq` (+ 8 h: registers 8 g + e = couts 16 g + 8 h + e).
+template <bool GAP>
+__device__ __forceinline__ void conv_epilogue_tile_t(const ConvParams& p, const float16v& acc, const float (&bias)[16], long m,
+                                                     long n, int oh, int ow, int cbase, int lane, bool valid, float* gq) {
     const bool pixshuf = p.flags & F_PIXSHUF;
     const bool has_res = p.flags & F_RES;
     long res_pix = m;
@@ -190,7 +196,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int c0 = cbase + g * 16 + (lane >> 5) * 8;
-        live[g] = c0 < p.Np;
+        live[g] = c0 < p.Np && (!GAP || valid);
         opix[g] = m;
         oc[g] = c0;
         if (pixshuf) {                                   // coutp % 8 == 0: a run of 8 never straddles two quads
@@ -238,6 +244,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = 0.f;
     }
+
     if (p.flags & F_ONECH) {
         // pixel-shuffle conv to ONE channel, fp32 map out (ld = 1): this lane's 8-channel run g is one quad; its first value is the pixel
 #pragma unroll
@@ -271,6 +278,25 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const fl
             }
         }
     }
+    if (GAP && gq != nullptr) {                      // (wave-uniform)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = live[e >> 3] ? (p.out_f32 ? v[e] : (float)(half_t)v[e]) : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float t = v[e];
+            t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8); t += __shfl_xor(t, 16);
+            v[e] = t;
+        }
+        if ((lane & 31) == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gq[e] += v[e]; gq[16 + e] += v[8 + e]; }
+        }
+    }
+}
+
+__device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const float16v& acc, const float (&bias)[16], long m,
+                                                   long n, int oh, int ow, int cbase, int lane) {
+    conv_epilogue_tile_t<false>(p, acc, bias, m, n, oh, ow, cbase, lane, true, nullptr);
 }
 
 // Ragged batches: an output tile that lies entirely right of its sample's width holds zeros by definition — the block writes
