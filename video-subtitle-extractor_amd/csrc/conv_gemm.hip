@@ -295,7 +295,7 @@ void conv_gemm_kernel(const ConvParams p) {
 
     // ---- epilogue (shared with conv_mfma_kernel) ---------------------------------------------------------------
     // F_GAPSUM: the global average pool behind this conv starts here.  Per accumulator tile the 16 stored values of a lane (one pixel)
-    // are summed over the tile's 32 pixels (xor butterfly inside the lane half), lane 0 of each half adds them to the WAVE's own
+    // are summed over the tile's 32 pixels (DPP adds inside the lane half), the last lane of each half adds them to the WAVE's own
     // LDS row (the ring is free behind the K loop); behind a barrier the rows of the waves that share 128 output pixels are added
     // in wave order and written as ONE partial-sum slot per 128 pixels of the image: a fixed order, no atomics — the same bits
     // every run.  The pool itself (simple_ops.hip, gap_finish2_kernel) adds the slots and divides.
