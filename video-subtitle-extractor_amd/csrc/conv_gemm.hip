@@ -304,7 +304,7 @@ void conv_gemm_kernel(const ConvParams p) {
     float* const sgap = reinterpret_cast<float*>(lds);
     if (gap) {
         __syncthreads();                             // every wave has left the K loop: the ring is free
-        if (lane < WTN) sgap[wave * WTN + lane] = 0.f;
+        for (int c = lane; c < WTN; c += 64) sgap[wave * WTN + c] = 0.f;       // (WTN = 96 in the 192-cout tiles)
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
