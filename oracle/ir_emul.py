@@ -397,17 +397,6 @@ class Emulator:
             return
         oc = int(r["out"]["c"])
         self.write_pair(r["out"], int(p[ir.P_LO_OUT]), y[..., :oc] if y.shape[3] >= oc else F.pad(y, (0, oc - y.shape[3])))
-        if flags & ir.F_GAPSUM:
-            # partial sums of the STORED values, one slot per 128 output pixels of an image (csrc/conv_gemm.hip; the kernel's summation
-            # order inside a slot is its own — the emulator keeps the slot structure and sums in float64)
-            assert (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and not flags & (ir.F_PIXSHUF | ir.F_DOT1 | ir.F_SRC2 | ir.F_HILO | ir.F_PW | ir.F_COL | ir.F_PATCH)
-            n_, h_, w_, _ = y.shape
-            v2 = r["out2"]
-            slots = int(v2["h"])
-            assert slots == -(-(h_ * w_) // 128) and int(v2["c"]) == Np and int(v2["esize"]) == 4 and int(v2["n"]) == n_
-            ys = (y.half().float() if self.round else y).reshape(n_, h_ * w_, Np).double()
-            ys = F.pad(ys, (0, 0, 0, slots * 128 - h_ * w_)).reshape(n_, slots, 128, Np).sum(2)
-            self.write(v2, ys.float().reshape(n_, slots, 1, Np))
         if flags & ir.F_TAIL2:
             # the second 2x2 s2 transposed conv (-> ONE channel) on the fp16 values just stored (csrc/conv_pw.hip, conv_pw_tail_kernel):
             # decoded from stage B's MFMA fragments [Np / 16][2][16][8] — a block-diagonal [16][Np] matrix, row 4 r + c, column
@@ -476,12 +465,6 @@ class Emulator:
         self.write(r["out"], self.per_sample(self.read(r["in0"]), pool))
 
     def _op4(self, r):   # GAP
-        if int(r["flags"]) & ir.F_GAPSUM:     # the producing conv wrote the partial sums (in2): slots added in order, divided by h w
-            pt = self.read(r["in2"])
-            hw = int(r["in0"]["h"]) * int(r["in0"]["w"])
-            assert pt.shape[1] == -(-hw // 128) and pt.shape[3] == int(r["in0"]["c"])
-            self.write(r["out"], (pt.double().sum(1, keepdim=True) / hw).float().reshape(pt.shape[0], 1, 1, pt.shape[3]))
-            return
         x = self.read(r["in0"])
         self.write(r["out"], self.per_sample(x, lambda xs: xs.mean((1, 2), keepdim=True)))
 

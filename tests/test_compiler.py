@@ -498,27 +498,3 @@ def test_head_tail_fusion_and_its_fallback(monkeypatch):
     assert not any(int(o["flags"]) & (ir.F_TAIL2 | ir.F_UP2HEAD) for o in prog.ops)
     ref = net_ref.run_graph(desc, w, x)[0].numpy()[:, 0]
     assert np.abs(ir_emul.Emulator(prog).run(ir_emul.to_nhwc8(x))[0][..., 0] - ref).max() < 5e-3
-
-
-def test_pool_partial_sums_in_the_producing_conv():
-    """F_GAPSUM: a global average pool over a map of >= 2048 pixels starts in the epilogue of the 1x1 conv that writes its input
-    (conv_gemm_kernel: fp32 partial sums of the stored values, one slot per 128 pixels of an image); OP_GAP | F_GAPSUM is the finishing
-    pass alone.  Every such conv is paired with its pool, the slot geometry is the kernel's, and the program still matches the fp32
-    interpreter; small maps (the other test shapes) keep the pool's own pass."""
-    desc, w = net_ref.get_weights("V4_ch_det")
-    x = np.random.default_rng(5).uniform(-1, 1, (1, 3, 256, 384)).astype(np.float16).astype(np.float32)
-    prog = compiler.compile_model(desc, w, 1, 256, 384)
-    convs = [o for o in prog.ops if int(o["kind"]) == ir.OP_CONV and int(o["flags"]) & ir.F_GAPSUM]
-    pools = [o for o in prog.ops if int(o["kind"]) == ir.OP_GAP]
-    fused = [o for o in pools if int(o["flags"]) & ir.F_GAPSUM]
-    assert len(convs) == len(fused) >= 1 and len(pools) > len(fused)          # (the 8x12 / 16x24 maps stay on gap_partial_kernel)
-    for c in convs:
-        hw = int(c["out"]["h"]) * int(c["out"]["w"])
-        assert int(c["out2"]["h"]) == -(-hw // 128) and int(c["out2"]["esize"]) == 4 and int(c["out2"]["c"]) == int(c["p"][ir.P_COUT]) == int(c["out2"]["ld"])
-        assert (int(c["p"][ir.P_KH]), int(c["p"][ir.P_KW])) == (1, 1) and not int(c["flags"]) & (ir.F_PW | ir.F_COL | ir.F_PATCH | ir.F_HILO)
-        assert any(int(g["in2"]["off"]) == int(c["out2"]["off"]) and int(g["in0"]["off"]) == int(c["out"]["off"]) for g in fused)
-    ref = net_ref.run_graph(desc, w, x)[0].numpy()[:, 0]
-    got = ir_emul.Emulator(prog).run(ir_emul.to_nhwc8(x))[0][..., 0]
-    assert np.abs(got - ref).max() < 5e-3
-    small = compiler.compile_model(desc, w, 1, 64, 96)
-    assert not any(int(o["flags"]) & ir.F_GAPSUM for o in small.ops if int(o["kind"]) in (ir.OP_CONV, ir.OP_GAP))

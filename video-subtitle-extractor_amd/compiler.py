@@ -194,8 +194,6 @@ COL3 = _dev_switch("VSE_COL3", "1") != "0"
 COL3_MAX_COUT = int(_dev_switch("VSE_COL3_MAXCOUT", "192"))     # per-layer A/B (tools/bench_conv.py --cfgs d,p,c): 224-cout layers tie or lose
 PW = _dev_switch("VSE_PW", "1") != "0"             # conv_pw_kernel for 1x1 convs (and 2x2 s2 transposed convs) over <= 64 input channels
 PW_MAX_COUT = int(_dev_switch("VSE_PW_MAXCOUT", "64"))
-GAPSUM = _dev_switch("VSE_GAPSUM", "1") != "0"     # global average pools start in the producing 1x1 conv's epilogue (F_GAPSUM)
-GAPSUM_MIN_PIX = 2048                              # maps below this many pixels: the pool's own pass costs a few microseconds
 TAIL2 = _dev_switch("VSE_TAIL2", "1") != "0"       # the server detector's second head deconv inside the first one's launch (F_TAIL2)
 COL3_MIN_K = int(_dev_switch("VSE_COL3_MINK", "250"))   # 3x3 32->32 @136x240 (K = 288): 0.180 ms on the implicit GEMM, 0.115 ms here
 COL3_WIDE_MIN_CIN = 128    # layers with more than 64 couts (two+ cout tiles refetch the patch) only from 128 input channels on
@@ -1494,21 +1492,7 @@ class Compiler(ChainMixin):
             self.add_gmacs(inv.n * oh * ow * (cin * cout * kh * kw + cout) / 1e9)
             self.env[dot["out_name"]] = dot["view"]
             return
-        gpart = None
-        if (GAPSUM and not self.ragged and not self.hilo and (kh, kw, sh, sw, ph, pw) == (1, 1, 1, 1, 0, 0) and Kp == inv.span and inv.span % 32 == 0
-                and inv_main.up == 0 and inv.parts is None and not (flags & ~(ir.F_RES | ir.F_WK32)) and oh * ow >= GAPSUM_MIN_PIX
-                and out.buf.esize == 2 and out.buf.lo_off == 0 and coutp == cout and self.gemm_eligible(kh, kw, ph, pw, inv.span, inv_main.up, flags)
-                and any(self.ops[k]["type"] == "pool2d" and (self.ops[k]["attrs"].get("adaptive", False) or self.ops[k]["attrs"].get("global_pooling", False))
-                        and self.ops[k]["attrs"]["pooling_type"] == "avg" for k in self._live_consumers(ep["out_name"]))):
-            # the global average pool that reads this conv's output starts in its epilogue (F_GAPSUM, conv_gemm.hip): fp32 partial sums
-            # of the stored values, one slot per 128 output pixels of an image; lower_pool emits the finishing pass only
-            slots = -(-(oh * ow) // 128)
-            gb = self.new_buf(inv.n, slots, 1, coutp, esize=4)
-            gpart = View(gb, 0, inv.n, slots, 1, [(0, coutp)], coutp)
-            flags |= ir.F_GAPSUM
-            self.gap_partials = getattr(self, "gap_partials", {})
-            self.gap_partials[ep["out_name"]] = (gpart, inv.n, oh, ow, coutp)
-        self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags, out2=gpart,
+        self.emit(ir.OP_CONV, ep["out_name"], ins, out, flags=flags,
                   p={ir.P_KH: kh, ir.P_KW: kw, ir.P_SH: sh, ir.P_SW: sw, ir.P_PH: ph, ir.P_PW: pw,
                      ir.P_ACT: ep["act"], ir.P_ACT2: ep["act2"], ir.P_COUT: coutp, ir.P_KTOT: Kp,
                      ir.P_INSHIFT: inv_main.up, ir.P_RESSHIFT: resshift, ir.P_CINP: inv.span, ir.P_IN2SHIFT: in2shift,
@@ -1801,12 +1785,6 @@ class Compiler(ChainMixin):
             splits = max(1, min(64, (x.h * x.w) // 256))
             if self.ragged:
                 splits = x.h          # gap_rows_kernel: one partial sum per row, a summation order that ignores the tensor's width
-            gp = getattr(self, "gap_partials", {}).get(op["in"]["X"][0])
-            if gp is not None and (x.n, x.h, x.w, x.span, x.c) == gp[1:] + (gp[4],) and x.up == 0 and x.parts is None:
-                # the producing conv's epilogue wrote the partial sums (F_GAPSUM): the finishing pass only
-                self.emit(ir.OP_GAP, name, [x, None, gp[0]], out, flags=ir.F_GAPSUM)
-                self.env[name] = out
-                return
             sb = self.new_buf(x.n, splits, 1, x.span, esize=4)
             scratch = View(sb, 0, x.n, splits, 1, [(0, x.span)], x.span)
             self.emit(ir.OP_GAP, name, [x, None, scratch], out)

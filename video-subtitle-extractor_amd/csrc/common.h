@@ -13,7 +13,7 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_HSWISH = 2, ACT_SWISH = 3, ACT_SIGMOID = 4, ACT_HSIGMOID = 5 };
 enum { OP_CONV = 1, OP_DWCONV, OP_POOL, OP_GAP, OP_SCALE, OP_BINARY, OP_RESIZE, OP_UNARY, OP_LAYERNORM, OP_ATTN,
        OP_SOFTMAX, OP_LSTM, OP_WSCALE, OP_CHAIN };   // OP_CHAIN: 1x1 / depthwise conv chain with LDS-resident intermediates (chain.hip)
-enum { F_LSTM_MFMA = 16384, F_ONECH = 32768, F_U8SRC = 65536, F_OGATE = 131072, F_DWPRE = 262144, F_HLSUM = 524288, F_TAIL2 = 1048576, F_GAPSUM = 2097152 };   // F_HLSUM: hi | lo weight rows in one 64-row stage, accumulator tiles added (see ir.py)   // F_DWPRE: depthwise conv fused in front of a 1x1 conv (conv_dwpw.hip)   // F_OGATE: in2 = per-image output gate (see ir.py)   // F_U8SRC: the stem conv resizes the uint8 BGR frames itself (see ir.py)   // F_ONECH: pixel-shuffle conv to one channel stores the fp32 map itself (see ir.py)
+enum { F_LSTM_MFMA = 16384, F_ONECH = 32768, F_U8SRC = 65536, F_OGATE = 131072, F_DWPRE = 262144, F_HLSUM = 524288, F_TAIL2 = 1048576 };   // F_HLSUM: hi | lo weight rows in one 64-row stage, accumulator tiles added (see ir.py)   // F_DWPRE: depthwise conv fused in front of a 1x1 conv (conv_dwpw.hip)   // F_OGATE: in2 = per-image output gate (see ir.py)   // F_U8SRC: the stem conv resizes the uint8 BGR frames itself (see ir.py)   // F_ONECH: pixel-shuffle conv to one channel stores the fp32 map itself (see ir.py)
 enum { F_LSTM_MFMA_ = 0 };   // OP_LSTM: W_hh^T in MFMA fragment order, H = 256 (lstm.hip); p[P_REVERSE] = 2: both directions, in1 = reverse gates
 enum { F_RES = 1, F_PIXSHUF = 2, F_OUT_F32 = 4, F_PATCH = 8, F_DOT1 = 16, F_SRC2 = 32, F_UP2HEAD = 64, F_WK32 = 128, F_GATE = 256, F_STEM = 512, F_HILO = 1024, F_COL = 2048, F_PW = 4096, F_IMGW = 8192 };
 // p[] slots (keep in sync with ir.py)

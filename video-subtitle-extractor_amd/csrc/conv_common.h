@@ -40,8 +40,6 @@ struct ConvParams {
     const half_t* ogate;    // F_OGATE: per-(image, cout) gate [n][ogate_ld] fp16; the value is multiplied by (1 + gate) ahead of the residual
     int ogate_ld;
     int wnp;                // conv_c3_kernel: weight rows per tap of a ring stage (= Np; F_HLSUM: 64 = hi 32 | lo 32 while Np stays 32)
-    float* gap_part;        // F_GAPSUM (conv_gemm_kernel): fp32 partial sums [n][gap_slots][Np] of the stored values, one slot per 128 output pixels of an image
-    int gap_slots;
     const uint8_t* u8src;   // F_U8SRC (stem): uint8 BGR frames [n][u8_h][u8_w][3], row pitch / frame stride in bytes
     int u8_h, u8_w;
     long u8_pitch, u8_fstride;
@@ -167,12 +165,8 @@ __device__ __forceinline__ void conv_epilogue_consts(const float* tab, int c, in
 // Epilogue of one 32(cout) x 32(pixel) accumulator tile: lane l owns pixel (l & 31) — passed in as (m, n, oh, ow).
 //   + bias (BN folded) -> activation -> scalar affine -> (+ residual, optionally nearest-upsampled) -> activation2
 //   -> fp16 / fp32 store; F_PIXSHUF scatters a 2x2-stride-2 transposed conv.
-// GAP (conv_gemm_kernel; active when gq != nullptr, F_GAPSUM): called by EVERY lane of the wave (`valid` = the lane's pixel exists); the 16 values AS STORED
-// (rounded to fp16; 0 for a pixel or couts that do not exist) are then summed over the tile's 32 pixels (xor butterfly inside the lane
-// half, DPP) and the LAST lane of each half adds the sums to the wave's own LDS row `gq` (+ 8 h: registers 8 g + e = couts 16 g + 8 h + e).
-template <bool GAP>
-__device__ __forceinline__ void conv_epilogue_tile_t(const ConvParams& p, const float16v& acc, const float (&bias)[16], long m,
-                                                     long n, int oh, int ow, int cbase, int lane, bool valid, float* gq) {
+__device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const float16v& acc, const float (&bias)[16], long m,
+                                                   long n, int oh, int ow, int cbase, int lane) {
     const bool pixshuf = p.flags & F_PIXSHUF;
     const bool has_res = p.flags & F_RES;
     long res_pix = m;
@@ -196,7 +190,7 @@ __device__ __forceinline__ void conv_epilogue_tile_t(const ConvParams& p, const 
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         const int c0 = cbase + g * 16 + (lane >> 5) * 8;
-        live[g] = c0 < p.Np && (!GAP || valid);
+        live[g] = c0 < p.Np;
         opix[g] = m;
         oc[g] = c0;
         if (pixshuf) {                                   // coutp % 8 == 0: a run of 8 never straddles two quads
@@ -244,7 +238,6 @@ __device__ __forceinline__ void conv_epilogue_tile_t(const ConvParams& p, const 
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = 0.f;
     }
-
     if (p.flags & F_ONECH) {
         // pixel-shuffle conv to ONE channel, fp32 map out (ld = 1): this lane's 8-channel run g is one quad; its first value is the pixel
 #pragma unroll
@@ -278,35 +271,6 @@ __device__ __forceinline__ void conv_epilogue_tile_t(const ConvParams& p, const 
             }
         }
     }
-    if (GAP && gq != nullptr) {                      // (wave-uniform)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = live[e >> 3] ? (p.out_f32 ? v[e] : (float)(half_t)v[e]) : 0.f;
-        // sum over the 32 lanes of a half with DPP adds (VALU only; the xor butterfly through ds_bpermute cost 0.44 ms on the 896 -> 256
-        // aggregation conv, more than the pool it replaced): quads, 8-lane halves, 16-lane rows — every lane of a row then holds the
-        // row's sum — and row_bcast15 adds the even row's sum into the odd row: lanes 16 .. 31 / 48 .. 63 hold the half's sum.
-        // (v_add_f32 with the DPP modifier on its first source: ONE instruction per level and value — through
-        // __builtin_amdgcn_update_dpp hipcc emits v_mov_b32_dpp + v_add_f32; level by level over the 16 values, so that a value's next
-        // level is 16 instructions behind the write it reads: the DPP read-after-VALU-write hazard needs two)
-#define VSE_DPP_LEVEL(ctrl)                                                                                   \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) asm volatile("v_add_f32_dpp %0, %0, %0 " ctrl : "+v"(v[e]));
-        asm volatile("s_nop 1");
-        VSE_DPP_LEVEL("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        VSE_DPP_LEVEL("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        VSE_DPP_LEVEL("row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        VSE_DPP_LEVEL("row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1")
-        VSE_DPP_LEVEL("row_bcast:15 row_mask:0xa bank_mask:0xf")
-#undef VSE_DPP_LEVEL
-        asm volatile("s_nop 1");
-        if ((lane & 31) == 31) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { gq[e] += v[e]; gq[16 + e] += v[8 + e]; }
-        }
-    }
-}
-
-__device__ __forceinline__ void conv_epilogue_tile(const ConvParams& p, const float16v& acc, const float (&bias)[16], long m,
-                                                   long n, int oh, int ow, int cbase, int lane) {
-    conv_epilogue_tile_t<false>(p, acc, bias, m, n, oh, ow, cbase, lane, true, nullptr);
 }
 
 // Ragged batches: an output tile that lies entirely right of its sample's width holds zeros by definition — the block writes

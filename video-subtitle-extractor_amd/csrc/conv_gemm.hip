@@ -79,13 +79,11 @@ void conv_gemm_kernel(const ConvParams p) {
     long m0 = (long)mtile * BM;
     long mend = p.M;                                 // rows at or beyond it do not exist
     const half_t* wsrc = p.w;
-    unsigned gimg = 0, gti = 0;                      // F_GAPSUM: image and tile-in-image of this block
-    if (p.flags & (F_IMGW | F_GAPSUM)) {
+    if (p.flags & F_IMGW) {
         const unsigned img = mtile / (unsigned)p.tiles_img, ti = mtile - img * (unsigned)p.tiles_img;
         m0 = (long)img * p.hw_img + (long)ti * BM;
         mend = (long)(img + 1) * p.hw_img;
-        wsrc += (long)img * p.wimg_stride;           // (0 without F_IMGW)
-        gimg = img; gti = ti;
+        wsrc += (long)img * p.wimg_stride;
     }
     const int n0 = ntile * BN;
 
@@ -294,26 +292,12 @@ void conv_gemm_kernel(const ConvParams p) {
     }
 
     // ---- epilogue (shared with conv_mfma_kernel) ---------------------------------------------------------------
-    // F_GAPSUM: the global average pool behind this conv starts here.  Per accumulator tile the 16 stored values of a lane (one pixel)
-    // are summed over the tile's 32 pixels (DPP adds inside the lane half), the last lane of each half adds them to the WAVE's own
-    // LDS row (the ring is free behind the K loop); behind a barrier the rows of the waves that share 128 output pixels are added
-    // in wave order and written as ONE partial-sum slot per 128 pixels of the image: a fixed order, no atomics — the same bits
-    // every run.  The pool itself (simple_ops.hip, gap_finish2_kernel) adds the slots and divides.
-    constexpr bool GAPC = MASK == 0;                 // (launch_conv_gemm: the unmasked 1x1 form only)
-    const bool gap = GAPC && p.gap_part != nullptr;  // (block-uniform)
-    float* const sgap = reinterpret_cast<float*>(lds);
-    if (gap) {
-        __syncthreads();                             // every wave has left the K loop: the ring is free
-        for (int c = lane; c < WTN; c += 64) sgap[wave * WTN + c] = 0.f;       // (WTN = 96 in the 192-cout tiles)
-    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const long m = m0 + wm * WTM + i * 32 + (lane & 31);
-        const bool valid = m < mend;
-        if (!valid && !gap) continue;
-        const long mc = valid ? m : m0;
-        const int ow = (int)(mc % p.OW);
-        const long t = mc / p.OW;
+        if (m >= mend) continue;
+        const int ow = (int)(m % p.OW);
+        const long t = m / p.OW;
         const int oh = (int)(t % p.OH);
         const long n = t / p.OH;
 #pragma unroll
@@ -324,24 +308,8 @@ void conv_gemm_kernel(const ConvParams p) {
             {
                 float bias[16];
                 conv_epilogue_consts(sbias, wn * WTN + j * 32, lane, bias);
-                // (ONE inlined copy of the epilogue: with a second one behind `if (gap)` hipcc stopped unrolling these loops and moved
-                // the accumulators to scratch memory)
-                conv_epilogue_tile_t<GAPC>(p, acc[i][j], bias, mc, n, oh, ow, n0 + wn * WTN + j * 32, lane, valid,
-                                           gap ? sgap + wave * WTN + j * 32 + (lane >> 5) * 8 : nullptr);
+                conv_epilogue_tile(p, acc[i][j], bias, m, n, oh, ow, n0 + wn * WTN + j * 32, lane);
             }
-    }
-    if (gap) {
-        __syncthreads();
-        constexpr int NH = BM / 128, WPH = WM / NH;                  // 128-pixel halves of the tile, wave rows per half
-        static_assert(BM % 128 == 0 && WM % NH == 0, "F_GAPSUM slots");
-        for (int t = tid; t < NH * BN; t += 64 * WM * WN) {
-            const int half = t / BN, c = t - half * BN;
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < WPH; ++w) sum += sgap[((half * WPH + w) * WN + c / WTN) * WTN + c % WTN];
-            const int slot = (int)gti * NH + half;
-            if (slot < p.gap_slots && n0 + c < p.Np) p.gap_part[((long)gimg * p.gap_slots + slot) * p.Np + n0 + c] = sum;
-        }
     }
 }
 
@@ -428,12 +396,7 @@ int launch_conv_gemm(ConvParams& p, int Kp, hipStream_t st) {
     p.nkh = p.nk;
     if (p.flags & F_HILO) p.nk *= 2;
     unsigned long long tiles = (unsigned long long)((p.M + g.bm - 1) / g.bm) * p.ntn;
-    if (p.flags & F_GAPSUM) {
-        // partial sums per 128 output pixels of an image: unmasked 1x1 form, fp16 tensor out, whole images
-        p.hw_img = p.OH * p.OW;
-        if (mode != 2 || !p.gap_part || p.gap_slots != (p.hw_img + 127) / 128 || (p.flags & (F_PIXSHUF | F_DOT1 | F_SRC2 | F_OUT_F32)) || p.out_f32) return VSE_E_INVAL;
-    }
-    if (p.flags & (F_IMGW | F_GAPSUM)) {
+    if (p.flags & F_IMGW) {
         if (mode != 2 || p.hw_img <= 0 || p.M % p.hw_img) return VSE_E_UNSUPPORTED;      // unmasked 1x1 only
         p.tiles_img = (p.hw_img + g.bm - 1) / g.bm;
         tiles = (unsigned long long)(p.M / p.hw_img) * p.tiles_img * p.ntn;

@@ -302,14 +302,6 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
         p.ogate = reinterpret_cast<const half_t*>(a.in2.ptr);
         p.ogate_ld = a.in2.ld;
     }
-    p.gap_part = nullptr; p.gap_slots = 0;
-    if (a.flags & F_GAPSUM) {
-        // out2 = fp32 partial sums [n][slots][1][Np] (dense), conv_gemm_kernel's unmasked 1x1 form only (launch_conv_gemm checks the rest)
-        if ((a.flags & (F_DOT1 | F_TAIL2 | F_UP2HEAD | F_PW | F_COL | F_PATCH | F_STEM | F_DWPRE | F_HILO)) || !a.dot_out.ptr || a.dot_out.esize != 4
-            || a.dot_out.n != a.in.n || a.dot_out.c != a.Np || a.dot_out.ld != a.Np || a.wl_out) return VSE_E_INVAL;
-        p.gap_part = reinterpret_cast<float*>(a.dot_out.ptr);
-        p.gap_slots = a.dot_out.h;
-    }
     p.u8src = a.u8src; p.u8_h = a.u8_h; p.u8_w = a.u8_w; p.u8_pitch = a.u8_pitch; p.u8_fstride = a.u8_fstride;
     if ((a.flags & F_U8SRC) && (!(a.flags & F_STEM) || !a.u8src || a.u8_h <= 0 || a.u8_w <= 0)) return VSE_E_INVAL;
     if (a.wl_out && (a.flags & (F_DOT1 | F_SRC2 | F_UP2HEAD | F_PIXSHUF))) return VSE_E_UNSUPPORTED;   // no per-sample width in these forms
@@ -337,7 +329,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
         const int rc = launch_conv_gemm(p, a.Kp, st);
         if (rc != VSE_E_UNSUPPORTED) return rc;
     }
-    if (a.flags & (F_WK32 | F_GAPSUM)) return VSE_E_UNSUPPORTED;     // 32-deep weight tiles / pool partial sums: conv_gemm_kernel only
+    if (a.flags & F_WK32) return VSE_E_UNSUPPORTED;     // 32-deep weight tiles are read by conv_gemm_kernel only
     const int bn = conv_tile_bn(a.Np);
     dim3 block(256);
     const int bm = bn == 128 ? 128 : 256;

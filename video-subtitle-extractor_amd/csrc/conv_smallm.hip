@@ -78,7 +78,7 @@ __global__ __launch_bounds__(64) void conv_smallm_hl_kernel(const ConvParams p) 
 // Layers this kernel serves: conv_gemm_kernel's unmasked 1x1 mode (mode 2) at stride 1 with at most 256 pixels, one weight stream.
 bool conv_smallm_shape_ok(int mode, long M, int sh, int sw, int same_hw, int flags, int cinp) {
     static const bool on = [] { const char* e = vse_dev_getenv("VSE_SMALLM"); return !(e && e[0] == '0'); }();
-    return on && mode == 2 && M <= 256 && sh == 1 && sw == 1 && same_hw && !(flags & (F_IMGW | F_PIXSHUF | F_DOT1 | F_SRC2 | F_GAPSUM)) && (cinp & 15) == 0;
+    return on && mode == 2 && M <= 256 && sh == 1 && sw == 1 && same_hw && !(flags & (F_IMGW | F_PIXSHUF | F_DOT1 | F_SRC2)) && (cinp & 15) == 0;
 }
 bool conv_smallm_ok(const ConvParams& p, int mode) {
     return conv_smallm_shape_ok(mode, p.M, p.sh, p.sw, p.H == p.OH && p.W == p.OW && p.Hs == p.H && p.Ws == p.W, p.flags, p.cinp);

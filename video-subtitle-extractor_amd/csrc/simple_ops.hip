@@ -403,28 +403,6 @@ __global__ void gap_finish_kernel(const float* __restrict__ part, TView out, int
     }
 }
 
-// F_GAPSUM: the partial sums [n][splits][c] were written by the producing conv's epilogue (conv_gemm.hip, one slot per 128 pixels):
-// grid (n, ceil(c / 64)); block = 4 slot lanes x 64 channels; lane q adds slots q, q + 4, ... (eight loads in flight), the four lane sums
-// are added in lane order — a fixed order.
-__global__ __launch_bounds__(256) void gap_finish2_kernel(const float* __restrict__ part, TView out, int splits, float inv_hw) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int n = blockIdx.x, c = blockIdx.y * 64 + cl;
-    const int cc = min(c, out.c - 1);
-    const float* src = part + (long)n * splits * out.c + cc;
-    float s = 0.f;
-    for (int k0 = q; k0 < splits; k0 += 32) {
-        float t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = src[(long)min(k0 + 4 * u, splits - 1) * out.c];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += (k0 + 4 * u < splits) ? t[u] : 0.f;
-    }
-    red[q][cl] = s;
-    __syncthreads();
-    if (q == 0 && c < out.c) reinterpret_cast<half_t*>(out.ptr)[(long)n * out.ld + c] = (half_t)((((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl]) * inv_hw);
-}
-
 // Ragged batches: the same pool with a summation order that depends on the pixel's (row, column) only — never on the width of
 // the batch tensor: grid (n, ceil(cg/8), h); lane pl of a block sums columns pl, pl + 32, ... of ROW blockIdx.z up to the
 // sample's own width, the 32 lane sums are added in lane order, gap_rows_finish adds the rows in order and divides by
@@ -980,12 +958,6 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
         case OP_GAP: {
             if ((in0.c & 7) || out.c != in0.c || in2.ptr == nullptr) return VSE_E_INVAL;
             const int splits = in2.h;   // scratch view [n, splits, 1, c] fp32
-            if (op.flags & F_GAPSUM) {   // the producing conv wrote the partial sums (one slot per 128 pixels): the finishing pass only
-                if (wl_in != nullptr || splits != (in0.h * in0.w + 127) / 128 || in2.c != in0.c || in2.ld != in0.c) return VSE_E_INVAL;
-                hipLaunchKernelGGL(gap_finish2_kernel, dim3(in0.n, (in0.c + 63) / 64), dim3(256), 0, st,
-                                   reinterpret_cast<const float*>(in2.ptr), out, splits, 1.f / ((float)in0.h * in0.w));
-                break;
-            }
             if (wl_in != nullptr) {      // ragged batch: row-structured sums (one split per row), per-sample divisor
                 if (splits != in0.h) return VSE_E_INVAL;
                 hipLaunchKernelGGL(gap_rows_kernel, dim3(in0.n, (in0.c + 63) / 64, in0.h), dim3(256), 0, st, in0,

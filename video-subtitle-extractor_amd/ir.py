@@ -91,9 +91,6 @@ F_ONECH = 32768     # OP_CONV with F_PIXSHUF | F_OUT_F32 and ONE real cout: the 
 F_HLSUM = 524288    # OP_CONV | F_COL, 3x3, <= 32 couts of a hi + lo net (the mobile detectors' 96 -> 24 neck convs): ONE pass over K with the lo
                     # weights as 32 more weight rows of a 64-row stage ([3 dy][hi 32 | lo 32][16]); conv_c3_kernel adds its two 32-cout
                     # accumulator tiles in the epilogue (instead of walking the patch chunks twice over a half-empty 32-cout tile)
-F_GAPSUM = 2097152  # OP_CONV (1x1 on conv_gemm_kernel, M tiles aligned to images): the global average pool that reads this conv's output starts in its
-                    # epilogue — out2 = fp32 partial sums [n][ceil(h w / 128)][1][C] of the fp16 values stored as `out`, one slot per 128 output
-                    # pixels of an image (fixed summation order).  OP_GAP | F_GAPSUM: in2 = those partial sums; only the finishing pass runs
 F_TAIL2 = 1048576   # OP_CONV | F_PW | F_PIXSHUF (2x2 s2 transposed conv c0 -> c1): a SECOND 2x2 s2 transposed conv c1 -> 1 (+ activation) is applied to
                     # the fp16 values stored as `out`, in the same launch (conv_pw_tail_kernel): out2 = the dense fp16 map [n, 4h, 4w] (ld 1),
                     # aux_off = stage B's MFMA A fragments [4 c1p / 16][2][16][8] fp16, f[FS_PRE_B] = its bias, p[P_DOTACT] = its activation
