@@ -108,6 +108,10 @@ CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (160, 72, (5, 5), (1, 1), (2, 2), 10, 12, 1),      # 25 taps, map too small for the patch kernel
     (32, 48, (2, 2), (2, 2), (0, 0), 18, 22, 2),       # even kernel, no padding
     (64, 200, (1, 1), (2, 2), (0, 0), 19, 27, 1),      # strided 1x1, cout tail inside the second tile
+    # small 1x1 problems on conv_smallm_kernel (<= 256 input channels of any multiple of 8, <= 4096 wave tiles: the SVTR necks)
+    (120, 360, (1, 1), (1, 1), (0, 0), 1, 112, 40),    # 7.5 K slices: the upper half of the last slice is masked; 140 x 12 wave tiles
+    (240, 136, (1, 1), (1, 1), (0, 0), 3, 50, 7),      # 15 slices = two rounds of loads; cout tail (136 = 4 x 32 + 8), pixel tail
+    (72, 200, (1, 1), (1, 1), (0, 0), 5, 13, 3),       # more than 64 input channels, half slice (72 = 4.5 x 16)
     # conv_stem_kernel (3x3 over <= 4 real channels; the 1x1 in front keeps 3 channels)
     (3, 64, (3, 3), (2, 2), (1, 1), 37, 70, 2),        # stride 2, odd map, row / column tile tails
     (3, 16, (3, 3), (2, 2), (1, 1), 48, 64, 1),        # 16 couts (mobile stems): second cout tile idle

@@ -338,6 +338,8 @@ int conv_gemm_config(int Np, int cinp, long M);
 // 1x1 conv over <= 256 pixels, operands straight from global memory (conv_smallm.hip); `mode` = conv_gemm_mode()
 bool conv_smallm_ok(const ConvParams& p, int mode);
 bool conv_smallm_shape_ok(int mode, long M, int sh, int sw, int same_hw, int flags, int cinp);
+bool conv_smallk_ok(const ConvParams& p);
+bool conv_smallk_shape_ok(int kh, int kw, int sh, int sw, int ph, int pw, int inshift, int same_hw, int flags, int cinp, long M, int Np);
 int launch_conv_smallm(const ConvParams& p, hipStream_t st);   // index into the tile-configuration table of conv_gemm.hip
 int conv_gemm_mode(int kh, int kw, int sh, int sw, int ph, int pw, int cinp, int Kp, int inshift, int flags);
 int conv_patch_th(int kh, int kw, int OH, int bn);

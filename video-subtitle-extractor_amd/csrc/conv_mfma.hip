@@ -324,6 +324,10 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
     if (a.flags & F_COL) return (p.kh == 3 && p.kw == 3) ? launch_conv_c3(p, a.in.n, st) : launch_conv_col(p, a.in.n, st);
     if (a.flags & F_PATCH) return launch_conv_patch(p, a.in.n, st);
     if (a.Kp % 64) return VSE_E_INVAL;
+    if (conv_smallk_ok(p)) {                             // a small 1x1 problem: one wave per 32 x 32 tile, all loads in flight (conv_smallm.hip)
+        p.nkh = a.Kp / ((a.flags & F_WK32) ? 32 : 64);
+        return launch_conv_smallm(p, st);
+    }
     static const bool use_gemm = [] { const char* e = vse_dev_getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
     if (use_gemm) {
         const int rc = launch_conv_gemm(p, a.Kp, st);

@@ -35,7 +35,7 @@ __device__ __forceinline__ void conv_smallm_body(const ConvParams& p, float* sbi
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const half8 zero8 = half8{0, 0, 0, 0, 0, 0, 0, 0};
-    const int nslice = p.cinp >> 4;
+    const int nslice = (p.cinp + 15) >> 4;                   // (cinp % 16 == 8: the upper half of the last slice lies behind the pixel's channels: zeros)
     // (hi pass, then lo pass over the same activations into the same accumulator: conv_gemm_kernel's two-pass K walk, identical bits)
 #pragma unroll 1
     for (int pass = 0; pass < (HILO ? 2 : 1); ++pass) {
@@ -45,7 +45,7 @@ __device__ __forceinline__ void conv_smallm_body(const ConvParams& p, float* sbi
 #pragma unroll
             for (int u = 0; u < SM_UNROLL; ++u) {
                 const int k = (s0 + u) << 4;
-                const bool live = s0 + u < nslice;
+                const bool live = k + fj * 8 < p.cinp;
                 wf[u] = (live && wok) ? *reinterpret_cast<const half8*>(wp + (long)(k / KT) * wstep + (k % KT)) : zero8;
                 xf[u] = (live && xok) ? *reinterpret_cast<const half8*>(xl + k) : zero8;
             }
@@ -83,8 +83,23 @@ bool conv_smallm_shape_ok(int mode, long M, int sh, int sw, int same_hw, int fla
 bool conv_smallm_ok(const ConvParams& p, int mode) {
     return conv_smallm_shape_ok(mode, p.M, p.sh, p.sw, p.H == p.OH && p.W == p.OW && p.Hs == p.H && p.Ws == p.W, p.flags, p.cinp);
 }
+// ... and (round 5) SMALL 1x1 PROBLEMS whatever their route would be: <= 256 input channels (any multiple of 8: the SVTR necks' 120 / 240
+// are not multiples of 32 and ran on the 128 x 128 tile of conv_mfma_kernel), <= 4096 (32-cout x 32-pixel) wave tiles — a recogniser
+// sequence's [crops, 1, T, 120] layers.  Such a launch is a handful of K steps behind a prologue and in front of an epilogue on 13-50 of
+// 256 CUs (13-23 us launch to launch); here every wave is its own block with ALL its loads in flight at once.  Same K order, same bits.
+bool conv_smallk_shape_ok(int kh, int kw, int sh, int sw, int ph, int pw, int inshift, int same_hw, int flags, int cinp, long M, int Np) {
+    static const bool on = [] { const char* e = vse_dev_getenv("VSE_SMALLK"); return !(e && e[0] == '0'); }();
+    return on && kh == 1 && kw == 1 && sh == 1 && sw == 1 && ph == 0 && pw == 0 && !inshift && same_hw && cinp > 0 && cinp <= 256 && (cinp & 7) == 0
+           && !(flags & (F_IMGW | F_PIXSHUF | F_DOT1 | F_SRC2 | F_PATCH | F_COL | F_PW | F_STEM | F_UP2HEAD | F_DWPRE | F_ONECH | F_TAIL2 | F_HLSUM))
+           && M > 0 && ((M + 31) / 32) * ((Np + 31) / 32) <= 4096;
+}
+bool conv_smallk_ok(const ConvParams& p) {
+    return conv_smallk_shape_ok(p.kh, p.kw, p.sh, p.sw, p.ph, p.pw, p.inshift, p.H == p.OH && p.W == p.OW && p.Hs == p.H && p.Ws == p.W, p.flags, p.cinp,
+                                p.M, p.Np);
+}
 
 int launch_conv_smallm(const ConvParams& p, hipStream_t st) {
+    if ((p.M + 31) / 32 > 65535) return VSE_E_UNSUPPORTED;
     const dim3 grid((unsigned)((p.Np + 31) / 32), (unsigned)((p.M + 31) / 32)), block(64);
     if (p.flags & F_HILO) {
         if (p.flags & F_WK32) hipLaunchKernelGGL((conv_smallm_hl_kernel<32>), grid, block, 0, st, p);

@@ -422,6 +422,12 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     }
     // conv_gemm_kernel configuration c, MASK m -> 200000 + 10*c + m; conv_mfma_kernel<.., UPS> -> 10000*UPS + BN
     static const bool use_gemm = [] { const char* e = vse_dev_getenv("VSE_CONV_GEMM"); return !(e && e[0] == '0'); }();
+    {
+        long m = (long)o.out.n * o.out.h * o.out.w;
+        if (conv_smallk_shape_ok(o.p[P_KH], o.p[P_KW], o.p[P_SH], o.p[P_SW], o.p[P_PH], o.p[P_PW], o.p[P_INSHIFT], o.in0.h == o.out.h && o.in0.w == o.out.w, o.flags,
+                                 o.p[P_CINP], m, o.p[P_COUT]))
+            return 900000 + ((o.flags & F_WK32) ? 32 : 64) + ((o.flags & F_HILO) ? 1000 : 0);   // conv_smallm_kernel<KT> (small 1x1 problems)
+    }
     const int mode = use_gemm ? conv_gemm_mode(o.p[P_KH], o.p[P_KW], o.p[P_SH], o.p[P_SW], o.p[P_PH], o.p[P_PW], o.p[P_CINP],
                                                o.p[P_KTOT], o.p[P_INSHIFT], o.flags) : 0;
     if (mode) {
