@@ -186,7 +186,20 @@ def main():
     backend = os.environ.get("VSE_DIST_BACKEND", "nccl")
     if "VSE_BENCH_DEVICE" in os.environ:
         local = int(os.environ["VSE_BENCH_DEVICE"])
-    if world > 1:
+    # VSE_FORCE_DIST=1 on ONE rank: the process group is initialised anyway and every collective of the N > 1 path (mode vote
+    # all_reduce, probe gather, barriers, all_reduce(MAX) of the times, size all_gather + payload gather) executes on a world of one
+    # — how a one-GPU box runs RCCL communicator init and the device-tensor collectives the 8-GPU job takes (tests/test_gpu_bench.py)
+    dist_on = world > 1 or os.environ.get("VSE_FORCE_DIST", "0") == "1"
+    if dist_on and world == 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            free_port = sk.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -204,17 +217,19 @@ def main():
     coll_dev = ctx.tdev if backend == "nccl" else "cpu"
     # gather vs all_gather for the record exchange: agreed by all ranks here, once, never inside the timed region (parallel.gather_mode)
     gmode = parallel.gather_mode(coll_dev)
-    if world > 1 and rank == 0:
+    if dist_on and rank == 0:
         print(f"[bench] record exchange: {gmode} (agreed by all {world} ranks)", file=sys.stderr, flush=True)
 
     def sync():
-        if world > 1:
+        if dist_on:
             dist.barrier()
+            parallel._count("barrier")
         torch.cuda.synchronize()
 
     # One workload = (model pair, frame size, frames per step): everything the timed region needs, built and resident before
     # it starts.  The headline is build(args...) below; `config.secondary` (north_star: "1080p AND 4K frame batches"; the
     # reference's default fast mode) times two more workloads with the same functions, a few steps each.
+    args.dist_on, args.dist_backend = dist_on, backend
     W = build_workload(args, ctx, world, rank, coll_dev, sync, log, args.models, args.height, args.width, args.batch)
     pipe, det, rec, det_id, rec_id, lang = W.pipe, W.det, W.rec, W.det_id, W.rec_id, W.lang
     frames_np, truth, overlay_np, overlay, quads = W.frames_np, W.truth, W.overlay_np, W.overlay, W.quads
@@ -357,9 +372,10 @@ def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, 
         out = run_steps(steps)
         sync()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if args.dist_on:
             tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            parallel._count("all_reduce")
             dt = float(tmax.item())
         return out, dt
 
@@ -420,10 +436,15 @@ def finish(args, ctx, world, rank, W, out, dt, log, host_threads, build_secondar
                        "frames_per_gpu_step": args.batch, "det_model": det_id, "rec_model": rec_id,
                        "weights": "real" if modelzoo.has_real_weights(det_id) else "seeded random (reference blobs missing)",
                        "gather": "one variable-length gather of all ranks' records to rank 0 at the end of the timed region"
-                                 + (f" ({parallel.gather_mode(None if world == 1 else W.coll_dev)}, agreed by all ranks at start-up)" if world > 1 else ""),
+                                 + (f" ({parallel.gather_mode(W.coll_dev)}, agreed by all ranks at start-up)" if args.dist_on else ""),
                        "host_threads_per_rank": host_threads if host_threads else "uncapped (1 rank)",
                        "records_gathered": len(out) if out is not None else 0},
         }
+        if args.dist_on:
+            # which collectives this rank issued so far (start-up vote + probe, the barriers and time reductions of every timed block,
+            # the record exchange of every run_steps call); world 1 + VSE_FORCE_DIST=1 = the one-GPU rehearsal of the N > 1 path
+            result["config"]["dist"] = {"backend": args.dist_backend, "world": world, "forced_on_one_rank": world == 1,
+                                        "collective_device": str(W.coll_dev), "collectives": dict(parallel.COLLECTIVES)}
         if not args.no_roofline:
             def profile_pass():                                  # the work of `span` steps, sequential, every op timed
                 ready = []
@@ -471,9 +492,10 @@ def finish(args, ctx, world, rank, W, out, dt, log, host_threads, build_secondar
             cs = P.standin_charset(shim._ncls(rec[0])) if lang != "en" else P.en_charset()
             result["cpu_baseline"] = cpu_baseline(args, frames_np, truth, det, rec, cs, overlay_np)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if args.dist_on:
         dist.barrier()
         dist.destroy_process_group()
+        parallel.reset_gather_mode()
     return result
 
 

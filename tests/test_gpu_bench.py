@@ -43,6 +43,25 @@ def test_bench_two_ranks_one_json_line(ctx):
     assert one["config"]["boxes_last_step"] > 0
 
 
+def test_bench_one_rank_runs_every_collective_of_the_path_over_rccl(ctx):
+    """no multi-GPU node is in reach, so RCCL's first contact would be the driver's 8-GPU run.  VSE_FORCE_DIST=1
+    makes ONE rank initialise the process group with backend "nccl" (= RCCL on ROCm) and take the N > 1 branches: communicator init
+    bound to the device, the mode vote (all_reduce on a device tensor + .item()), the probe gather, the barrier inside sync(), the
+    all_reduce(MAX) of the ranks' times, the size all_gather and the ONE payload gather of the records (parallel.gather_records on
+    device tensors) — each executes on an MI355X, on a world of one.  The 1 -> 8 curve stays unmeasured."""
+    env = dict(os.environ, VSE_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("VSE_DIST_BACKEND", None)
+    flags = ["--steps", "2", "--warmup", "1", "--batch", "16", "--no-cpu-baseline", "--no-roofline", "--no-secondary", "--other-mode-steps", "0"]
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + flags, env)
+    d = one["config"]["dist"]
+    assert d["backend"] == "nccl" and d["world"] == 1 and d["forced_on_one_rank"] and d["collective_device"].startswith("cuda")
+    c = d["collectives"]
+    # vote 1 + time reductions 2 (warm-up block is untimed: one per timed() call) | probe 1 + payload per run_steps call 2 | sizes 2 | barriers 2 per timed()
+    assert c["all_reduce"] >= 2 and c["gather"] >= 3 and c["all_gather"] >= 2 and c["barrier"] >= 2, c
+    assert one["n_gpus"] == 1 and one["config"]["records_gathered"] == 16 * 2 and one["config"]["boxes_last_step"] > 0
+    assert "gather" in one["config"]["gather"]
+
+
 @pytest.mark.parametrize("det_id,rec_id,H,W,nf", [("V4_ch_det", "V4_ch_rec", 1080, 1920, 4), ("V4_ch_det_fast", "V4_ch_rec_fast", 1080, 1920, 4),
                                                   ("V4_ch_det", "V4_ch_rec", 2160, 3840, 2)])
 def test_bench_configuration_c2_against_the_oracle_in_one_piece(ctx, det_id, rec_id, H, W, nf):

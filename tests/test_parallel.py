@@ -111,17 +111,66 @@ def test_gather_mode_is_agreed_collectively_even_when_one_rank_forces_the_fallba
         assert got[0][3] == list(range(9)) and got[1][3] is None
 
 
-def test_gather_mode_rejects_an_unknown_override(monkeypatch):
-    import pytest
+def _worker_bad_override(rank, world, port, q, bad_rank):
     import torch.distributed as dist
-    monkeypatch.setenv("VSE_GATHER", "broadcast")
-    assert parallel.gather_mode() == "local"                     # no process group: nothing to decide
-    monkeypatch.setattr(dist, "is_initialized", lambda: True)
-    monkeypatch.setattr(dist, "get_world_size", lambda: 2)
-    monkeypatch.setattr(dist, "get_rank", lambda: 0)
-    monkeypatch.setattr(dist, "get_backend", lambda: "gloo")
-    with pytest.raises(ValueError):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("VSE_GATHER", None)
+    if rank == bad_rank:
+        os.environ["VSE_GATHER"] = "broadcast"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
         parallel.gather_mode()
+        q.put((rank, "no error"))
+    except ValueError as exc:
+        q.put((rank, str(exc)))
+    dist.barrier()                       # both ranks are still in step: nobody is stuck in the vote's all_reduce
+    dist.destroy_process_group()
+
+
+def test_gather_mode_rejects_an_unknown_override_on_every_rank():
+    """an invalid VSE_GATHER on ONE rank must not raise before the collective (the other rank would wait in the
+    all_reduce until the backend's timeout): the invalid value is a vote (-1) and BOTH ranks raise behind the all_reduce."""
+    assert parallel.gather_mode() == "local"                     # no process group: nothing to decide
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker_bad_override, args=(r, 2, port, q, 1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert "another rank" in got[0] and "'broadcast'" in got[1], got
+
+
+def _worker_world1_forced(q, port):
+    """VSE_FORCE_DIST=1: a world of ONE runs the whole collective sequence (what bench.py does on a one-GPU box with RCCL)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VSE_FORCE_DIST="1")
+    os.environ.pop("VSE_GATHER", None)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    assert parallel.dist_active()
+    mode = parallel.gather_mode()
+    recs = [(f, np.full((1, 4, 2), f, np.float32), [(f"t{f}", 0.5)]) for f in (2, 0, 1)]
+    out = parallel.gather_records(recs)
+    q.put((mode, [r[0] for r in out], dict(parallel.COLLECTIVES)))
+    dist.destroy_process_group()
+    parallel.reset_gather_mode()
+
+
+def test_world_of_one_runs_the_collectives_when_forced():
+    assert not parallel.dist_active()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_world1_forced, args=(q, 35500 + (os.getpid() % 2000)))
+    p.start()
+    mode, frames, calls = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    assert mode == "gather" and frames == [0, 1, 2]
+    assert calls == {"all_reduce": 1, "gather": 2, "all_gather": 1}, calls     # vote, probe + payload, sizes
 
 
 # ---- eight ranks on one node: the HOST side of a step under the per-rank thread cap ---------------------------------------

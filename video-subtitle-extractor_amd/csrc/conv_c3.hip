@@ -37,6 +37,18 @@
 // the LDS-DMAs, so the first counted waits of the next tile also wait for the stores' HBM round trip.)
 #define C3RING 4
 #define C3BN 64
+// Timing-only ablations for the Winograd F(2x2, 3x3) go / no-go (EXPERIMENTS G; results are WRONG, never in a product build):
+//   VSE_C3_ABL = 1: 16 of the 36 MFMAs per chunk and wave (the MFMA count of the 16 frequency GEMMs over the same outputs), every DMA,
+//                   fragment read, wait and barrier unchanged — an UPPER bound for a Winograd form inside this skeleton (its 16 / 9 x
+//                   larger weight stream, input transform and output transform all cost extra);
+//   VSE_C3_ABL = 2: + 128 v_pk_add_f16 per chunk and wave (the packed adds of B^T d B on 8-channel fragments).
+#ifndef VSE_C3_ABL
+#define VSE_C3_ABL 0
+#endif
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+#if VSE_C3_ABL && !defined(VSE_DEV_BUILD)
+#error "VSE_C3_ABL is a development-build ablation"
+#endif
 
 // BN = 64 couts per block (TN = 2 accumulator tiles per row) or, for layers with <= 32 couts (the mobile detectors' 96 -> 24 neck convs,
 // the server detector's 32 -> 32), BN = 32: half the MFMAs, half the weight stage; everything else is the same code.
@@ -252,12 +264,27 @@ __device__ __forceinline__ void conv_c3_body(const ConvParams& p) {
             for (int j = 0; j < TN; ++j) Wn[j] = *reinterpret_cast<const half8*>(ldsb + wv + j * 1024 + 2 * BN * 32);
             Xn = *reinterpret_cast<const half8*>(ldsb + xo + 3 * ROWB);
             __builtin_amdgcn_sched_group_barrier(0x100, TN + 1, 0);
+            if (!VSE_C3_ABL || dx == 0) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[j], X0, acc[0][j], 0, 0, 0);
                 acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[j], X1, acc[1][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
+            } else {                                     // ablation: the fragments stay read (kept alive), no matrix work
+                asm volatile("" :: "v"(X0), "v"(Wc[0]));
+            }
+#if VSE_C3_ABL == 2
+            {
+                unsigned t0 = __builtin_bit_cast(uint4v, X0)[0], t1 = __builtin_bit_cast(uint4v, X0)[1], t2 = __builtin_bit_cast(uint4v, X1)[2], t3 = __builtin_bit_cast(uint4v, X1)[3];
+#pragma unroll
+                for (int r = 0; r < (dx == 0 ? 11 : 10); ++r) {          // 4 x (11 + 10 + 10) + ... ~ 128 packed adds per chunk
+                    asm volatile("v_pk_add_f16 %0, %0, %1\n\tv_pk_add_f16 %1, %1, %2\n\tv_pk_add_f16 %2, %2, %3\n\tv_pk_add_f16 %3, %3, %0"
+                                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                }
+                asm volatile("" :: "v"(t0), "v"(t1), "v"(t2), "v"(t3));
+            }
+#endif
             X0 = X1; X1 = Xn;
 #pragma unroll
             for (int j = 0; j < TN; ++j) Wc[j] = Wn[j];
@@ -270,12 +297,16 @@ __device__ __forceinline__ void conv_c3_body(const ConvParams& p) {
             Xn = *reinterpret_cast<const half8*>(ldsb + xno + ROWB);
             __builtin_amdgcn_sched_group_barrier(0x100, TN + 2, 0);
 #endif
+            if (!VSE_C3_ABL) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[j], X0, acc[0][j], 0, 0, 0);
                 acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Wc[j], X1, acc[1][j], 0, 0, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * TN, 0);
+            } else {
+                asm volatile("" :: "v"(X0), "v"(X1), "v"(Wc[0]));
+            }
 #if VSE_C3_XPRE
             X0 = Xn0; X1 = Xn;
 #pragma unroll

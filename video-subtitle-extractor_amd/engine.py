@@ -321,6 +321,7 @@ class Net:
         self.wbytes = 0
         self.ws = {}          # one workspace per plan: plans of one net may run concurrently on different streams
         self.ws_budget = int(float(os.environ.get("VSE_WS_BUDGET_GB", "64")) * (1 << 30))     # per net; LRU beyond it
+        self.ws_evictions = 0 # workspaces dropped by that LRU so far (tools/soak.py reports it)
 
     def program(self, n, h, w):
         key = (n, h, w)
@@ -393,6 +394,7 @@ class Net:
                 t.cuda.synchronize(self.ctx.tdev)
                 while self.ws and total + need > self.ws_budget:
                     total -= int(self.ws.pop(next(iter(self.ws))).numel())
+                    self.ws_evictions += 1
             ws = t.zeros(need, dtype=t.uint8, device=self.ctx.tdev)
         self.ws[k] = ws                       # (re-)inserted last: dict order = least recently used first
         return ws

@@ -84,7 +84,42 @@ def unpack_records(buf):
     return recs
 
 
-_GATHER_MODE = {}          # (backend, world, rank, id of the default process group) -> "gather" | "all_gather"
+_GATHER_MODE = {}          # token of the default process group -> "gather" | "all_gather"
+COLLECTIVES = {}           # name -> calls issued by this module / counted by its callers (bench.py reports them)
+
+
+def _count(name):
+    COLLECTIVES[name] = COLLECTIVES.get(name, 0) + 1
+
+
+def dist_active():
+    """Is there an exchange step to run?  Yes with more than one rank — and with ONE rank when VSE_FORCE_DIST=1: the whole
+    collective sequence (all_reduce vote, probe gather, size all_gather, payload gather, barrier) then runs on a world of one, which
+    is how a one-GPU box executes the RCCL code path the 8-GPU job takes (tests/test_gpu_bench.py)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("VSE_FORCE_DIST", "0") == "1"
+
+
+def _group_token():
+    """Identifies THIS initialisation of the default process group: the group object carries the token, so a group destroyed and
+    re-created in one process (whose id() may be reused) never inherits the previous group's cached decision."""
+    import torch.distributed as dist
+    g = dist.group.WORLD
+    tok = getattr(g, "_vse_token", None)
+    if tok is None:
+        tok = object()
+        try:
+            g._vse_token = tok
+        except AttributeError:            # a group type without a __dict__: fall back to (id, backend, world), cleared by reset()
+            return (id(g), dist.get_backend(), dist.get_world_size())
+    return tok
+
+
+def reset_gather_mode():
+    """Forget every cached decision (call next to dist.destroy_process_group())."""
+    _GATHER_MODE.clear()
 
 
 def gather_mode(device=None):
@@ -92,30 +127,39 @@ def gather_mode(device=None):
     receives world x the payload and drops it) — decided ONCE per process group, COLLECTIVELY, before any timed region:
     every rank votes from static knowledge only (the backend's name; VSE_GATHER=gather|all_gather overrides a rank's vote), the
     votes are combined with all_reduce(MIN) — a collective every backend has — so all ranks leave with the same answer even when
-    only one of them asked for the fallback.  When the answer is "gather" the ranks then run one 8-byte gather as a start-up
-    check; an error there PROPAGATES (with the remedy in its message).  Nothing is ever decided by catching an exception in the
-    middle of the exchange: a rank-local failure there would leave the ranks in different collectives (VERDICT r4 #7)."""
+    only one of them asked for the fallback.  An INVALID override is a vote too (-1): it travels through the same all_reduce and
+    every rank raises afterwards — a rank that raised before the collective would leave the others waiting in it.  When the answer
+    is "gather" the ranks then run one 8-byte gather as a start-up check; an error there PROPAGATES (with the remedy in its
+    message).  Nothing is ever decided by catching an exception in the middle of the exchange: a rank-local failure there would
+    leave the ranks in different collectives (VERDICT r4 #7)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not dist_active():
         return "local"
     backend, world, rank = dist.get_backend(), dist.get_world_size(), dist.get_rank()
-    key = (backend, world, rank, id(dist.group.WORLD))
+    key = _group_token()
     if key in _GATHER_MODE:
         return _GATHER_MODE[key]
     dev = device if device is not None else ("cuda" if backend == "nccl" else "cpu")
     want = os.environ.get("VSE_GATHER", "").strip().lower()
     if want not in ("", "gather", "all_gather"):
-        raise ValueError(f"VSE_GATHER={want!r}: expected 'gather' or 'all_gather'")
-    vote = 0 if want == "all_gather" else (1 if want == "gather" or backend in ("nccl", "gloo") else 0)
+        vote = -1
+    else:
+        vote = 0 if want == "all_gather" else (1 if want == "gather" or backend in ("nccl", "gloo") else 0)
     v = torch.tensor([vote], dtype=torch.int32, device=dev)
     dist.all_reduce(v, op=dist.ReduceOp.MIN)
-    mode = "gather" if int(v.item()) == 1 else "all_gather"
+    _count("all_reduce")
+    agreed = int(v.item())
+    if agreed < 0:
+        raise ValueError("VSE_GATHER: expected 'gather' or 'all_gather'" + (f", this rank has {want!r}" if vote < 0 else
+                         " (another rank's value is invalid)"))
+    mode = "gather" if agreed == 1 else "all_gather"
     if mode == "gather":
         probe = torch.full((8,), rank, dtype=torch.uint8, device=dev)
         got = [torch.zeros(8, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
         try:
             dist.gather(probe, got, dst=0)
+            _count("gather")
         except Exception as exc:
             raise RuntimeError(f"the start-up probe of dist.gather failed on rank {rank} (backend {backend}): set VSE_GATHER=all_gather on "
                                f"every rank to use the all_gather form of the record exchange") from exc
@@ -131,7 +175,7 @@ def gather_records(records, device=None, to_all=False):
     gather vs all_gather: gather_mode() (decided once per process group; call it before a timed region — bench.py does)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not dist_active():
         return sorted(records, key=lambda r: r[0])
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -140,17 +184,20 @@ def gather_records(records, device=None, to_all=False):
     size = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sizes, size)
+    _count("all_gather")
     mx = int(max(int(s.item()) for s in sizes))
     buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
     buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
     if mode == "all_gather":
         bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)]
         dist.all_gather(bufs, buf)
+        _count("all_gather")
     else:
         # north_star: "RCCL ... only for the final box/text gather" — a gather to rank 0: the other ranks send their padded
         # buffer once and receive nothing (an all_gather would deliver world x the payload to ranks that drop it).  Errors propagate.
         bufs = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
         dist.gather(buf, bufs, dst=0)
+        _count("gather")
     if rank != 0 and not to_all:
         return None
     out = []
