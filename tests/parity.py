@@ -26,18 +26,41 @@ import numpy as np
 # dlog: |delta log p| over all classes with oracle p > 1e-12 (dlog_median: its median); dlog_top: over the oracle's top-5 classes of a
 # step; maxp_rel: relative error of a step's largest probability (what the CTC confidence averages); tie: oracle log-margin under which
 # a step's arg-max may flip
-TOL = {"default": dict(dlog=2.5e-1, dlog_median=3e-2, dlog_top=1.5e-1, maxp_rel=1.2e-1, tie=1e-1),
-       "V2": dict(dlog=5e-3, dlog_median=6e-4, dlog_top=3e-3, maxp_rel=3e-3, tie=5e-3)}
+# conf_diff: relative confidence difference allowed to a reachable-but-DIFFERENT string (measured <= 1.9e-2 over 14 such strings)
+TOL = {"default": dict(dlog=2.5e-1, dlog_median=3e-2, dlog_top=1.5e-1, maxp_rel=1.2e-1, tie=1e-1, conf_diff=5e-2),
+       "V2": dict(dlog=5e-3, dlog_median=6e-4, dlog_top=3e-3, maxp_rel=3e-3, tie=5e-3, conf_diff=5e-3)}
 
 
-def tol_for(mid):
-    return TOL["V2" if mid.startswith("V2_") else "default"]
+# The KERNEL legs: the bounds above are dominated by the rounding of the stand-in WEIGHTS to fp16.  oracle/ir_emul.py
+# executes the engine's own Program — the very fp16 (folded) weights the kernels read — on the CPU: with fp32 activations ("fp16w": what
+# is left is the engine's fp16 activation storage + its arithmetic) and with every stored tensor rounded to fp16 where the kernels round
+# ("stored": what is left is fp32 summation order and the transcendentals).  Measured on MI355X (round 6, test_gpu_nets / test_gpu_ragged):
+#   mobile recognisers (V4 fast, V3): max |dlog p| 3.5-4.9e-2, median 3.8-5.8e-3, top-5 2.1-3.7e-2, max-probability 1.8-2.4 % — BOTH legs;
+#   V4_ch_rec (server HGNet): 6.3-8.5e-2, 6.8-8.8e-3, 3.3-5.5e-2, 2.4-3.4 % — BOTH legs;   V2 (BiLSTM CRNN): 1.0-1.9e-3, 1.1-1.4e-4.
+# The "stored" leg is NOT tighter than the "fp16w" leg: a single 1-ulp fp16 difference anywhere in a stored tensor (two fp32 sums in
+# another order) is amplified by these random nets to the same 4-8e-2 at the output as rounding every activation — at NETWORK level the
+# nets' conditioning is the floor, and the kernels' own error is pinned where it can be isolated: test_gpu_nets.test_conv_shapes compares
+# every kernel family on single convs with the emulator (same fp16 weights, same fp16 storage): <= 4.7e-4 of the output range over 49
+# cases (bound 1.2e-3 = a fp16 ulp).  Bounds below: ~2 x (server) / 2.5 x the measured figures.
+_K_MOBILE = dict(dlog=1.2e-1, dlog_median=1.5e-2, dlog_top=9e-2, maxp_rel=6e-2, tie=5e-2)
+_K_SERVER = dict(dlog=1.7e-1, dlog_median=1.8e-2, dlog_top=1.1e-1, maxp_rel=7e-2, tie=6e-2)
+_K_V2 = dict(dlog=5e-3, dlog_median=4e-4, dlog_top=2e-3, maxp_rel=1.5e-3, tie=5e-3)
+TOL_KERNEL = {"fp16w": {"default": _K_MOBILE, "V4_ch_rec": _K_SERVER, "V2": _K_V2},
+              "stored": {"default": _K_MOBILE, "V4_ch_rec": _K_SERVER, "V2": _K_V2}}
 
 
-def check_rec_probs(mid, probs, ref, idx=None, maxp=None):
+def tol_for(mid, leg=None):
+    row = "V2" if mid.startswith("V2_") else "default"
+    if leg is None:
+        return TOL[row]
+    return TOL_KERNEL[leg].get(mid, TOL_KERNEL[leg][row])
+
+
+def check_rec_probs(mid, probs, ref, idx=None, maxp=None, leg=None):
     """probs, ref: [..., T, C] softmax outputs (engine, oracle); idx / maxp: the engine's device arg-max and max-probability [..., T].
-    Asserts the bounds of tol_for(mid); -> dict of the measured figures."""
-    tol = tol_for(mid)
+    leg: None = against the fp32 oracle on fp32 weights; "fp16w" / "stored" = against the CPU emulator of the engine program (kernel legs).
+    Asserts the bounds of tol_for(mid, leg); -> dict of the measured figures."""
+    tol = tol_for(mid, leg)
     probs = np.asarray(probs, np.float64)
     ref = np.asarray(ref, np.float64)
     assert probs.shape == ref.shape, (probs.shape, ref.shape)
@@ -89,12 +112,25 @@ def reachable(text, ref_probs, charset, tie):
     return any(j == len(text) for j, _ in states)
 
 
+CONF_DIFFS = []        # relative confidence differences of the reachable-but-different strings seen so far (tests print their maximum)
+
+
 def check_text(mid, text, score, ref_probs, charset, ref_text, ref_conf):
     """One recognised crop against the oracle's distribution: the string must be reachable through near-ties only; an identical string
-    must carry the oracle's confidence within the max-probability bound.  -> True when the strings are identical."""
+    must carry the oracle's confidence within the max-probability bound; a reachable-but-different string (a near-tie step went the
+    other way: one character more, fewer or other) within `conf_diff` (~2.5 x the measured maximum).  -> True when the strings are identical."""
     tol = tol_for(mid)
     assert reachable(text, ref_probs, charset, tol["tie"]), (mid, text, ref_text)
+    rel = abs(score - ref_conf) / max(ref_conf, 1e-12)
     if text == ref_text:
-        assert abs(score - ref_conf) <= tol["maxp_rel"] * max(ref_conf, 1e-12), (mid, score, ref_conf)
+        assert rel <= tol["maxp_rel"], (mid, score, ref_conf)
         return True
+    CONF_DIFFS.append(rel)
+    assert rel <= tol["conf_diff"], (mid, text, ref_text, score, ref_conf)
     return False
+
+
+def share_floor(nexact, nbox, floor, what=""):
+    """The share of exactly identical strings must not fall under `floor` (set per model pair from the measured share minus a margin:
+    a random-weight head flips a step wherever the oracle's top-2 log-margin is under the engine's error, so the share is not 1)."""
+    assert nbox > 0 and nexact >= floor * nbox - 1e-9, (what, nexact, nbox, floor)

@@ -16,13 +16,13 @@ CASES = [("V4_ch_det", (2, 3, 96, 160)), ("V4_ch_det", (1, 3, 128, 256)),    # 2
          ("V2_ch_rec", (2, 3, 32, 128))]
 
 
-def run_hip(ctx, desc, w, x, want_probs=True):
+def run_hip(ctx, desc, w, x, want_probs=True, with_net=False):
     import torch
     from vse_amd import engine
     net = engine.Net(ctx, desc, w, want_probs=want_probs)
     xt = torch.from_numpy(ir_emul.to_nhwc8(x).astype(np.float16)).cuda()
     outs = [o.cpu().numpy() for o in net.run(xt)]
-    return outs
+    return (outs, net) if with_net else outs
 
 
 @pytest.mark.parametrize("mid,shape", CASES)
@@ -39,7 +39,7 @@ def test_net_matches_oracle(ctx, mid, shape):
         x = np.random.default_rng(0).uniform(-1, 1, shape).astype(np.float32)
     x = x.astype(np.float16).astype(np.float32)
     ref = net_ref.run_graph(desc, w, x)[0].numpy()
-    outs = run_hip(ctx, desc, w, x)
+    outs, net = run_hip(ctx, desc, w, x, with_net=True)
     if "_det" in mid:
         got = outs[0][..., 0]
         r = ref[:, 0]
@@ -62,7 +62,16 @@ def test_net_matches_oracle(ctx, mid, shape):
         maxp = outs[-1][:, 0, :, 1]
         stats = check_rec_probs(mid, probs, ref, idx=idx, maxp=maxp)
         print(f"{mid} {shape}: " + ", ".join(f"{k} {v:.3g}" for k, v in stats.items()))
+        # the kernel legs: the SAME program (the engine's folded fp16 weights) on the CPU emulator — fp32 activations, then fp16 storage
+        # where the kernels store fp16: what the kernels themselves add, without the weight rounding that dominates the bound above
+        prog = net.program(x.shape[0], x.shape[2], x.shape[3])
+        for leg, rnd in (("fp16w", False), ("stored", True)):
+            emu = ir_emul.Emulator(prog, round_f16=rnd).run(ir_emul.to_nhwc8(x).astype(np.float16 if rnd else np.float32))[0][:, 0]
+            st = check_rec_probs(mid, probs, emu, idx=idx, maxp=maxp, leg=leg)
+            print(f"{mid} {shape} kernel leg {leg}: " + ", ".join(f"{k} {v:.3g}" for k, v in st.items()))
 
+
+KERNEL_LEG_CONV = 1.2e-3    # of the output range; measured <= 4.7e-4 over the 49 cases (MI355X, round 6): about one fp16 ulp
 
 CONVS = [  # cin, cout, k, stride, pad, h, w, n
     (3, 16, (3, 3), (2, 2), (1, 1), 33, 47, 2), (16, 40, (1, 1), (1, 1), (0, 0), 9, 13, 3),
@@ -143,11 +152,19 @@ def test_conv_shapes(ctx, cin, cout, k, s, p, h, w, n):
            "b1": rng.standard_normal(cout).astype(np.float32) * 0.1}
     x = rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float16).astype(np.float32)
     ref = net_ref.run_graph(desc, wts, x)[0].numpy()
-    got = run_hip(ctx, desc, wts, x)[0]
-    got = np.transpose(got, (0, 3, 1, 2))
+    outs, net = run_hip(ctx, desc, wts, x, with_net=True)
+    got = np.transpose(outs[0], (0, 3, 1, 2))
     assert got.shape == ref.shape
     err = np.abs(got - ref).max()
     assert err < 2e-2 * max(1.0, np.abs(ref).max()), err
+    # the kernel's own error, weight rounding excluded (ADVICE r5 / VERDICT r5 #5): the same two-op program on the CPU emulator with
+    # the engine's fp16 weights and fp16 storage of the intermediate tensor — what is left is the fp32 summation order of ONE conv and
+    # the rare 1-ulp flip of a stored fp16 value: a handful of fp16 ulps of the output, whatever the kernel family
+    emu = ir_emul.Emulator(net.program(n, h, w), round_f16=True).run(ir_emul.to_nhwc8(x).astype(np.float16))[0]
+    emu = np.transpose(emu, (0, 3, 1, 2))[:, :cout]
+    kerr = np.abs(got - emu).max() / max(1.0, np.abs(emu).max())
+    print(f"conv {cin}->{cout} k{k} s{s} {h}x{w}: vs oracle {err:.3g}, kernel leg (vs emulator, fp16 storage) {kerr:.3g} of the output range")
+    assert kerr < KERNEL_LEG_CONV, kerr
 
 
 @pytest.mark.parametrize("mid", ["V3_ch_det_fast", "V4_ch_det_fast", "V2_ch_det"])

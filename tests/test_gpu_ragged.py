@@ -45,6 +45,16 @@ def test_ragged_batch_matches_oracle_per_sample(ctx, mid, h, widths):
         tn = int(tl[n])
         assert ref.shape[0] == tn, (ref.shape, tn)
         check_rec_probs(mid, probs[n, :tn], ref, idx=idx[n, :tn])     # log-probabilities of every class, max probability, arg-max outside near-ties
+    # the kernel leg (tests/parity.py TOL_KERNEL): the same ragged program on the CPU emulator with fp16 storage where the kernels store
+    # fp16 — the weight rounding that dominates the bound above is on both sides, what is left is the kernels' own arithmetic
+    prog = net.program(len(widths), h, wmax)
+    emu = ir_emul.Emulator(prog, round_f16=True).run(ir_emul.to_nhwc8(x).astype(np.float16), widths=widths)[0][:, 0]
+    worst = {}
+    for n, wn in enumerate(widths):
+        tn = int(tl[n])
+        st = check_rec_probs(mid, probs[n, :tn], emu[n, :tn], idx=idx[n, :tn], leg="stored")
+        worst = {k: max(v, worst.get(k, 0.0)) for k, v in st.items()}
+    print(f"{mid} ragged {widths} kernel leg stored: " + ", ".join(f"{k} {v:.3g}" for k, v in worst.items()))
 
 
 @pytest.mark.parametrize("mid,h,widths", CASES)
