@@ -302,7 +302,7 @@ def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, 
     if args.det_stream_mode == "shared":
         det_streams = [torch.cuda.Stream(device=ctx.tdev, priority=args.det_priority)] * depth
     elif args.det_stream_mode == "independent":
-        det_streams = ctx.side_streams(depth, priority=args.det_priority)
+        det_streams = ctx.side_streams(depth, priority=args.det_priority, role="det")
     else:
         det_streams = [torch.cuda.Stream(device=ctx.tdev, priority=args.det_priority) for _ in range(depth)]
     pipe.rec_stream_priority = args.rec_priority

@@ -62,6 +62,10 @@ const char* vse_last_error(void);
 size_t vse_sizeof_op(void);
 size_t vse_sizeof_view(void);
 int vse_abi_version(void);
+/* 1 when the library was compiled with -DVSE_DEV_BUILD (experimental kernels + their environment switches), 0 for the product build.
+ * The host side consults it before honouring VSE_DEV_BUILD=1 in the environment (vse_amd.engine.load_library): compiler-side experiment
+ * switches must never route to kernels a product library refuses.  No reference counterpart (build hygiene, not an operator). */
+int vse_is_dev_build(void);
 
 /* ---- network programs ----------------------------------------------------------------------------- */
 /* Upload (or replace) the packed weight blob of one model; returns a weights handle id >= 0.

@@ -29,6 +29,7 @@ def test_record_layouts(built_lib):
     assert lib.vse_sizeof_op() == ir.OP_DT.itemsize == 352
     assert lib.vse_sizeof_view() == ir.VIEW_DT.itemsize == 40
     assert lib.vse_abi_version() == 2
+    assert lib.vse_is_dev_build() == 0            # the in-tree library is the product build: no experiment switch reaches it
 
 
 def test_product_refuses_without_gpu(built_lib):

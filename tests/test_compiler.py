@@ -494,7 +494,15 @@ def test_head_tail_fusion_and_its_fallback(monkeypatch):
         outs[t2] = ir_emul.Emulator(prog, round_f16=True).run(ir_emul.to_nhwc8(x))[0]
     assert np.abs(outs[None] - outs[False]).max() < 2e-6 and outs[None].std() > 0
     monkeypatch.setattr(compiler, "HEAD_UP2", False)
-    prog = compiler.compile_model(desc, w, 1, 64, 96)
+    store, fb = compiler.WeightStore(), {}
+    prog = compiler.compile_model(desc, w, 1, 64, 96, store=store, fallbacks=fb)
     assert not any(int(o["flags"]) & (ir.F_TAIL2 | ir.F_UP2HEAD) for o in prog.ops)
+    # the abandoned attempt leaves nothing behind in the shared store, and the outcome is remembered for the next shape
+    direct = compiler.WeightStore()
+    compiler.compile_model(desc, w, 1, 64, 96, store=direct, tail2=False)
+    assert fb == {"tail2": False} and len(store.blob) == len(direct.blob) and set(store.index) == set(direct.index)
+    fb2 = {}
+    prog2 = compiler.compile_model(desc, w, 1, 96, 128, store=store, tail2=fb["tail2"], fallbacks=fb2)
+    assert fb2 == {} and not any(int(o["flags"]) & ir.F_TAIL2 for o in prog2.ops)        # no failed attempt this time
     ref = net_ref.run_graph(desc, w, x)[0].numpy()[:, 0]
     assert np.abs(ir_emul.Emulator(prog).run(ir_emul.to_nhwc8(x))[0][..., 0] - ref).max() < 5e-3

@@ -20,6 +20,23 @@ def test_side_streams_are_concurrent_and_shared(ctx):
     assert not ctx.streams_concurrent(ss[0], ss[0])                                               # one stream is in order with itself
 
 
+def test_roles_never_share_stream_objects_even_at_equal_priority(ctx):
+    """with one cached list per PRIORITY, a recogniser at the detector's priority (bench.py --det-priority -1, or
+    rec_stream_priority = 0) received the detector's own stream objects and the det / rec overlap serialised silently."""
+    from vse_amd import engine
+    c2 = engine.Context(0)
+    det = c2.side_streams(2, priority=0, role="det")
+    rec = c2.side_streams(2, priority=0, role="rec")
+    handles = [s.cuda_stream for s in det + rec]
+    assert len(set(handles)) == 4, handles
+    assert [s.cuda_stream for s in c2.side_streams(2, priority=0, role="det")] == handles[:2]       # cached per (priority, role)
+    assert all(c2.streams_concurrent(a, b) for a in det for b in det if a is not b)
+    assert all(c2.streams_concurrent(a, b) for a in rec for b in rec if a is not b)
+    print("cross-verified against the other role:", getattr(c2, "side_streams_cross_verified", True),
+          [c2.streams_concurrent(a, b) for a in det for b in rec])
+    c2.close()
+
+
 def test_side_streams_degrade_when_nothing_runs_concurrently(ctx, monkeypatch):
     from vse_amd import engine
     c2 = engine.Context(0)

@@ -162,6 +162,16 @@ class WeightStore:
     def array(self):
         return np.frombuffer(bytes(self.blob), dtype=np.uint8).copy()
 
+    def snapshot(self):
+        """State to roll back to when a compile attempt is abandoned (compile_model's fallbacks): the blobs an aborted attempt
+        packed would otherwise stay in the store — uploaded with every plan, read by none."""
+        return len(self.blob), dict(self.index)
+
+    def rollback(self, snap):
+        n, index = snap
+        del self.blob[n:]
+        self.index = dict(index)          # a copy: the snapshot must survive the adds that follow (it may be rolled back to again)
+
 
 # ------------------------------------------------------------------------------------------------ compiler
 _VIRTUAL = {"nearest_interp_v2", "flatten_contiguous_range", "transpose2", "reshape2", "squeeze2", "dropout",
@@ -2251,13 +2261,20 @@ class Compiler(ChainMixin):
 
 
 def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_probs=True, store=None, reuse=True, hilo=False,
-                  ragged=False, input_norm=None, fuse_preprocess=False, chain=None, tail2=None):
+                  ragged=False, input_norm=None, fuse_preprocess=False, chain=None, tail2=None, se_lateral=None, fallbacks=None):
     """reuse=False gives every buffer its own workspace range (debugging: all intermediates stay readable).
     hilo=True stores every conv / depthwise / transposed-conv weight as an fp16 hi + lo pair (F_HILO): ~22-bit weights for
     twice the MFMA work — for nets whose boxes must track an fp32 reference closely.
     ragged=True (recognisers): `width` is the widest sample of the batch; the plan runs with a per-sample width table
-    (Program.width_table) and every sample gets the values a batch of its own width would have produced, bit for bit."""
+    (Program.width_table) and every sample gets the values a batch of its own width would have produced, bit for bit.
+    se_lateral=False / tail2=False: compile without that rewrite from the start; `fallbacks` (a dict): the rewrites this call had to
+    abandon are recorded there as {"tail2": False, "se_lateral": False} so that the caller (engine.Net) passes them for the next shape
+    instead of paying the failed attempt again."""
+    snap = store.snapshot() if store is not None else None
+
     def build(se_lateral, tail2=tail2):
+        if snap is not None:
+            store.rollback(snap)         # blobs of an abandoned attempt leave the shared store (nothing refers to their offsets)
         c = Compiler(desc, weights, batch, height, width, fetch_cols, want_probs, store, reuse, se_lateral=se_lateral, tail2=tail2)
         c.ragged = bool(ragged)
         c.hilo = bool(hilo)
@@ -2270,13 +2287,17 @@ def compile_model(desc, weights, batch, height, width, fetch_cols=(0,), want_pro
         return c.compile()
     try:
         try:
-            return build(None)
+            return build(se_lateral)
         except Tail2Unsupported:
             # the dense map of an F_TAIL2 conv met a reader that cannot take it: the two transposed convs as separate launches
             tail2 = False
-            return build(None, False)
+            if fallbacks is not None:
+                fallbacks["tail2"] = False
+            return build(se_lateral, False)
     except GatedConvUnsupported:
         # _rewrite_se_laterals turned a 1x1 conv + SE block into a gated conv whose surroundings the epilogue cannot express (an affine or
         # an activation behind the SE add, a gate shape, a kernel family): the graph compiled before that rewrite existed — compile it
         # without the rewrite instead of refusing it
+        if fallbacks is not None:
+            fallbacks["se_lateral"] = False
         return build(False, tail2)

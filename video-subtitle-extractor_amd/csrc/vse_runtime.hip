@@ -53,6 +53,13 @@ const char* vse_last_error(void) { return g_err.c_str(); }
 size_t vse_sizeof_op(void) { return sizeof(vse_op); }
 size_t vse_sizeof_view(void) { return sizeof(vse_view); }
 int vse_abi_version(void) { return 2; }
+int vse_is_dev_build(void) {
+#ifdef VSE_DEV_BUILD
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int vse_init(int device_id, vse_ctx** out) {
     if (!out) return VSE_E_INVAL;

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSE_LIB_PATH") or os.path.join(_HERE, "libvse_hip.so")      # (VSE_LIB_PATH: ablation builds of tools/)
 
 EXPORTS = [
-    "vse_init", "vse_destroy", "vse_last_error", "vse_sizeof_op", "vse_sizeof_view", "vse_abi_version",
+    "vse_init", "vse_destroy", "vse_last_error", "vse_sizeof_op", "vse_sizeof_view", "vse_abi_version", "vse_is_dev_build",
     "vse_weights_upload", "vse_weights_free", "vse_plan_create", "vse_plan_destroy", "vse_plan_run", "vse_plan_run_ragged",
     "vse_plan_width_levels", "vse_plan_profile", "vse_plan_op_variant", "vse_plan_op_kernel_name", "vse_det_preprocess", "vse_db_workspace_bytes",
     "vse_db_postprocess", "vse_rec_preprocess", "vse_rec_preprocess_scratch_bytes", "vse_ctc_collapse", "vse_ctc_collapse_ragged",
@@ -65,6 +65,11 @@ def load_library(path=None):
     for name in EXPORTS:
         if not hasattr(lib, name):
             raise VseError(f"libvse_hip.so does not export {name}")
+    if os.environ.get("VSE_DEV_BUILD", "0") == "1" and not lib.vse_is_dev_build():
+        # ir.dev_switch honours the compiler's experiment switches under VSE_DEV_BUILD=1; a PRODUCT library ignores its half of them
+        # (vse_dev_getenv) and refuses the experimental kernels: the two halves of an A/B arm would silently disagree
+        raise VseError(f"VSE_DEV_BUILD=1 but {path} is a product build: rebuild with `VSE_DEV_BUILD=1 python __graft_entry__.py --force` or "
+                       "point VSE_LIB_PATH at a development build (tools/build_ab.sh), or unset VSE_DEV_BUILD")
     lib.vse_last_error.restype = C.c_char_p
     lib.vse_sizeof_op.restype = C.c_size_t
     lib.vse_sizeof_view.restype = C.c_size_t
@@ -169,19 +174,31 @@ class Context:
         t.cuda.synchronize(self.tdev)
         return a0.elapsed_time(b1) < 0.5 * a0.elapsed_time(a1)
 
-    def side_streams(self, n, priority=0, tries=24):
+    def side_streams(self, n, priority=0, tries=24, role="default"):
         """n streams of the given priority that run concurrently with each other AND with the current stream (verified by
-        streams_concurrent), cached per (device, priority): every pipeline of the process gets the same ones."""
+        streams_concurrent), cached per (priority, role): every pipeline of the process gets the same ones for the same role, and two
+        roles — the detector batches in flight ("det") and the recogniser's width groups ("rec") — never receive the same stream objects,
+        whatever their priorities (with one list per priority, equal priorities made the detector / recogniser overlap serialise
+        silently).  A candidate is also checked against the streams of the OTHER roles: preferred when it runs beside all of them
+        (the device has a handful of hardware queues: not always possible), accepted after half the tries when it only runs beside
+        its own list and the main stream (`side_streams_cross_verified` tells)."""
         t = self.torch
         cache = self.__dict__.setdefault("_side_streams", {})
-        have = cache.setdefault(priority, [])
+        have = cache.setdefault((priority, role), [])
+        others = [s for k, lst in cache.items() if k != (priority, role) for s in lst]
         main = t.cuda.current_stream(self.tdev)
+        budget = tries
         while len(have) < n and tries > 0:
             tries -= 1
             s = t.cuda.Stream(device=self.tdev, priority=priority)
-            if any(s.cuda_stream == h.cuda_stream for h in have):
+            if any(s.cuda_stream == h.cuda_stream for h in have + others):
                 continue
-            if self.streams_concurrent(main, s) and all(self.streams_concurrent(h, s) for h in have):
+            if not (self.streams_concurrent(main, s) and all(self.streams_concurrent(h, s) for h in have)):
+                continue
+            cross = all(self.streams_concurrent(o, s) for o in others)
+            if cross or tries < budget // 2:
+                if not cross:
+                    self.side_streams_cross_verified = False
                 have.append(s)
         if len(have) < n:
             # nothing on this device runs side by side right now — a profiler that serialises dispatches (rocprofv3 --pmc), one hardware
@@ -190,7 +207,10 @@ class Context:
             warnings.warn(f"only {len(have)} of {n} HIP streams of priority {priority} verified to run concurrently; using unverified ones")
             self.side_streams_verified = False
             while len(have) < n:
-                have.append(t.cuda.Stream(device=self.tdev, priority=priority))
+                s = t.cuda.Stream(device=self.tdev, priority=priority)
+                if not any(s.cuda_stream == h.cuda_stream for h in have + others) or tries < -64:
+                    have.append(s)
+                tries -= 1
         return have[:n]
 
     def close(self):
@@ -322,6 +342,7 @@ class Net:
         self.ws = {}          # one workspace per plan: plans of one net may run concurrently on different streams
         self.ws_budget = int(float(os.environ.get("VSE_WS_BUDGET_GB", "64")) * (1 << 30))     # per net; LRU beyond it
         self.ws_evictions = 0 # workspaces dropped by that LRU so far (tools/soak.py reports it)
+        self.fallbacks = {}   # rewrites compile_model had to abandon for this graph (tail2 / se_lateral): remembered for the next shape
 
     def program(self, n, h, w):
         key = (n, h, w)
@@ -329,7 +350,9 @@ class Net:
             try:
                 prog = compiler.compile_model(self.desc, self.weights, n, h, w, self.fetch_cols, self.want_probs,
                                               self.store, hilo=self.hilo, ragged=self.ragged, input_norm=self.input_norm,
-                                              fuse_preprocess=self.fuse_preprocess, chain=self.chain, tail2=self.tail2)
+                                              fuse_preprocess=self.fuse_preprocess, chain=self.chain,
+                                              tail2=self.fallbacks.get("tail2", self.tail2),
+                                              se_lateral=self.fallbacks.get("se_lateral"), fallbacks=self.fallbacks)
             except compiler.UnsupportedGraph:
                 if not self.fuse_preprocess or self.plans:
                     raise

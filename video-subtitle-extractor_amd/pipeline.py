@@ -313,7 +313,7 @@ class OcrPipeline:
             if len(getattr(self, "_streams", [])) < nstreams:
                 # streams VERIFIED to run beside each other and beside the main stream, shared by every pipeline of the context
                 # (engine.Context.side_streams: torch's pool streams may alias one hardware queue and then execute in order)
-                self._streams = self.ctx.side_streams(nstreams, priority=getattr(self, "rec_stream_priority", -1))
+                self._streams = self.ctx.side_streams(nstreams, priority=getattr(self, "rec_stream_priority", -1), role="rec")
             for st in self._streams[:nstreams]:
                 st.wait_stream(main)
         try:
@@ -387,7 +387,7 @@ class OcrPipeline:
         depth = max(1, int(depth))
         rec_span = max(1, int(rec_span)) if self.rec_mode == "ragged" else 1
         if len(getattr(self, "_det_streams", [])) < depth:
-            self._det_streams = self.ctx.side_streams(depth)      # verified concurrent with each other and with the main stream
+            self._det_streams = self.ctx.side_streams(depth, role="det")      # verified concurrent with each other and with the main stream
         main = t.cuda.current_stream(self.ctx.tdev)
         queue, ready = [], []
 
@@ -428,7 +428,7 @@ class OcrPipeline:
         t = self.ctx.torch
         depth = max(1, int(depth))
         if len(getattr(self, "_det_streams", [])) < depth:
-            self._det_streams = self.ctx.side_streams(depth)      # verified concurrent with each other and with the main stream
+            self._det_streams = self.ctx.side_streams(depth, role="det")      # verified concurrent with each other and with the main stream
         main = t.cuda.current_stream(self.ctx.tdev)
         queue = []
 
