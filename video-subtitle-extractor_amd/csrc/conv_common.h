@@ -316,6 +316,7 @@ int launch_conv_col3w(const ConvParams& p, int n_img, hipStream_t st);
 // depthwise k x k conv fused in front of a 1x1 conv (conv_dwpw.hip, F_DWPRE): p.kh / sh / ph = the depthwise geometry, p.dotw = its table
 int launch_conv_dwpw(const ConvParams& p, hipStream_t st);
 bool conv_dwpw_ok(int k, int s, int cinp, int Np, int flags);
+int conv_dwpw_rows_stride(int k, int pad, int s, int cinp, int lo_in);      // stride of the row-streaming form (conv_dwpw_rows_kernel), 0 = the tile form
 // 3x3 sibling, two blocks per CU (conv_c3.hip, F_COL with kh = kw = 3)
 int launch_conv_c3(const ConvParams& p, int n_img, hipStream_t st);
 double conv_c3_plan(int OH, int OW, int* rw_out);

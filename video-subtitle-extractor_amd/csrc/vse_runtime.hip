@@ -413,7 +413,11 @@ int vse_plan_op_variant(vse_plan* p, int i) {
     if (o.kind != OP_CONV) return 0;
     if (o.flags & F_UP2HEAD) return 400000;   // conv_head_up2_kernel
     if (o.flags & F_STEM) return 500000;      // conv_stem_kernel
-    if (o.flags & F_DWPRE) return 850000 + 10 * ((o.p[P_CINP] + 15) / 16) + o.p[P_KH];   // conv_dwpw_kernel<KS, K, LO>
+    if (o.flags & F_DWPRE) {
+        const int rs = conv_dwpw_rows_stride(o.p[P_KH], o.p[P_PH], o.p[P_SH], o.p[P_CINP], o.p[P_LO_IN]);
+        if (rs) return 860000 + 10 * ((o.p[P_CINP] + 15) / 16) + rs;                       // conv_dwpw_rows_kernel<KS, LO, S>
+        return 850000 + 10 * ((o.p[P_CINP] + 15) / 16) + o.p[P_KH];                        // conv_dwpw_kernel<KS, K, LO>
+    }
     if (o.flags & F_PW) return ((o.flags & F_TAIL2) ? 810000 : 800000) + (o.p[P_CINP] + 15) / 16;   // conv_pw_kernel<KS> / conv_pw_tail_kernel<KS>
     if ((o.flags & F_COL) && o.p[P_KH] == 3 && o.p[P_KW] == 3) {   // conv_c3_kernel<RW, 8 / RW>
         int rw;
@@ -462,6 +466,7 @@ const char* vse_plan_op_kernel_name(vse_plan* p, int i) {
     const int code = vse_plan_op_variant(p, i);
     if (code >= 901000) snprintf(buf, sizeof buf, "conv_smallm_hl_kernel<%d>", code - 901000);
     else if (code >= 900000) snprintf(buf, sizeof buf, "conv_smallm_kernel<%d>", code - 900000);
+    else if (code >= 860000) snprintf(buf, sizeof buf, "conv_dwpw_rows_kernel<%d, %s, %d>", (code - 860000) / 10, o.p[P_LO_IN] ? "true" : "false", code % 10);
     else if (code >= 850000) snprintf(buf, sizeof buf, "conv_dwpw_kernel<%d, %d, %s>", (code - 850000) / 10, code % 10, o.p[P_LO_IN] ? "true" : "false");
     else if (code >= 810000) snprintf(buf, sizeof buf, "conv_pw_tail_kernel<%d>", code - 810000);
     else if (code >= 800000) snprintf(buf, sizeof buf, "conv_pw_kernel<%d>", code - 800000);
