@@ -55,7 +55,8 @@ def parse():
     ap.add_argument("--min-rec-group", type=int, default=8,
                     help="rec width buckets with fewer crops absorb the next narrower bucket (0 = off); 8: the 4-crop 1280-px bucket of "
                          "the default workload joins the 1024-px one - 6 %% less GPU time in conv kernels at the same frames/s")
-    ap.add_argument("--rec-streams", type=int, default=2)
+    ap.add_argument("--rec-streams", type=int, default=4, help="side streams of the recogniser's width groups (4: every group of a span in flight at once; server pair "
+                    "2021 / 2003 vs 2010 / 2008 frames/s at 2 on one box = neutral, mobile pair 8.41-8.45 k vs 8.17-8.26 k)")
     ap.add_argument("--rec-span", type=int, default=2, help="streaming form, ragged mode: the crops of this many consecutive batches are "
                     "recognised together (results do not depend on the grouping; larger launches fill the chip on the recogniser's small maps)")
     ap.add_argument("--rec-graphs", action="store_true", help="every recogniser invocation (plan + CTC collapse, ~80 launches) as one HIP graph "
@@ -372,7 +373,7 @@ def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, 
         out = run_steps(steps)
         sync()
         dt = time.perf_counter() - t0
-        if args.dist_on:
+        if getattr(args, "dist_on", False):      # (tools that build a workload directly have no process group)
             tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             parallel._count("all_reduce")

@@ -46,7 +46,7 @@ def run_stream(ctx, models="server", total_frames=21600, batch=64, height=1080, 
         det = (det[0], bench.empty_det_head(det[0], det[1]))
     charset = shim.standin_charset(lang, shim._ncls(rec[0]))
     pipe = pipeline.OcrPipeline(ctx, det, rec, charset, rec_mode="ragged", bucket=256, batch_round=4, min_rec_group=8)   # bench.py's settings
-    pipe.rec_streams = 2
+    pipe.rec_streams = 4
     pipe.rec_stream_priority = -1
     if ws_budget_gb is not None:       # the recogniser's workspace LRU (engine.Net._workspace; default VSE_WS_BUDGET_GB = 64)
         pipe.rec.ws_budget = int(ws_budget_gb * (1 << 30))

@@ -410,15 +410,16 @@ class Net:
         if ws is None:
             # a long video meets many recogniser shapes (crops x width bucket), each with a workspace of its own (they are
             # zero-initialised and their padding regions must stay zero, so plans cannot share one): keep the total under a
-            # budget by dropping the least recently used ones — after a device synchronisation, they may still be in flight
+            # budget by dropping the least recently used ones.  No device synchronisation: every use records the stream it runs on
+            # (below), so the caching allocator itself holds a dropped workspace back until the launches that read it have finished
+            # (round 6: the synchronisation drained the detector batches in flight — 4 % of the rate of a stream at its budget)
             need = max(prog.ws_bytes, 256)
             total = sum(int(w.numel()) for w in self.ws.values())
-            if self.ws and total + need > self.ws_budget:
-                t.cuda.synchronize(self.ctx.tdev)
-                while self.ws and total + need > self.ws_budget:
-                    total -= int(self.ws.pop(next(iter(self.ws))).numel())
-                    self.ws_evictions += 1
+            while self.ws and total + need > self.ws_budget:
+                total -= int(self.ws.pop(next(iter(self.ws))).numel())
+                self.ws_evictions += 1
             ws = t.zeros(need, dtype=t.uint8, device=self.ctx.tdev)
+        ws.record_stream(t.cuda.current_stream(self.ctx.tdev))
         self.ws[k] = ws                       # (re-)inserted last: dict order = least recently used first
         return ws
 

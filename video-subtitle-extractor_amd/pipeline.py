@@ -104,6 +104,11 @@ class OcrPipeline:
         self.min_rec_group = min_rec_group    # bucketed mode: buckets with fewer crops absorb the next narrower bucket
         self.profile_sink = None              # list: when set, every net run is profiled per op and appended here
         self.rec_streams = 1                  # >1: width groups of the recogniser run on that many side streams
+        # ragged grouping (_ragged_partition): fixed cost of one launch sequence in crop-pixels.  The mobile recognisers (< 8 M
+        # parameters: ~80 launches of ~10 us per sequence, latency-bound) do better with MORE, smaller groups spread over the side
+        # streams than the server model (MI355X, bench.py --models fast, 4 streams: 8.42-8.51 k frames/s at 5000, 8.58-8.67 k at 2000)
+        nparam_rec = sum(int(np.prod(v.shape)) for v in rec_model[1].values())
+        self.ragged_launch_cost = 5000 if nparam_rec >= 8_000_000 else 2000
 
     def _run(self, net, x, slot=0, widths=None):
         if getattr(self, "profile_sink", None) is not None:
