@@ -12,6 +12,7 @@ CASES = [("V4_ch_det", (2, 3, 96, 160)), ("V4_ch_det", (1, 3, 128, 256)),    # 2
          ("V4_ch_det", (2, 3, 96, 224)),                                         # head kernel: half-empty last column tile
          ("V4_ch_det_fast", (2, 3, 96, 160)), ("V3_ch_det_fast", (1, 3, 96, 160)),
          ("V2_ch_det", (1, 3, 64, 96)), ("V4_ch_rec", (3, 3, 48, 200)), ("V4_ch_rec_fast", (2, 3, 48, 320)),
+         ("V4_ch_rec_fast", (3, 3, 48, 200)),      # maps 100 / 50 px wide: the column-walk depthwise kernel's partial quads, 12 / 6 / 3-row maps
          ("V4_en_rec_fast", (6, 3, 48, 352)), ("V3_ch_rec_fast", (2, 3, 48, 160)), ("V3_latin_rec_fast", (2, 3, 48, 160)),
          ("V2_ch_rec", (2, 3, 32, 128))]
 

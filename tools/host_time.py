@@ -15,7 +15,7 @@ from vse_amd import engine, modelzoo, pipeline, shim, synth
 models = sys.argv[sys.argv.index("--models") + 1] if "--models" in sys.argv else "server"
 batch = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 64
 ctx = engine.Context(0)
-det_id, rec_id, lang = ("V4_ch_det", "V4_ch_rec", "ch") if models == "server" else ("V3_ch_det_fast", "V4_en_rec_fast", "en")
+det_id, rec_id, lang = {"server": ("V4_ch_det", "V4_ch_rec", "ch"), "fast": ("V4_ch_det_fast", "V4_ch_rec_fast", "ch")}.get(models, ("V3_ch_det_fast", "V4_en_rec_fast", "en"))
 det, rec = modelzoo.get_model(det_id, seed=0), modelzoo.get_model(rec_id, seed=1)
 overlay = None
 frames_np, truth = synth.make_frames(batch, 1080, 1920, seed=100, return_truth=True)
@@ -23,7 +23,7 @@ if not modelzoo.has_real_weights(det_id):
     det = (det[0], bench.empty_det_head(det[0], det[1]))
     overlay = torch.from_numpy(bench.text_kernel_maps(truth, 1080, 1920, 544, 960)).cuda()
 pipe = pipeline.OcrPipeline(ctx, det, rec, shim.standin_charset(lang, shim._ncls(rec[0])), bucket=256, batch_round=4, min_rec_group=8)
-pipe.rec_streams = 2
+pipe.rec_streams = 4
 frames = torch.from_numpy(frames_np).cuda()
 
 

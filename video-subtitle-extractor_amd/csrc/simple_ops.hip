@@ -95,6 +95,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(TView in, TView out, TView 
     }
 }
 
+#ifndef VSE_DWROW_ABL
+#define VSE_DWROW_ABL 0
+#endif
 // Row-blocked variant: one thread produces FOUR consecutive output pixels of one row for one 8-channel group, so every
 // input vector of a filter row is loaded once for the outputs that share it ((4-1)*SW + KW loads instead of 4*KW) and every
 // weight vector once per tap instead of once per output.  Same accumulation order per output as dwconv_kernel (bias, then
@@ -142,6 +145,9 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
 #pragma unroll
                 for (int c = 0; c < WIN; ++c) {
                     const int iw = iw0 + c;
+#if defined(VSE_DEV_BUILD) && VSE_DWROW_ABL == 2      // timing-only ablation: ONE gather per filter row (results wrong)
+                    if (c > 0) { x[c] = x[0]; continue; }
+#endif
                     x[c] = (!CHK || (iw >= 0 && iw < in.w)) ? ld8(in, rowpix + iw, g * 8 + coff) : half8{0, 0, 0, 0, 0, 0, 0, 0};
                 }
                 // all loads of the row first, arithmetic afterwards: multiplying each vector as it arrives serialises the loads
@@ -153,6 +159,9 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
                 }
 #pragma unroll
                 for (int dx = 0; dx < KW; ++dx) {
+#if defined(VSE_DEV_BUILD) && VSE_DWROW_ABL == 1      // timing-only ablation: 1 / KW of the multiply-adds, every gather kept (results wrong)
+                    if (dx > 0) { asm volatile("" :: "v"(x[dx]), "v"(x[WIN - 1])); continue; }
+#endif
                     const float4v k0 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + g * 8);
                     const float4v k1 = *reinterpret_cast<const float4v*>(w + (long)(dy * KW + dx) * in.c + g * 8 + 4);
 #pragma unroll
@@ -183,6 +192,125 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(TView in, TView out, TV
             if (wl_out != nullptr && ow0 + o >= wl_out[n]) r = half8{0, 0, 0, 0, 0, 0, 0, 0};
             st8(out, (n * out.h + oh) * out.w + ow0 + o, g * 8, r);
             if (lo_off) st8(out, (n * out.h + oh) * out.w + ow0 + o, g * 8 + lo_off, rl);
+        }
+    }
+}
+
+// Column-walk variant (round 6): one thread produces OUTW consecutive output pixels x TWO channels of every row of a segment of output
+// rows, walking down the input rows once, with its KH x KW x 2 filter weights and every accumulator in REGISTERS.  An input row is gathered
+// once (OUTW + KW - 1 dwords) and converted to fp32 once; its filter rows are applied to the (up to KH / SH) output rows it belongs to, each
+// keeping its own fp32 accumulator in a ring of R = ceil(KH / SH) slots; the multiply-adds are v_pk_fma_f32 (both channels per instruction):
+// the inner loop is 80 % multiply-adds, no LDS, no table reads.  dwconv_row_kernel gathers KH x (3 SW + KW) vectors, re-reads the table per
+// tap and issues KH x KW x 8 v_fma_mix_f32 per output pixel; its ablations (round 6, V4_ch_rec_fast 56 x 896: 1 / KW of the multiply-adds
+// -0.21 of 0.65 ms, one gather per row -0.13) show multiply-adds, gathers and per-item index arithmetic each a third of it.  (A first
+// column-walk form with 8 channels per thread and the table in LDS — 50 ds_read_b128 per input row — was 15 % SLOWER than the row kernel.)
+// Per accumulator the order is the row kernel's — bias, then taps row-major; rows outside the image skipped, columns outside read as zeros
+// (adding 0 * w is the skip, bit for bit, unless an accumulator is exactly -0) — and an fp32 fma of the exactly converted fp16 value is what
+// v_fma_mix_f32 computes: identical bits (development build: tools/ab_env_digest.py VSE_DW_COL 0 1).
+// Plain fp16 tensors only (a pair input walks its hi rows, then its lo rows, into one chain: not streamable in that order), no gate, KW = KH
+// in {3, 5}, 'same' padding, horizontal stride 1, vertical stride 1 or 2: the mobile recognisers' depthwise layers.
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+template <int KH, int SH, int OUTW>
+__global__ __launch_bounds__(256) void dwconv_col_kernel(TView in, TView out, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         int rs, int nseg, int act, float act_a, float act_b, float post_a, float post_b,
+                                                         const int* __restrict__ wl_out) {
+    constexpr int KW = KH, P = KH / 2, R = (KH + SH - 1) / SH, U = R * SH, WIN = OUTW + KW - 1;
+    const int C = in.c, cp = C >> 1;
+    const bool affine = post_a != 1.f || post_b != 0.f;
+    const int owq = (out.w + OUTW - 1) / OUTW;
+    const long total = (long)out.n * nseg * owq * cp;
+    const long i = xcd_block(blockIdx.x, gridDim.x) * 256L + threadIdx.x;
+    if (i >= total) return;
+    int g, q, sg;
+    long t = vse_divmod(i, cp, g);                             // g: channel pair
+    t = vse_divmod(t, owq, q);
+    const long n = vse_divmod(t, nseg, sg);
+    const int o0 = sg * rs, o1 = min(o0 + rs, out.h);          // this thread's output rows
+    const int ow0 = q * OUTW, iw0 = ow0 - P;
+    int coff[WIN];
+    bool okc[WIN];
+#pragma unroll
+    for (int c = 0; c < WIN; ++c) {
+        okc[c] = (unsigned)(iw0 + c) < (unsigned)in.w;
+        coff[c] = min(max(iw0 + c, 0), in.w - 1) * in.ld;
+    }
+    const bool inside = __builtin_amdgcn_ballot_w64(!(okc[0] & okc[WIN - 1])) == 0;      // every lane's WIN columns lie in the image
+    const half_t* img = reinterpret_cast<const half_t*>(in.ptr) + n * (long)in.h * in.w * in.ld + g * 2;
+    float2v wk[KH * KW];
+#pragma unroll
+    for (int k = 0; k < KH * KW; ++k) wk[k] = *reinterpret_cast<const float2v*>(w + (long)k * C + g * 2);
+    const float2v bias2 = *reinterpret_cast<const float2v*>(bias + g * 2);
+    float2v acc[R][OUTW];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int o = 0; o < OUTW; ++o) acc[r][o] = bias2;
+    const int wl = wl_out != nullptr ? wl_out[n] : 0x7fffffff;
+    half_t* const obase = reinterpret_cast<half_t*>(out.ptr) + g * 2;
+    auto finish = [&](int oh, float2v (&a)[OUTW]) __attribute__((always_inline)) {      // activation, affine, fp16 store of one output row; slot back to bias
+#pragma unroll
+        for (int o = 0; o < OUTW; ++o) {
+            float v2[2] = {a[o][0], a[o][1]};
+            a[o] = bias2;
+            vse_act_n<2>(v2, act, act_a, act_b);
+            if (ow0 + o >= out.w) continue;
+            half2v r2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) r2[e] = (half_t)(affine ? v2[e] * post_a + post_b : v2[e]);
+            if (ow0 + o >= wl) r2 = half2v{0, 0};
+            *reinterpret_cast<half2v*>(obase + ((n * out.h + oh) * (long)out.w + ow0 + o) * out.ld) = r2;
+        }
+    };
+    auto load_row = [&](int ih, half2v (&xv)[WIN]) __attribute__((always_inline)) {
+        const half_t* rowp = img + (long)min(max(ih, 0), in.h - 1) * in.w * in.ld;
+#pragma unroll
+        for (int c = 0; c < WIN; ++c) xv[c] = *reinterpret_cast<const half2v*>(rowp + coff[c]);
+    };
+    // local input row l = ih - o0 * SH runs from -U (a whole unrolled round in front of the segment: rows that reach no output row of the
+    // segment are skipped by a wave-uniform test) to the last row the segment reads
+    const int l_end = (o1 - 1 - o0) * SH - P + KH - 1;
+    half2v nx[WIN];
+    load_row(o0 * SH - P, nx);
+#pragma unroll 1
+    for (int lb = -U; lb <= l_end; lb += U) {
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int l = lb + j, ih = o0 * SH + l;
+            if (l < -P || l > l_end) continue;                                  // (uniform)
+            if (!inside) {                                                      // (uniform) columns outside the image read as zeros
+#pragma unroll
+                for (int c = 0; c < WIN; ++c)
+                    if (!okc[c]) nx[c] = half2v{0, 0};
+            }
+            float2v xf[WIN];                                                    // this row in fp32 (exact conversions), then the next row's
+#pragma unroll
+            for (int c = 0; c < WIN; ++c) xf[c] = float2v{(float)nx[c][0], (float)nx[c][1]};      // gathers fly during this row's arithmetic
+            load_row(ih + 1, nx);
+            if (ih >= 0 && ih < in.h) {                                         // (uniform: rows outside the image contribute nothing)
+#pragma unroll
+                for (int dy = 0; dy < KH; ++dy) {
+                    const int num = j + P - dy;                                 // = SH * (oh - o0 - lb / SH)
+                    if (((num % SH) + SH) % SH != 0) continue;                  // (compile time after unrolling)
+                    const int ohl = (num >= 0 ? num / SH : -((-num + SH - 1) / SH));        // floor division, compile time
+                    const int slot = ((ohl % R) + R) % R;
+                    const int oh = o0 + lb / SH + ohl;                          // (lb is a multiple of U = R * SH)
+                    if (oh < o0 || oh >= o1) continue;                          // (uniform)
+#pragma unroll
+                    for (int dx = 0; dx < KW; ++dx)
+#pragma unroll
+                        for (int o = 0; o < OUTW; ++o) acc[slot][o] = __builtin_elementwise_fma(xf[o + dx], wk[dy * KW + dx], acc[slot][o]);
+                }
+            }
+            {   // the output row whose LAST filter row this input row carries is complete
+                const int num = j + P - (KH - 1);
+                if (((num % SH) + SH) % SH == 0) {
+                    const int ohl = (num >= 0 ? num / SH : -((-num + SH - 1) / SH));
+                    const int slot = ((ohl % R) + R) % R;
+                    const int oh = o0 + lb / SH + ohl;
+                    if (oh >= o0 && oh < o1) finish(oh, acc[slot]);
+                }
+            }
         }
     }
 }
@@ -906,6 +1034,34 @@ int launch_simple_op(const vse_op& op, const TView& in0, const TView& in1, const
             const int hilo = ((op.flags & F_HILO) ? 1 : 0) | ((p[P_LO_OUT] >> 3) << 1) | ((p[P_LO_RES] >> 3) << 13);
             if (!(op.flags & F_GATE)) gate.ptr = nullptr;
             else if (!in1.ptr || in1.c != in0.c || in1.n != in0.n || in1.esize != 2) return VSE_E_INVAL;
+            // column-walk form (dwconv_col_kernel): plain fp16 tensors, no gate, square 3 x 3 / 5 x 5 'same' filters, horizontal stride 1
+            static const bool dw_col = [] { const char* e = vse_dev_getenv("VSE_DW_COL"); return !(e && e[0] == '0'); }();
+            if (dw_col && !gate.ptr && !p[P_LO_OUT] && !p[P_LO_RES] && kw == p[P_KH] && (kw == 3 || kw == 5) && sw == 1 && (p[P_SH] == 1 || p[P_SH] == 2)
+                && p[P_PH] == kw / 2 && p[P_PW] == kw / 2 && out.w == in0.w && out.h == (in0.h + 2 * (kw / 2) - kw) / p[P_SH] + 1
+                && in0.ld * (long)in0.w * in0.h < 0x7fffffffl) {
+#ifndef VSE_DWCOL_OUTW
+#define VSE_DWCOL_OUTW 4
+#endif
+                const int outw = VSE_DWCOL_OUTW, cpn = in0.c >> 1, owq = (out.w + outw - 1) / outw;
+                const long cols = (long)out.n * owq * cpn;                     // one thread per (column strip, channel pair, row segment)
+                int nseg = (int)((262144 + cols - 1) / cols);                   // >= ~256 k threads where the map allows it, >= 4 rows per segment
+                if (nseg > (out.h + 3) / 4) nseg = (out.h + 3) / 4;
+                if (nseg < 1) nseg = 1;
+                const int rs = (out.h + nseg - 1) / nseg;
+                nseg = (out.h + rs - 1) / rs;
+                const long total = cols * nseg;
+                const unsigned long long blocks = (unsigned long long)((total + 255) / 256);
+                if (blocks > 0 && blocks <= 0x7fffffffull) {
+#define DW_COL(KH_, SH_, OW_) hipLaunchKernelGGL((dwconv_col_kernel<KH_, SH_, OW_>), dim3((unsigned)blocks), dim3(256), 0, st, in0, out, wk, bk, rs, nseg, \
+                                                 p[P_ACT], f[FS_ACT_A], f[FS_ACT_B], f[FS_POST_A], f[FS_POST_B], wl_out)
+                    if (kw == 5 && p[P_SH] == 1) DW_COL(5, 1, VSE_DWCOL_OUTW);
+                    else if (kw == 5) DW_COL(5, 2, VSE_DWCOL_OUTW);
+                    else if (p[P_SH] == 1) DW_COL(3, 1, VSE_DWCOL_OUTW);
+                    else DW_COL(3, 2, VSE_DWCOL_OUTW);
+#undef DW_COL
+                    break;
+                }
+            }
             if ((kw == 3 || kw == 5) && (sw == 1 || sw == 2)) {
 #ifdef VSE_DEV_BUILD
                 // VSE_DW_TILE: 0 = row kernel only, 1 = LDS-tile kernel for 5 x 5 filters, 2 = for 3 x 3 filters too
