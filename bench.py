@@ -69,6 +69,8 @@ def parse():
     ap.add_argument("--secondary-steps", type=int, default=8)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="finish batch k before the detector of batch k+1 starts")
+    ap.add_argument("--no-host-pipeline", dest="host_pipeline", action="store_false",
+                    help="read a span's recognition results back right behind its launches (rounds 1-5) instead of after the NEXT span's launches")
     ap.add_argument("--det-priority", type=int, default=0, help="HIP stream priority of the detector streams (-1 = high)")
     ap.add_argument("--rec-priority", type=int, default=-1, help="HIP stream priority of the recogniser side streams (-1 = high: the small recogniser kernels get CUs as they free up beside the detector of the next batch, +0.6 %)")
     ap.add_argument("--det-stream-mode", default="independent", choices=["own", "shared", "independent"],
@@ -324,16 +326,21 @@ def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, 
         db = ctx.db_postprocess(maps, args.height, args.width, **pipe.db)
         return k, ([pipeline.sorted_boxes(b[0]) for b in db] if args.boxes == "db" else quads)
 
-    def stage2_recognise(ready):
-        """ready: [(step, boxes per frame)] of consecutive batches -> their records (every batch reads the same resident frames)."""
-        if len(ready) == 1:
-            res = [pipe.recognize(frames, ready[0][1])]
-        else:
-            res = pipe.recognize_multi([frames] * len(ready), [b for _, b in ready])
+    def rec_launch(ready):
+        """ready: [(step, boxes per frame)] of consecutive batches (every batch reads the same resident frames): their crops and
+        recogniser sequences enqueued, nothing read back -> handle for rec_collect."""
+        return list(ready), pipe.recognize_multi_launch([frames] * len(ready), [b for _, b in ready])
+
+    def rec_collect(launched):
+        ready, handle = launched
         out = []
-        for (k, boxes), r in zip(ready, res):
+        for (k, boxes), r in zip(ready, pipe.recognize_multi_collect(handle)):
             out += records(k, boxes, r)
         return out
+
+    def stage2_recognise(ready):
+        """launch + read-back in one piece (the profiling pass and the one-kernel-at-a-time form)."""
+        return rec_collect(rec_launch(ready))
 
     span = max(1, args.rec_span) if args.rec_mode == "ragged" else 1
 
@@ -351,19 +358,33 @@ def build_workload(args, ctx, world, rank, coll_dev, sync, log, models, height, 
         else:
             for st in det_streams:
                 st.wait_stream(torch.cuda.current_stream(ctx.tdev))
-            queue, ready = [], []
+            # software pipeline of the host side: the recognition of span s + 1 is LAUNCHED before the results of span s are read back,
+            # so the host never waits behind launch chains it has just enqueued while the detector batches it has yet to enqueue wait
+            # for it (every span launched inside the timed region is also collected inside it)
+            queue, ready, launched = [], [], None
+            need = span if pipe.rec_mode == "ragged" else 1
+
+            def flush():
+                nonlocal launched, ready
+                nxt = rec_launch(ready)
+                ready = []
+                if not args.host_pipeline:
+                    return rec_collect(nxt)
+                got = rec_collect(launched) if launched is not None else []
+                launched = nxt
+                return got
             for k in range(n):
                 queue.append(stage1(k) + (k,))
                 if len(queue) > depth:
                     ready.append(stage2_boxes(queue.pop(0)))
-                    if len(ready) >= (span if pipe.rec_mode == "ragged" else 1):
-                        local += stage2_recognise(ready)
-                        ready = []
+                    if len(ready) >= need:
+                        local += flush()
             while queue:
                 ready.append(stage2_boxes(queue.pop(0)))
-                if len(ready) >= (span if pipe.rec_mode == "ragged" else 1) or not queue:
-                    local += stage2_recognise(ready)
-                    ready = []
+                if len(ready) >= need or not queue:
+                    local += flush()
+            if launched is not None:
+                local += rec_collect(launched)
         return parallel.gather_records(local, device=coll_dev)
 
     def timed(warmup, steps):

@@ -22,11 +22,11 @@ def main():
     W = bench.build_workload(args, ctx, 1, 0, "cpu", sync, lambda m: None, args.models, args.height, args.width, args.batch)
     for label in ("full", "det+db only", "full", "det+db only"):
         if label != "full":
-            W.pipe.recognize = lambda frames, boxes: [[("", 0.0)] * len(b) for b in boxes]
-            W.pipe.recognize_multi = lambda fl, bl: [[[("", 0.0)] * len(b) for b in boxes] for boxes in bl]
+            W.pipe.recognize_multi_launch = lambda fl, bl: bl
+            W.pipe.recognize_multi_collect = lambda bl: [[[("", 0.0)] * len(b) for b in boxes] for boxes in bl]
         else:
-            W.pipe.__dict__.pop("recognize", None)
-            W.pipe.__dict__.pop("recognize_multi", None)
+            W.pipe.__dict__.pop("recognize_multi_launch", None)
+            W.pipe.__dict__.pop("recognize_multi_collect", None)
         out, dt = W.timed(args.warmup, args.steps)
         print(f"{label:12s}: {args.batch * args.steps / dt:8.1f} frames/s  {1e3 * dt / args.steps:7.3f} ms / step", flush=True)
 

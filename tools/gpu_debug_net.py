@@ -32,7 +32,7 @@ def main():
     xt = torch.from_numpy(x8.astype(np.float16)).cuda()
     outs = net.run(xt)
     torch.cuda.synchronize()
-    ws = net.ws[((n, h, w), 0)].cpu().numpy()
+    ws = net.ws[((n, h, w), 0)][0].cpu().numpy()
     bad = 0
     views = [(k, r, r[slot]) for k, r in enumerate(prog.ops)
              for slot in (("out", "out2", "in2") if int(r["kind"]) == ir.OP_CHAIN else ("out",)) if int(r[slot]["n"]) > 0]

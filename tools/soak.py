@@ -122,8 +122,8 @@ def run_stream(ctx, models="server", total_frames=21600, batch=64, height=1080, 
         "memory_allocated_gb": round(marks[-1][4] / 1e9, 3), "memory_allocated_at_one_third_gb": round(marks[third][4] / 1e9, 3),
         "memory_peak_gb": round(torch.cuda.max_memory_allocated() / 1e9, 3),
         "rec_workspace_budget_gb": round(pipe.rec.ws_budget / (1 << 30), 1),
-        "rec_workspace_gb": round(sum(int(w.numel()) for w in pipe.rec.ws.values()) / 1e9, 3),
-        "det_workspace_gb": round(sum(int(w.numel()) for w in pipe.det.ws.values()) / 1e9, 3),
+        "rec_workspace_gb": round(sum(int(w[0].untyped_storage().nbytes()) for w in pipe.rec.ws.values()) / 1e9, 3),
+        "det_workspace_gb": round(sum(int(w[0].untyped_storage().nbytes()) for w in pipe.det.ws.values()) / 1e9, 3),
         "pool_gb": round((sum(int(p.numel()) for p in pool) + sum(4 * int(o.numel()) for o in overlays)) / 1e9, 3),
         "det_plans": len(pipe.det.plans), "streaming": f"ocr_stream(depth={depth}, rec_span={rec_span})",
     }

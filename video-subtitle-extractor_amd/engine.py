@@ -406,21 +406,40 @@ class Net:
         several streams as long as every in-flight run has its own slot."""
         t = self.ctx.torch
         k = (key, slot)
-        ws = self.ws.pop(k, None)
-        if ws is None:
+        ent = self.ws.pop(k, None)            # (view handed to the plan, stream of its last use)
+        cur = t.cuda.current_stream(self.ctx.tdev)
+        if ent is None:
             # a long video meets many recogniser shapes (crops x width bucket), each with a workspace of its own (they are
-            # zero-initialised and their padding regions must stay zero, so plans cannot share one): keep the total under a
-            # budget by dropping the least recently used ones.  No device synchronisation: every use records the stream it runs on
-            # (below), so the caching allocator itself holds a dropped workspace back until the launches that read it have finished
-            # (round 6: the synchronisation drained the detector batches in flight — 4 % of the rate of a stream at its budget)
+            # zero-initialised and their padding regions must stay zero, so plans cannot share one): the total is kept under a
+            # budget, least recently used first.  No device synchronisation and, where possible, no allocator round trip:
+            #  * a victim last used on THIS stream and large enough is re-zeroed and reused in place — the memset and the new plan's
+            #    launches queue behind its last launch on that stream (a recogniser slot always runs on the same side stream);
+            #  * otherwise victims are dropped (every use records its stream, so the caching allocator holds the memory back until
+            #    its launches finished) and a fresh buffer is allocated.
+            # (Round 6: a synchronising eviction drained the detector batches in flight, -4 % on a stream at its budget; dropping
+            # without reuse made a host that runs a span ahead wait in hipMalloc for blocks still held back: -4 % again.)
             need = max(prog.ws_bytes, 256)
-            total = sum(int(w.numel()) for w in self.ws.values())
-            while self.ws and total + need > self.ws_budget:
-                total -= int(self.ws.pop(next(iter(self.ws))).numel())
-                self.ws_evictions += 1
-            ws = t.zeros(need, dtype=t.uint8, device=self.ctx.tdev)
-        ws.record_stream(t.cuda.current_stream(self.ctx.tdev))
-        self.ws[k] = ws                       # (re-)inserted last: dict order = least recently used first
+            total = sum(int(e[0].untyped_storage().nbytes()) for e in self.ws.values())
+            ws = None
+            if self.ws and total + need > self.ws_budget:
+                for vk, (vws, vstream) in self.ws.items():           # least recently used first
+                    cap = int(vws.untyped_storage().nbytes())
+                    if vstream == cur.cuda_stream and need <= cap <= 4 * need:
+                        del self.ws[vk]
+                        self.ws_evictions += 1
+                        base = t.empty(0, dtype=t.uint8, device=self.ctx.tdev).set_(vws.untyped_storage(), 0, (cap,))
+                        ws = base[:need]
+                        ws.zero_()
+                        break
+            if ws is None:
+                while self.ws and total + need > self.ws_budget:
+                    total -= int(self.ws.pop(next(iter(self.ws)))[0].untyped_storage().nbytes())
+                    self.ws_evictions += 1
+                ws = t.zeros(need, dtype=t.uint8, device=self.ctx.tdev)
+        else:
+            ws = ent[0]
+        ws.record_stream(cur)
+        self.ws[k] = (ws, cur.cuda_stream)    # (re-)inserted last: dict order = least recently used first
         return ws
 
     def _ext(self, prog, x):

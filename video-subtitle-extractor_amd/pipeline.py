@@ -265,13 +265,24 @@ class OcrPipeline:
         many crops (MI355X, V4_ch_rec, 78 crops per 64-frame batch: 9.3 ms of sequential GPU time per batch in their own sequences,
         7.7 ms per batch together with the next batch's; end to end +0.9 %).
         -> list (per tensor) of list (per frame) of [(text, score)]."""
+        return self.recognize_multi_collect(self.recognize_multi_launch(frames_list, boxes_list))
+
+    def recognize_multi_launch(self, frames_list, boxes_list):
+        """The launch half of recognize_multi(): crops are cut and every recogniser sequence is enqueued on the side streams; NOTHING
+        is read back — the host does not wait for the GPU.  -> a handle for recognize_multi_collect().  A streaming caller launches
+        span s + 1 before it collects span s (ocr_stream, bench.py): the read-back then finds its results finished instead of
+        stalling the host — and with it the detector batches it has yet to enqueue — behind the recogniser's launch chains."""
         specs = []
         for k, boxes_per_frame in enumerate(boxes_list):
             for s in self._crop_specs(boxes_per_frame):
                 s["src"] = k
                 specs.append(s)
-        results = [[[("", 0.0)] * len(b) for b in boxes_per_frame] for boxes_per_frame in boxes_list]
-        for s, r in zip(specs, self._recognize_specs(list(frames_list), specs)):
+        shape = [[len(b) for b in boxes_per_frame] for boxes_per_frame in boxes_list]
+        return dict(specs=specs, shape=shape, run=self._launch_specs(list(frames_list), specs))
+
+    def recognize_multi_collect(self, handle):
+        results = [[[("", 0.0)] * nb for nb in per_frame] for per_frame in handle["shape"]]
+        for s, r in zip(handle["specs"], self._collect_specs(handle["run"])):
             results[s["src"]][s["frame"]][s["slot"]] = r
         return results
 
@@ -302,11 +313,15 @@ class OcrPipeline:
     def _recognize_specs(self, frames, specs):
         """-> [(text, score)] per spec.  frames: one cuda uint8 [N,H,W,3] tensor, or a list of them with spec["src"] naming the
         tensor a crop is cut from."""
+        return self._collect_specs(self._launch_specs(frames, specs))
+
+    def _launch_specs(self, frames, specs):
+        """Crops + recogniser sequences of `specs` enqueued (side streams when rec_streams > 1); -> run handle for _collect_specs.
+        The main stream does NOT wait for the side streams: every group records an event, the read-back waits for those."""
         t = self.ctx.torch
         frames_list = list(frames) if isinstance(frames, (list, tuple)) else [frames]
-        out = [("", 0.0)] * len(specs)
         if not specs:
-            return out
+            return dict(n=0, pending=[])
         pending = []
         groups = self._groups(specs)
         # width groups are independent: run them on side streams so the latency-bound launches of small groups overlap.
@@ -362,13 +377,25 @@ class OcrPipeline:
                 else:
                     idx_maxp = self._run(self.rec, x, slot=slot, widths=np.asarray(widths, np.int32))[-1]          # [B,1,T,2]
                     oi, ol, oc = self.ctx.ctc_collapse(idx_maxp, self.rec.last_tlen)
-                pending.append((idx, oi, ol, oc))
+                ev = t.cuda.Event()
+                ev.record(t.cuda.current_stream(self.ctx.tdev))
+                pending.append((idx, oi, ol, oc, ev))
         finally:
             if nstreams > 1:
                 t.cuda.set_stream(main)
+                # the frames were allocated on the caller's stream and are read by the crop kernels on the side streams: tell the
+                # allocator (the main stream no longer waits for the side streams here, so nothing else orders a later free behind them)
                 for st in self._streams[:nstreams]:
-                    main.wait_stream(st)
-        for idx, oi, ol, oc in pending:                      # one sync per group at the end
+                    for fr in frames_list:
+                        fr.record_stream(st)
+        return dict(n=len(specs), pending=pending)
+
+    def _collect_specs(self, run):
+        """Read-back + string decode of a launched run: waits for each group's event (long finished when the caller launched the
+        next span in between), one device -> host copy per output."""
+        out = [("", 0.0)] * run["n"]
+        for idx, oi, ol, oc, ev in run["pending"]:
+            ev.synchronize()
             oi, ol, oc = oi.cpu().numpy(), ol.cpu().numpy(), oc.cpu().numpy()
             for k, i in enumerate(idx):
                 ids = oi[k, :ol[k]]
@@ -402,11 +429,23 @@ class OcrPipeline:
             n, h, w, _ = frames.shape
             return frames, [sorted_boxes(r[0]) for r in self.ctx.db_postprocess(maps, h, w, **self.db)]
 
+        prev = []                                             # the span launched last: (boxes per batch, launch handle)
+
         def flush():
-            rec = self.recognize_multi([f for f, _ in ready], [b for _, b in ready])
-            outs = [self._filter(b, r) for (_, b), r in zip(ready, rec)]
+            # launch this span's recognition, THEN read the previous span's results back: the host never waits for launch chains it has
+            # just enqueued (results come out one span later, in order)
+            cur = ([b for _, b in ready], self.recognize_multi_launch([f for f, _ in ready], [b for _, b in ready]))
             ready.clear()
+            outs = collect()
+            prev.append(cur)
             return outs
+
+        def collect():
+            if not prev:
+                return []
+            boxes_list, handle = prev.pop()
+            rec = self.recognize_multi_collect(handle)
+            return [self._filter(b, r) for b, r in zip(boxes_list, rec)]
         for k, frames in enumerate(batches):
             # the iterator may have produced this batch asynchronously on the main stream (GPU decode, crop, non-blocking
             # upload): order the detector stream after it for EVERY batch
@@ -426,6 +465,7 @@ class OcrPipeline:
             ready.append(boxes_of(*queue.pop(0)))
             if len(ready) >= rec_span or not queue:
                 yield from flush()
+        yield from collect()
 
     def detect_stream(self, batches, depth=2):
         """ocr_stream()'s detector half: yields detect(batch) for each batch, in order, with the detectors of the next `depth`
