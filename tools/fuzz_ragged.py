@@ -14,6 +14,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import torch
 from oracle import ir_emul, net_ref
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from parity import check_rec_probs
 from vse_amd import engine
 
 DEFAULT = "V4_ch_rec,V4_en_rec_fast,V4_ch_rec_fast,V3_ch_rec_fast,V3_korean_rec_fast,V2_ch_rec"
@@ -62,13 +64,13 @@ def main():
             i = int(rng.integers(n))
             ref = net_ref.run_graph(desc, w, x[i:i + 1, :, :, :widths[i]])[0].numpy()[0]
             ti = int(tl[i])
-            err = np.abs(outs[0][i, 0, :ti] - ref)
-            okp = np.all((err < 1e-3) | (err < 1e-1 * ref)) and (mid.startswith("V3_") or err.max() < 1e-3) and ref.shape[0] == ti
-            srt = np.sort(ref, -1)
-            clear = (srt[..., -1] - srt[..., -2]) > 0.05 * srt[..., -1]
-            oki = np.array_equal(outs[-1].view(np.int32)[i, 0, :ti, 0][clear], ref.argmax(-1)[clear])
-            if not (okp and oki):
-                bad.append((case, mid, "oracle", n, widths[i], wt, float(err.max())))
+            # the recogniser criterion of the GPU tests (tests/parity.py: log-probabilities of every class, per-step max probability,
+            # arg-max outside near-ties) — the absolute softmax bound this tool held until round 5 predates the live stand-in weights
+            try:
+                assert ref.shape[0] == ti
+                st = check_rec_probs(mid, outs[0][i, 0, :ti], ref, idx=outs[-1].view(np.int32)[i, 0, :ti, 0])
+            except AssertionError as exc:
+                bad.append((case, mid, "oracle", n, widths[i], wt, str(exc)[:160]))
     print(f"fuzz_ragged: {a.cases} cases, seed {a.seed}: {len(bad)} failures", bad[:10])
     return 1 if bad else 0
 
